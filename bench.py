@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- batched MuZero act() env-steps/s at num_simulations=50 (BASELINE.json metric).
+
+A "step" is one batched act(): root inference + 50 simulations of select -> recurrent_fn -> expand
+-> backup + visit-count sampling, for every root of the batch -- ONE launch of the fused gfx950
+kernel.  Workload at N=1: BASELINE configs[1] (CartPole-v1 shapes: obs 4, MLP embed 8, A=2, support
+10, 4096 parallel roots, S=50) with the reference's full semantics on (Dirichlet root noise, mctx's
+threefry tie-break noise, Gumbel sampling from the key).  Inputs are synthetic and already resident in
+HBM when the timed region starts.  For N>1 every rank owns 4096 more roots of one global batch (weak
+scaling, no collective on the data path; RCCL is used only for the barrier and the max-over-ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (roots per GPU, obs_dim, E, A, support, S)
+    "cartpole": (4096, 4, 8, 2, 10, 50),       # BASELINE.json configs[1] -- the metric's config
+    "lunarlander": (8192, 8, 32, 4, 10, 50),   # configs[2]
+}
+
+
+def haiku_style_weights(seed, obs_dim, E, A, F, H=16):
+    """w ~ TruncNormal(sigma = 1/sqrt(fan_in)), b = 0 (hk.Linear default), torch.Generator(seed)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(i, o):
+        w = torch.empty(i, o)
+        torch.nn.init.trunc_normal_(w, 0.0, 1.0, -2.0, 2.0, generator=g)
+        return w / np.sqrt(i)
+
+    z = torch.zeros
+    return {"repr_w": tn(obs_dim, E), "repr_b": z(E),
+            "pv_w1": tn(E, H), "pv_b1": z(H), "pv_w2": tn(H, F), "pv_b2": z(F),
+            "pp_w1": tn(E, H), "pp_b1": z(H), "pp_w2": tn(H, A), "pp_b2": z(A),
+            "dr_w1": tn(E + A, H), "dr_b1": z(H), "dr_w2": tn(H, F), "dr_b2": z(F),
+            "dn_w1": tn(E + A, H), "dn_b1": z(H), "dn_w2": tn(H, E), "dn_b2": z(E)}
+
+
+def algorithmic_bytes(depth_sum_total, roots, S, A, E, obs_dim):
+    """per root D*[4(5A+3)+48] + S*(8E+4A+36) + (4*obs+4E+8A+20), D from the kernel."""
+    return depth_sum_total * (4 * (5 * A + 3) + 48) + roots * (S * (8 * E + 4 * A + 36)
+                                                               + (4 * obs_dim + 4 * E + 8 * A + 20))
+
+
+def cpu_baseline(weights, obs, noise, A, E, F, S, support, budget_s=12.0):
+    """The CPU oracle (a port: our restatement of the mctx semantics, NOT the reference itself --
+    jax/mctx are not installable here) timed on this box's host cores on the same workload."""
+    from oracle import pyoracle as po
+    po.build()
+    w = {k: v.numpy() for k, v in weights.items()}
+    mlp = po.Mlp(w, obs.shape[1], E, A, F, support_size=support)
+    cores = os.cpu_count() or 1
+    B = obs.shape[0]
+    out = {}
+    for label, nthreads in (("1", 1), ("all", cores)):
+        cfg = po.SearchCfg(S, tiebreak=1)
+        tree = po.Tree(B, S + 1, A, E)
+        reps, t_total = 0, 0.0
+        while t_total < budget_s / 2 and reps < 20:
+            t0 = time.perf_counter()
+            po.act_mlp(mlp, cfg, obs, [0, reps], noise, 0.25, None, 1.0, None, nthreads=nthreads, tree=tree)
+            t_total += time.perf_counter() - t0
+            reps += 1
+        out[label] = (B * reps / t_total, reps, t_total)
+    return {"value": round(out["all"][0], 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(out["1"][0], 1),
+            "sample": f"{B} roots x S={S}, {out['all'][1]} acts on {cores} threads ({out['all'][2]:.1f}s) "
+                      f"and {out['1'][1]} acts on 1 thread ({out['1'][2]:.1f}s); gcc -O2 C oracle, "
+                      f"root-major OpenMP"}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cartpole", choices=sorted(WORKLOADS))
+    ap.add_argument("--roots", type=int, default=0, help="roots per GPU (default: the workload's)")
+    ap.add_argument("--no-tiebreak", action="store_true", help="drop mctx's threefry tie-break noise (NOT the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL
+
+    from muax_amd import MuZeroSearch, SearchConfig
+    B, obs_dim, E, A, support, S = WORKLOADS[args.workload]
+    if args.roots:
+        B = args.roots
+    F = 2 * support + 1
+    weights = haiku_style_weights(0, obs_dim, E, A, F)
+    g = torch.Generator().manual_seed(1000 + rank)
+    obs = torch.rand(B, obs_dim, generator=g) * 2 - 1
+    noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)) if A > 1 else torch.ones(B, 1)
+    dev = torch.device("cuda", local_rank)
+    search = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=not args.no_tiebreak,
+                                          global_batch=B * world, root_offset=B * rank), dev)
+    search.set_mlp_weights(weights, obs_dim, support, 0.99)
+    d_obs, d_noise = obs.to(dev), noise.to(dev)
+
+    def step(i):
+        search.act_mlp(d_obs, (0, i), dirichlet_noise=d_noise, dirichlet_fraction=0.25, temperature=1.0)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    depth_total = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record()
+        step(args.warmup + i)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
+    actions = search.action.cpu()
+    assert int(actions.min()) >= 0 and int(actions.max()) < A
+
+    if rank == 0:
+        abytes = algorithmic_bytes(depth_total, B, S, A, E, obs_dim)
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "batched act() env-steps/sec at num_simulations=50",
+            "value": round(B * world * args.steps / elapsed, 1),
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {B} roots/GPU, obs {obs_dim}, MLP embed {E}, A={A}, "
+                                   f"support {support}, num_simulations={S}, dirichlet 0.25/0.3, "
+                                   f"tiebreak={'threefry' if not args.no_tiebreak else 'off'}, temperature 1",
+                       "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(args.workload),
+                         "kernel": "mz_act_fused_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(abytes),
+                         "mean_selection_depth": round(depth_total / (B * S), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, obs.numpy(), noise.numpy(), A, E, F, S, support)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

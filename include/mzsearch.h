@@ -1,0 +1,145 @@
+/*
+ * mzsearch.h -- C-ABI of the MI355X-native batched MuZero search.
+ *
+ * This is the drop-in boundary for the one path this repository accelerates:
+ * what muax.MuZero._plan hands to mctx.muzero_policy (reference
+ * muax/model.py:222-243, muax/policy.py:13-30) and the two callbacks mctx makes
+ * into muax (root inference muax/model.py:251-263, recurrent inference
+ * muax/model.py:265-282).  The reference has no FFI of its own (it is pure
+ * Python on JAX); INTEGRATION.md shows the ctypes stub a muax maintainer would
+ * add.  Plain pointers and sizes only; every pointer is a DEVICE pointer owned
+ * by the caller (PyTorch) unless stated, borrowed for the duration of the call.
+ * All kernels are enqueued on the caller's HIP stream (`stream` is a
+ * hipStream_t passed as void*); no entry point synchronises.
+ *
+ * There is NO CPU fallback behind this ABI: mzs_create fails without a gfx950
+ * device.
+ *
+ * Layout of batched arrays follows mctx: row-major [B], [B,A], [B,E], and for
+ * tree views [B,N], [B,N,A], [B,N,E] with N = num_simulations + 1.
+ */
+#ifndef MZSEARCH_H
+#define MZSEARCH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZS_ABI_VERSION 1
+
+enum {
+  MZS_OK = 0,
+  MZS_E_INVALID = -1,     /* bad argument (shape, null, range) -> ValueError */
+  MZS_E_UNSUPPORTED = -2, /* configuration has no kernel instance             */
+  MZS_E_RUNTIME = -3,     /* HIP runtime error                                 */
+  MZS_E_NODEVICE = -4     /* no gfx950 device                                  */
+};
+
+typedef struct mzs_handle mzs_handle;
+
+/* Search configuration: the keyword arguments of MuZero.act that reach
+ * mctx.muzero_policy (muax/model.py:82-96), plus the batch geometry. */
+typedef struct {
+  int32_t struct_size;     /* sizeof(mzs_config), for ABI checking */
+  int32_t device;          /* HIP device ordinal */
+  int32_t batch;           /* B: roots held by this handle (this GPU's shard) */
+  int32_t num_actions;     /* A */
+  int32_t num_simulations; /* S */
+  int32_t embed_dim;       /* E: flattened embedding elements per node */
+  int32_t max_depth;       /* <= 0: num_simulations (mctx default) */
+  int32_t qtransform;      /* 0: qtransform_by_parent_and_siblings */
+  int32_t tiebreak;        /* 0: none; 1: JAX threefry stream (1e-7 * uniform) */
+  int32_t reserved0;
+  float pb_c_init;         /* 1.25  */
+  float pb_c_base;         /* 19652 */
+  int64_t global_batch;    /* B of the un-sharded batch (PRNG stream layout); 0 -> batch */
+  int64_t root_offset;     /* global index of local root 0 */
+} mzs_config;
+
+/* Weights of the default MLP trio (muax/nn.py:59-115), haiku layout w[in][out],
+ * float32 device pointers. hidden width is 16 as in the reference. */
+typedef struct {
+  int32_t struct_size;
+  int32_t obs_dim;
+  int32_t support_size;       /* F = 2*support_size+1 */
+  int32_t recurrent_pred_on;  /* 0: child embedding (muax/model.py:272); 1: parent (frameworks/coax/model.py:448) */
+  float discount;
+  float reserved0;
+  const float *repr_w, *repr_b;               /* [obs,E] [E]   */
+  const float *pv_w1, *pv_b1, *pv_w2, *pv_b2; /* [E,16] [16] [16,F] [F] */
+  const float *pp_w1, *pp_b1, *pp_w2, *pp_b2; /* [E,16] [16] [16,A] [A] */
+  const float *dr_w1, *dr_b1, *dr_w2, *dr_b2; /* [E+A,16] [16] [16,F] [F] */
+  const float *dn_w1, *dn_b1, *dn_w2, *dn_b2; /* [E+A,16] [16] [16,E] [E] */
+} mzs_mlp_weights;
+
+/* Caller-owned output arrays in mctx.Tree layout (search_tree of PolicyOutput).
+ * Either every pointer is set or the struct pointer is NULL. */
+typedef struct {
+  int32_t *node_visits;            /* [B,N]   */
+  float *raw_values;               /* [B,N]   */
+  float *node_values;              /* [B,N]   */
+  int32_t *parents;                /* [B,N]   */
+  int32_t *action_from_parent;     /* [B,N]   */
+  int32_t *children_index;         /* [B,N,A] */
+  float *children_prior_logits;    /* [B,N,A] */
+  float *children_values;          /* [B,N,A] */
+  int32_t *children_visits;        /* [B,N,A] */
+  float *children_rewards;         /* [B,N,A] */
+  float *children_discounts;       /* [B,N,A] */
+  float *embeddings;               /* [B,N,E] */
+} mzs_tree_view;
+
+/* Per-call arguments of the fused act path. */
+typedef struct {
+  int32_t struct_size;
+  int32_t reserved0;
+  const float *obs;               /* [B,obs_dim] */
+  const float *dirichlet_noise;   /* [B,A] or NULL (then dirichlet_fraction must be 0) */
+  const uint8_t *invalid_actions; /* [B,A] 1 = invalid, or NULL */
+  const float *gumbel;            /* [B,A] or NULL: drawn from `key` as jax.random.categorical */
+  uint32_t key[2];                /* the rng_key given to MuZero.act (HOST values) */
+  float dirichlet_fraction;       /* 0.25 */
+  float temperature;              /* 1.0  */
+  int32_t *action;                /* out [B] */
+  float *action_weights;          /* out [B,A] */
+  float *root_value;              /* out [B]: network value of the root (muax/model.py:243) */
+  float *search_value;            /* out [B] or NULL: node_values[:,0] after search */
+  int32_t *depth_sum;             /* out [B] or NULL: sum over simulations of selection depth */
+  const mzs_tree_view *tree;      /* or NULL */
+} mzs_act_args;
+
+int mzs_abi_version(void);
+const char *mzs_last_error(const mzs_handle *h); /* h may be NULL: last create error */
+
+int mzs_create(const mzs_config *cfg, mzs_handle **out);
+int mzs_destroy(mzs_handle *h);
+
+/* ---- fused path: whole act() for the default MLP trio in one launch ---- */
+int mzs_mlp_set_weights(mzs_handle *h, const mzs_mlp_weights *w);
+int mzs_act_mlp(mzs_handle *h, const mzs_act_args *args, void *stream);
+
+/* ---- step-wise path: any repr/pred/dyn plugin nets run by the caller ----
+ * mzs_root        <- RootFnOutput(prior_logits, value, embedding)  (muax/model.py:258-262)
+ * mzs_select      -> (parent embedding, action) for recurrent_fn   (mctx simulate + expand gather)
+ * mzs_expand_backup <- RecurrentFnOutput + next embedding            (muax/model.py:276-282)
+ * mzs_finish      -> PolicyOutput(action, action_weights)           (mctx summary + categorical)
+ * `key` is the act rng_key (host values); used only when tiebreak != 0 or gumbel == NULL. */
+int mzs_root(mzs_handle *h, const float *prior_logits, const float *value,
+             const float *embedding, const uint8_t *invalid_actions,
+             const float *dirichlet_noise, float dirichlet_fraction,
+             const uint32_t key[2], void *stream);
+int mzs_select(mzs_handle *h, int32_t sim, int32_t *action_out,
+               float *parent_embedding_out, void *stream);
+int mzs_expand_backup(mzs_handle *h, int32_t sim, const float *reward,
+                      const float *discount, const float *prior_logits,
+                      const float *value, const float *next_embedding, void *stream);
+int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
+               int32_t *action_out, float *action_weights_out,
+               float *search_value_out, int32_t *depth_sum_out, void *stream);
+int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""muax_amd -- MI355X-native batched MuZero search behind the muax.MuZero.act() contract.
+
+Only the hot path of bwfbowen/muax is rebuilt here: the
+mctx.muzero_policy loop as hand-written gfx950 HIP kernels behind a C-ABI
+(include/mzsearch.h), and the host-side mirror of the reference interface
+(MuZero.act, the repr_fn/pred_fn/dy_fn plugin surface, the policy adapters).
+"""
+from .search import MuZeroSearch, PolicyOutput, SearchConfig, SearchTree, key_words  # noqa: F401
+
+__version__ = "0.1.0"

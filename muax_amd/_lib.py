@@ -1,0 +1,101 @@
+"""ctypes binding of include/mzsearch.h (the C-ABI of the HIP search library).
+
+The product path has NO CPU fallback: if libmzsearch.so is missing, or there is
+no gfx950 device, the calls below raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+_vp = C.c_void_p  # device pointers travel as integers
+
+MZS_OK, MZS_E_INVALID, MZS_E_UNSUPPORTED, MZS_E_RUNTIME, MZS_E_NODEVICE = 0, -1, -2, -3, -4
+
+
+class MzsConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32),
+                ("num_actions", C.c_int32), ("num_simulations", C.c_int32), ("embed_dim", C.c_int32),
+                ("max_depth", C.c_int32), ("qtransform", C.c_int32), ("tiebreak", C.c_int32),
+                ("reserved0", C.c_int32), ("pb_c_init", C.c_float), ("pb_c_base", C.c_float),
+                ("global_batch", C.c_int64), ("root_offset", C.c_int64)]
+
+
+MLP_WEIGHT_NAMES = ["repr_w", "repr_b", "pv_w1", "pv_b1", "pv_w2", "pv_b2", "pp_w1", "pp_b1", "pp_w2",
+                    "pp_b2", "dr_w1", "dr_b1", "dr_w2", "dr_b2", "dn_w1", "dn_b1", "dn_w2", "dn_b2"]
+
+
+class MzsMlpWeights(C.Structure):
+    _fields_ = ([("struct_size", C.c_int32), ("obs_dim", C.c_int32), ("support_size", C.c_int32),
+                 ("recurrent_pred_on", C.c_int32), ("discount", C.c_float), ("reserved0", C.c_float)]
+                + [(n, _vp) for n in MLP_WEIGHT_NAMES])
+
+
+TREE_FIELDS = ["node_visits", "raw_values", "node_values", "parents", "action_from_parent",
+               "children_index", "children_prior_logits", "children_values", "children_visits",
+               "children_rewards", "children_discounts", "embeddings"]
+TREE_INT_FIELDS = {"node_visits", "parents", "action_from_parent", "children_index", "children_visits"}
+
+
+class MzsTreeView(C.Structure):
+    _fields_ = [(n, _vp) for n in TREE_FIELDS]
+
+
+class MzsActArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("reserved0", C.c_int32), ("obs", _vp),
+                ("dirichlet_noise", _vp), ("invalid_actions", _vp), ("gumbel", _vp),
+                ("key", C.c_uint32 * 2), ("dirichlet_fraction", C.c_float), ("temperature", C.c_float),
+                ("action", _vp), ("action_weights", _vp), ("root_value", _vp), ("search_value", _vp),
+                ("depth_sum", _vp), ("tree", C.POINTER(MzsTreeView))]
+
+
+EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
+                    "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_select", "mzs_expand_backup",
+                    "mzs_finish", "mzs_tree_export"]
+
+_lib = None
+
+
+def load(build_if_missing: bool = True):
+    """Load muax_amd/lib/libmzsearch.so; raises RuntimeError if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: build it with `python -m muax_amd._build`")
+        _build.build()
+    L = C.CDLL(path)
+    L.mzs_abi_version.restype = C.c_int
+    L.mzs_last_error.restype = C.c_char_p
+    L.mzs_last_error.argtypes = [_vp]
+    L.mzs_create.argtypes = [C.POINTER(MzsConfig), C.POINTER(_vp)]
+    L.mzs_destroy.argtypes = [_vp]
+    L.mzs_mlp_set_weights.argtypes = [_vp, C.POINTER(MzsMlpWeights)]
+    L.mzs_act_mlp.argtypes = [_vp, C.POINTER(MzsActArgs), _vp]
+    L.mzs_root.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.POINTER(C.c_uint32 * 2), _vp]
+    L.mzs_select.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
+    L.mzs_expand_backup.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.mzs_finish.argtypes = [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.mzs_tree_export.argtypes = [_vp, C.POINTER(MzsTreeView), _vp]
+    for n in EXPORTED_SYMBOLS[2:]:
+        getattr(L, n).restype = C.c_int
+    if L.mzs_abi_version() != 1:
+        raise RuntimeError("libmzsearch.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(code: int, handle=None):
+    """Map C-ABI status codes onto Python exceptions (ValueError for bad arguments, as the
+    reference raises for bad shapes/arguments; RuntimeError for device failures)."""
+    if code == MZS_OK:
+        return
+    msg = load().mzs_last_error(handle)
+    msg = msg.decode() if msg else f"mzsearch error {code}"
+    if code in (MZS_E_INVALID, MZS_E_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

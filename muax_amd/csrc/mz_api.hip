@@ -1,0 +1,340 @@
+// mz_api.hip -- host side of the C-ABI declared in include/mzsearch.h.
+// Pure HIP runtime: no torch types, no CPU compute fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/mzsearch.h"
+#include "mz_fused.cuh"
+#include "mz_step.cuh"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---- host-side JAX threefry (key bookkeeping only: 3 blocks per simulation) ----
+inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+void h_threefry(const uint32_t key[2], uint32_t x0, uint32_t x1, uint32_t out[2]) {
+  static const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  const uint32_t ks[3] = {key[0], key[1], key[0] ^ key[1] ^ 0x1BD11BDAu};
+  x0 += ks[0];
+  x1 += ks[1];
+  for (int g = 0; g < 5; ++g) {
+    for (int i = 0; i < 4; ++i) {
+      x0 += x1;
+      x1 = rotl32(x1, R[g & 1][i]) ^ x0;
+    }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  out[0] = x0;
+  out[1] = x1;
+}
+uint32_t h_bits(const uint32_t key[2], uint64_t size, uint64_t i) {
+  uint64_t half = (size + 1) / 2;
+  uint64_t blk = i < half ? i : i - half;
+  uint64_t c1 = half + blk;
+  uint32_t out[2];
+  h_threefry(key, (uint32_t)blk, c1 < size ? (uint32_t)c1 : 0u, out);
+  return i < half ? out[0] : out[1];
+}
+void h_split(const uint32_t key[2], uint64_t n, uint64_t row, uint32_t out[2]) {
+  out[0] = h_bits(key, 2 * n, 2 * row);
+  out[1] = h_bits(key, 2 * n, 2 * row + 1);
+}
+
+}  // namespace
+
+struct mzs_handle {
+  mzs_config cfg;
+  std::string err;
+  bool have_weights = false;
+  mzs_mlp_weights w;
+  mz::StepState step;  // device buffers of the step-wise path (lazily allocated)
+  uint32_t k_sample[2] = {0, 0};
+  uint32_t sim_keys[mz::kMaxSims][2];
+};
+
+namespace {
+
+int fail(mzs_handle* h, int code, const char* fmt, const char* a = "") {
+  char buf[512];
+  snprintf(buf, sizeof buf, fmt, a);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+#define MZS_HIP(h, call)                                                   \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess) return fail(h, MZS_E_RUNTIME, #call ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+// mctx muzero_policy / search key walk: (k_sample, k_dirichlet, k_search) = split(key, 3);
+// per simulation (rng, simulate_key, expand_key) = split(rng, 3).
+void derive_keys(mzs_handle* h, const uint32_t key[2]) {
+  uint32_t rk[2];
+  h_split(key, 3, 0, h->k_sample);
+  h_split(key, 3, 2, rk);
+  int S = h->cfg.num_simulations;
+  for (int s = 0; s < S && s < mz::kMaxSims; ++s) {
+    uint32_t nk[2];
+    h_split(rk, 3, 1, h->sim_keys[s]);
+    h_split(rk, 3, 0, nk);
+    rk[0] = nk[0];
+    rk[1] = nk[1];
+  }
+}
+
+template <class C>
+int launch_fused(mzs_handle* h, const mz::FusedParams& p, hipStream_t stream) {
+  static std::once_flag once[16];
+  int dev = h->cfg.device;
+  hipError_t attr_err = hipSuccess;
+  std::call_once(once[dev & 15], [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mz::mz_act_fused_kernel<C>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess)
+    return fail(h, MZS_E_RUNTIME, "hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+  int grid = (p.B + C::ROOTS_PER_WG - 1) / C::ROOTS_PER_WG;
+  hipLaunchKernelGGL(mz::mz_act_fused_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, p);
+  MZS_HIP(h, hipGetLastError());
+  return MZS_OK;
+}
+
+template <int A, int E, int F, int NMAX, int WAVES>
+int dispatch_tb(mzs_handle* h, const mz::FusedParams& p, hipStream_t stream) {
+  if (h->cfg.tiebreak) return launch_fused<mz::FusedCfg<A, E, F, NMAX, true, WAVES>>(h, p, stream);
+  return launch_fused<mz::FusedCfg<A, E, F, NMAX, false, WAVES>>(h, p, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mzs_abi_version(void) { return MZS_ABI_VERSION; }
+
+const char* mzs_last_error(const mzs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mzs_create(const mzs_config* cfg, mzs_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MZS_E_INVALID, "mzs_create: null argument");
+  if (cfg->struct_size != (int32_t)sizeof(mzs_config))
+    return fail(nullptr, MZS_E_INVALID, "mzs_create: mzs_config size mismatch (ABI)");
+  if (cfg->batch <= 0 || cfg->num_actions <= 0 || cfg->num_simulations <= 0 || cfg->embed_dim <= 0)
+    return fail(nullptr, MZS_E_INVALID, "mzs_create: batch, num_actions, num_simulations, embed_dim must be positive");
+  if (cfg->num_actions > 64) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: num_actions > 64");
+  if (cfg->num_simulations >= 65535) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: num_simulations too large");
+  if (cfg->qtransform != 0) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: only qtransform_by_parent_and_siblings");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MZS_E_NODEVICE, "mzs_create: no HIP device (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_create: bad device ordinal");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, MZS_E_RUNTIME, "mzs_create: hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, MZS_E_NODEVICE, "mzs_create: device is %s, kernels are built for gfx950 only", prop.gcnArchName);
+  mzs_handle* h = new mzs_handle();
+  h->cfg = *cfg;
+  if (h->cfg.global_batch <= 0) h->cfg.global_batch = cfg->batch;
+  if (h->cfg.root_offset < 0 || h->cfg.root_offset + cfg->batch > h->cfg.global_batch) {
+    delete h;
+    return fail(nullptr, MZS_E_INVALID, "mzs_create: root_offset + batch exceeds global_batch");
+  }
+  memset(&h->w, 0, sizeof h->w);
+  *out = h;
+  return MZS_OK;
+}
+
+int mzs_destroy(mzs_handle* h) {
+  if (!h) return MZS_OK;
+  hipSetDevice(h->cfg.device);
+  h->step.release();
+  delete h;
+  return MZS_OK;
+}
+
+int mzs_mlp_set_weights(mzs_handle* h, const mzs_mlp_weights* w) {
+  if (!h) return MZS_E_INVALID;
+  if (!w || w->struct_size != (int32_t)sizeof(mzs_mlp_weights))
+    return fail(h, MZS_E_INVALID, "mzs_mlp_set_weights: null or size mismatch (ABI)");
+  const float* const* ptrs = &w->repr_w;
+  for (int i = 0; i < 18; ++i)
+    if (!ptrs[i]) return fail(h, MZS_E_INVALID, "mzs_mlp_set_weights: null weight pointer");
+  if (w->obs_dim <= 0 || w->support_size <= 0) return fail(h, MZS_E_INVALID, "mzs_mlp_set_weights: obs_dim/support_size");
+  h->w = *w;
+  h->have_weights = true;
+  return MZS_OK;
+}
+
+int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_act_args))
+    return fail(h, MZS_E_INVALID, "mzs_act_mlp: null or size mismatch (ABI)");
+  if (!h->have_weights) return fail(h, MZS_E_INVALID, "mzs_act_mlp: call mzs_mlp_set_weights first");
+  if (!a->obs || !a->action || !a->action_weights || !a->root_value)
+    return fail(h, MZS_E_INVALID, "mzs_act_mlp: obs/action/action_weights/root_value must be set");
+  if (!a->dirichlet_noise && a->dirichlet_fraction != 0.0f)
+    return fail(h, MZS_E_INVALID, "mzs_act_mlp: dirichlet_fraction != 0 needs dirichlet_noise");
+  const mzs_config& c = h->cfg;
+  if (c.num_simulations > mz::kMaxSims) return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: num_simulations > 256 (use the step-wise path)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+
+  mz::FusedParams p;
+  memset(&p, 0, sizeof p);
+  p.obs = a->obs; p.dirichlet_noise = a->dirichlet_noise; p.invalid = a->invalid_actions; p.gumbel = a->gumbel;
+  const mzs_mlp_weights& w = h->w;
+  p.repr_w = w.repr_w; p.repr_b = w.repr_b;
+  p.pv_w1 = w.pv_w1; p.pv_b1 = w.pv_b1; p.pv_w2 = w.pv_w2; p.pv_b2 = w.pv_b2;
+  p.pp_w1 = w.pp_w1; p.pp_b1 = w.pp_b1; p.pp_w2 = w.pp_w2; p.pp_b2 = w.pp_b2;
+  p.dr_w1 = w.dr_w1; p.dr_b1 = w.dr_b1; p.dr_w2 = w.dr_w2; p.dr_b2 = w.dr_b2;
+  p.dn_w1 = w.dn_w1; p.dn_b1 = w.dn_b1; p.dn_w2 = w.dn_w2; p.dn_b2 = w.dn_b2;
+  p.action = a->action; p.action_weights = a->action_weights; p.root_value = a->root_value;
+  p.search_value = a->search_value; p.depth_sum = a->depth_sum;
+  if (a->tree) {
+    const mzs_tree_view& t = *a->tree;
+    const void* const* tp = reinterpret_cast<const void* const*>(&t);
+    for (int i = 0; i < 12; ++i)
+      if (!tp[i]) return fail(h, MZS_E_INVALID, "mzs_act_mlp: tree view has a null array");
+    p.t_node_visits = t.node_visits; p.t_raw_values = t.raw_values; p.t_node_values = t.node_values;
+    p.t_parents = t.parents; p.t_action_from_parent = t.action_from_parent;
+    p.t_children_index = t.children_index; p.t_children_prior_logits = t.children_prior_logits;
+    p.t_children_values = t.children_values; p.t_children_visits = t.children_visits;
+    p.t_children_rewards = t.children_rewards; p.t_children_discounts = t.children_discounts;
+    p.t_embeddings = t.embeddings;
+    p.export_tree = 1;
+  }
+  p.B = c.batch; p.obs_dim = w.obs_dim; p.S = c.num_simulations; p.max_depth = c.max_depth;
+  p.support = w.support_size; p.pred_on_parent = w.recurrent_pred_on;
+  p.pb_c_init = c.pb_c_init; p.pb_c_base = c.pb_c_base;
+  p.dirichlet_fraction = a->dirichlet_fraction; p.discount = w.discount; p.temperature = a->temperature;
+  p.global_batch = (uint64_t)c.global_batch; p.root_offset = (uint64_t)c.root_offset;
+  derive_keys(h, a->key);
+  p.k_sample[0] = h->k_sample[0]; p.k_sample[1] = h->k_sample[1];
+  memcpy(p.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)c.num_simulations);
+
+  const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, N = c.num_simulations + 1;
+#define MZS_INST(A_, E_, F_, NMAX_, WAVES_) \
+  if (A == A_ && E == E_ && F == F_ && N <= NMAX_) return dispatch_tb<A_, E_, F_, NMAX_, WAVES_>(h, p, stream);
+  MZS_INST(2, 8, 21, 51, 4)    // CartPole   (BASELINE cfg1/cfg2; README.md:102-132)
+  MZS_INST(4, 32, 21, 51, 2)   // LunarLander (BASELINE cfg3)
+  MZS_INST(3, 8, 21, 33, 4)    // odd action count (tests)
+  MZS_INST(4, 8, 21, 51, 4)
+#undef MZS_INST
+  return fail(h, MZS_E_UNSUPPORTED,
+              "mzs_act_mlp: no fused kernel instance for this (A, E, F, S); use the step-wise path");
+}
+
+// ---------------------------------------------------------------------------
+// step-wise path
+// ---------------------------------------------------------------------------
+
+int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const float* embedding,
+             const uint8_t* invalid_actions, const float* dirichlet_noise, float dirichlet_fraction,
+             const uint32_t key[2], void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!prior_logits || !value || !embedding) return fail(h, MZS_E_INVALID, "mzs_root: null input");
+  if (!dirichlet_noise && dirichlet_fraction != 0.0f)
+    return fail(h, MZS_E_INVALID, "mzs_root: dirichlet_fraction != 0 needs dirichlet_noise");
+  const mzs_config& c = h->cfg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  if (!h->step.allocated) {
+    hipError_t e = h->step.allocate(c.batch, c.num_simulations + 1, c.num_actions, c.embed_dim);
+    if (e != hipSuccess) return fail(h, MZS_E_RUNTIME, "mzs_root: tree allocation: %s", hipGetErrorString(e));
+  }
+  uint32_t zero[2] = {0, 0};
+  derive_keys(h, key ? key : zero);
+  if (c.tiebreak) {
+    MZS_HIP(h, hipMemcpyAsync(h->step.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)c.num_simulations,
+                              hipMemcpyHostToDevice, stream));
+  }
+  mz::StepArgs sa = h->step.args(c);
+  hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
+                     value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction);
+  MZS_HIP(h, hipGetLastError());
+  h->step.rooted = true;
+  return MZS_OK;
+}
+
+int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_embedding_out, void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "mzs_select: call mzs_root first");
+  if (sim < 0 || sim >= h->cfg.num_simulations) return fail(h, MZS_E_INVALID, "mzs_select: sim out of range");
+  if (!action_out || !parent_embedding_out) return fail(h, MZS_E_INVALID, "mzs_select: null output");
+  const mzs_config& c = h->cfg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  mz::StepArgs sa = h->step.args(c);
+  hipLaunchKernelGGL(mz::step_select_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+                     action_out, parent_embedding_out);
+  MZS_HIP(h, hipGetLastError());
+  return MZS_OK;
+}
+
+int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const float* discount,
+                      const float* prior_logits, const float* value, const float* next_embedding,
+                      void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "mzs_expand_backup: call mzs_root first");
+  if (sim < 0 || sim >= h->cfg.num_simulations) return fail(h, MZS_E_INVALID, "mzs_expand_backup: sim out of range");
+  if (!reward || !discount || !prior_logits || !value || !next_embedding)
+    return fail(h, MZS_E_INVALID, "mzs_expand_backup: null input");
+  const mzs_config& c = h->cfg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  mz::StepArgs sa = h->step.args(c);
+  hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+                     reward, discount, prior_logits, value, next_embedding);
+  MZS_HIP(h, hipGetLastError());
+  return MZS_OK;
+}
+
+int mzs_finish(mzs_handle* h, float temperature, const float* gumbel, int32_t* action_out,
+               float* action_weights_out, float* search_value_out, int32_t* depth_sum_out, void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "mzs_finish: call mzs_root first");
+  if (!action_out || !action_weights_out) return fail(h, MZS_E_INVALID, "mzs_finish: null output");
+  const mzs_config& c = h->cfg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  mz::StepArgs sa = h->step.args(c);
+  hipLaunchKernelGGL(mz::step_finish_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, temperature,
+                     gumbel, h->k_sample[0], h->k_sample[1], action_out, action_weights_out, search_value_out,
+                     depth_sum_out);
+  MZS_HIP(h, hipGetLastError());
+  return MZS_OK;
+}
+
+int mzs_tree_export(mzs_handle* h, const mzs_tree_view* out, void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "mzs_tree_export: no step-wise tree (call mzs_root first)");
+  if (!out) return fail(h, MZS_E_INVALID, "mzs_tree_export: null view");
+  const void* const* tp = reinterpret_cast<const void* const*>(out);
+  for (int i = 0; i < 12; ++i)
+    if (!tp[i]) return fail(h, MZS_E_INVALID, "mzs_tree_export: tree view has a null array");
+  const mzs_config& c = h->cfg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  const size_t BN = (size_t)c.batch * (c.num_simulations + 1);
+  const mz::StepState& s = h->step;
+#define CP(dst, src, n) MZS_HIP(h, hipMemcpyAsync(dst, src, (n) * 4, hipMemcpyDeviceToDevice, stream))
+  CP(out->node_visits, s.node_visits, BN); CP(out->raw_values, s.raw_values, BN);
+  CP(out->node_values, s.node_values, BN); CP(out->parents, s.parents, BN);
+  CP(out->action_from_parent, s.action_from_parent, BN);
+  CP(out->children_index, s.children_index, BN * c.num_actions);
+  CP(out->children_prior_logits, s.children_prior_logits, BN * c.num_actions);
+  CP(out->children_values, s.children_values, BN * c.num_actions);
+  CP(out->children_visits, s.children_visits, BN * c.num_actions);
+  CP(out->children_rewards, s.children_rewards, BN * c.num_actions);
+  CP(out->children_discounts, s.children_discounts, BN * c.num_actions);
+  CP(out->embeddings, s.embeddings, BN * c.embed_dim);
+#undef CP
+  return MZS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// mz_spec.cuh -- device-side arithmetic spec "MZ-F32" and CDNA4 row primitives.
+//
+// One search root is owned by one DPP row (16 lanes of a 64-wide wavefront), so
+// every cross-lane exchange on the path is a DPP modifier on a VALU op -- no LDS
+// round trip, no ds_bpermute.  All float arithmetic is IEEE binary32 RN
+// (+,-,*,/,sqrt,fma; -ffp-contract=off, fused multiply-adds only where written
+// as __builtin_fmaf); exp/log are spelled out so that results do not depend on
+// a device math library.  The reduction order of every float sum is the
+// "canonical 16-wide sum": 16 partials p_l = x_l + x_{l+16} + ... then an xor
+// butterfly over 1,2,4,8 -- which is exactly what the DPP butterfly below does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace mz {
+
+#define MZ_DEV __device__ __forceinline__
+
+constexpr float kFltTiny = 1.17549435e-38f;
+constexpr float kFltLowest = -3.40282347e+38f;
+
+template <int I, int N>
+struct StaticFor {
+  template <class Fn>
+  static MZ_DEV void run(Fn&& f) {
+    f(std::integral_constant<int, I>{});
+    StaticFor<I + 1, N>::run(f);
+  }
+};
+template <int N>
+struct StaticFor<N, N> {
+  template <class Fn>
+  static MZ_DEV void run(Fn&&) {}
+};
+
+MZ_DEV float u2f(uint32_t u) { return __uint_as_float(u); }
+MZ_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// ---------------------------------------------------------------------------
+// DPP row primitives (a row = 16 consecutive lanes)
+// ---------------------------------------------------------------------------
+constexpr int kDppXor1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror (== xor 4 once quads are uniform)
+constexpr int kDppMirror = 0x140;     // row_mirror      (== xor 8 once halves are uniform)
+constexpr int kDppBcast0 = 0x150;     // row_newbcast:0 (gfx90a+)
+
+template <int CTRL>
+MZ_DEV int dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+MZ_DEV float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// value of lane I of this row, in every lane of the row
+template <int I>
+MZ_DEV float bcast(float x) { return dpp_f<kDppBcast0 + I>(x); }
+template <int I>
+MZ_DEV int bcast_i(int x) { return dpp_i<kDppBcast0 + I>(x); }
+template <int I>
+MZ_DEV uint32_t bcast_u(uint32_t x) { return (uint32_t)dpp_i<kDppBcast0 + I>((int)x); }
+
+template <int STEP>
+struct Bfly;
+template <> struct Bfly<0> { static constexpr int ctrl = kDppXor1; };
+template <> struct Bfly<1> { static constexpr int ctrl = kDppXor2; };
+template <> struct Bfly<2> { static constexpr int ctrl = kDppHalfMirror; };
+template <> struct Bfly<3> { static constexpr int ctrl = kDppMirror; };
+
+constexpr int ceil_log2(int n) { return n <= 1 ? 0 : 1 + ceil_log2((n + 1) / 2); }
+
+// canonical 16-wide sum of the per-lane partials (all 4 butterfly steps)
+MZ_DEV float row_sum(float p) {
+  p = p + dpp_f<kDppXor1>(p);
+  p = p + dpp_f<kDppXor2>(p);
+  p = p + dpp_f<kDppHalfMirror>(p);
+  p = p + dpp_f<kDppMirror>(p);
+  return p;
+}
+// max / min over the first 2^STEPS-aligned group of lanes (order independent)
+template <int STEPS>
+MZ_DEV float row_max(float x) {
+  StaticFor<0, STEPS>::run([&](auto ic) {
+    constexpr int s = decltype(ic)::value;
+    x = fmaxf(x, dpp_f<Bfly<s>::ctrl>(x));
+  });
+  return x;
+}
+template <int STEPS>
+MZ_DEV float row_min(float x) {
+  StaticFor<0, STEPS>::run([&](auto ic) {
+    constexpr int s = decltype(ic)::value;
+    x = fminf(x, dpp_f<Bfly<s>::ctrl>(x));
+  });
+  return x;
+}
+MZ_DEV int row_sum_i(int p) {
+  p = p + dpp_i<kDppXor1>(p);
+  p = p + dpp_i<kDppXor2>(p);
+  p = p + dpp_i<kDppHalfMirror>(p);
+  p = p + dpp_i<kDppMirror>(p);
+  return p;
+}
+// first-max argmax over (score, index) with a payload riding along
+template <int STEPS>
+MZ_DEV void row_argmax(float& score, int& idx, int& payload) {
+  StaticFor<0, STEPS>::run([&](auto ic) {
+    constexpr int s = decltype(ic)::value;
+    float os = dpp_f<Bfly<s>::ctrl>(score);
+    int oi = dpp_i<Bfly<s>::ctrl>(idx);
+    int op = dpp_i<Bfly<s>::ctrl>(payload);
+    bool take = (os > score) || (os == score && oi < idx);
+    score = take ? os : score;
+    idx = take ? oi : idx;
+    payload = take ? op : payload;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// MZ-F32 scalar math
+// ---------------------------------------------------------------------------
+MZ_DEV float exp_core(float x, int& k) {
+  const float LOG2E = 1.44269504088896341f;
+  const float LN2_HI = 6.93145752e-1f;
+  const float LN2_LO = 1.42860677e-6f;
+  float kf = __builtin_rintf(x * LOG2E);
+  float r = __builtin_fmaf(kf, -LN2_HI, x);
+  r = __builtin_fmaf(kf, -LN2_LO, r);
+  float p = 1.0f / 5040.0f;
+  p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+  p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+  p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+  p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  float rr = r * r;
+  k = (int)kf;
+  return __builtin_fmaf(p, rr, r);
+}
+MZ_DEV float pow2i(int k) { return u2f((uint32_t)(k + 127) << 23); }
+
+MZ_DEV float exp_neg(float x) {  // x <= 88; exact 0 below -87
+  int k;
+  float q = exp_core(fmaxf(x, -87.0f), k);
+  float e = (1.0f + q) * pow2i(k);
+  return x < -87.0f ? 0.0f : e;
+}
+MZ_DEV float elu(float x) {  // jax.nn.elu, alpha = 1
+  float xn = fminf(x, 0.0f);
+  int k;
+  float q = exp_core(fmaxf(xn, -87.0f), k);
+  float em1 = (k == 0) ? q : (1.0f + q) * pow2i(k) - 1.0f;
+  em1 = xn < -87.0f ? -1.0f : em1;
+  return x > 0.0f ? x : em1;
+}
+MZ_DEV float log_pos(float x) {  // x > 0, normal
+  const float LN2_HI = 6.9313812256e-01f;
+  const float LN2_LO = 9.0580006145e-06f;
+  const float LG1 = 0.66666662693f, LG2 = 0.40000972152f;
+  const float LG3 = 0.28498786688f, LG4 = 0.24279078841f;
+  uint32_t ix = f2u(x);
+  ix += 0x3f800000u - 0x3f3504f3u;
+  int e = (int)(ix >> 23) - 127;
+  ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+  float m = u2f(ix);
+  float f = m - 1.0f;
+  float s = f / (2.0f + f);
+  float z = s * s;
+  float w = z * z;
+  float t1 = w * (LG2 + w * LG4);
+  float t2 = z * (LG1 + w * LG3);
+  float R = t2 + t1;
+  float hfsq = (0.5f * f) * f;
+  float dk = (float)e;
+  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+MZ_DEV float inv_scaling(float x) {  // muax/utils.py:70-76, eps = 1e-3
+  float ax = fabsf(x);
+  float a = (ax + 1.0f) + 0.001f;
+  float b = 0.004f * a;
+  float c = 1.0f + b;
+  float d = sqrtf(c);
+  float e = (d - 1.0f) / 0.002f;
+  float g = e * e - 1.0f;
+  float sgn = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+  return sgn * g;
+}
+// sqrt(n) * (pb_c_init + log((n + base + 1) / base)), mctx muzero_action_selection
+MZ_DEV float puct_scale(int n, float pb_c_init, float pb_c_base) {
+  float num = ((float)n + pb_c_base) + 1.0f;
+  float pb_c = pb_c_init + log_pos(num / pb_c_base);
+  return sqrtf((float)n) * pb_c;
+}
+
+// ---------------------------------------------------------------------------
+// JAX threefry2x32 (non-partitionable stream)
+// ---------------------------------------------------------------------------
+MZ_DEV void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+#define MZ_TF_ROUND(r)                       \
+  x0 += x1;                                  \
+  x1 = __builtin_rotateleft32(x1, r) ^ x0;
+  x0 += k0; x1 += k1;
+  MZ_TF_ROUND(13) MZ_TF_ROUND(15) MZ_TF_ROUND(26) MZ_TF_ROUND(6)
+  x0 += k1; x1 += k2 + 1u;
+  MZ_TF_ROUND(17) MZ_TF_ROUND(29) MZ_TF_ROUND(16) MZ_TF_ROUND(24)
+  x0 += k2; x1 += k0 + 2u;
+  MZ_TF_ROUND(13) MZ_TF_ROUND(15) MZ_TF_ROUND(26) MZ_TF_ROUND(6)
+  x0 += k0; x1 += k1 + 3u;
+  MZ_TF_ROUND(17) MZ_TF_ROUND(29) MZ_TF_ROUND(16) MZ_TF_ROUND(24)
+  x0 += k1; x1 += k2 + 4u;
+  MZ_TF_ROUND(13) MZ_TF_ROUND(15) MZ_TF_ROUND(26) MZ_TF_ROUND(6)
+  x0 += k2; x1 += k0 + 5u;
+#undef MZ_TF_ROUND
+}
+// counters of the block that produces flat[i] of threefry_2x32(key, iota(size))
+MZ_DEV void bits_block(uint64_t size, uint64_t i, uint32_t& x0, uint32_t& x1, bool& second) {
+  uint64_t half = (size + 1) >> 1;
+  second = i >= half;
+  uint64_t blk = second ? i - half : i;
+  uint64_t c1 = half + blk;
+  x0 = (uint32_t)blk;
+  x1 = c1 < size ? (uint32_t)c1 : 0u;
+}
+MZ_DEV float uniform_from_bits(uint32_t bits) { return u2f((bits >> 9) | 0x3f800000u) - 1.0f; }
+MZ_DEV float gumbel_from_bits(uint32_t bits) {
+  float u = uniform_from_bits(bits);
+  u = u * (1.0f - kFltTiny) + kFltTiny;
+  u = fmaxf(u, kFltTiny);
+  return -log_pos(-log_pos(u));
+}
+
+}  // namespace mz

@@ -1,0 +1,393 @@
+// mz_step.cuh -- step-wise search for ARBITRARY plugin nets (the repr_fn /
+// pred_fn / dy_fn surface of muax/model.py:52-54): the caller runs its own
+// networks between mzs_select and mzs_expand_backup, exactly where mctx calls
+// recurrent_fn (mctx search.expand).  The tree lives in HBM in mctx's own
+// layout so that PolicyOutput.search_tree is a plain copy.  Same row mapping
+// and arithmetic spec as the fused kernel; A and E are run-time (A <= 64).
+#pragma once
+#include "../../include/mzsearch.h"
+#include "mz_spec.cuh"
+
+#pragma clang fp contract(off)
+
+namespace mz {
+
+constexpr int kMaxAS = 4;  // action slots per lane (A <= 64)
+
+struct StepArgs {
+  int32_t B, N, A, E, S, max_depth, tiebreak;
+  float pb_c_init, pb_c_base;
+  uint64_t global_batch, root_offset;
+  int32_t* node_visits; float* raw_values; float* node_values;
+  int32_t* parents; int32_t* action_from_parent;
+  int32_t* children_index; float* children_prior_logits; float* children_prior_probs;
+  float* children_values; int32_t* children_visits; float* children_rewards;
+  float* children_discounts; float* embeddings;
+  uint8_t* root_invalid;
+  int32_t *sel_parent, *sel_action, *sel_depth, *depth_sum, *path;
+  const uint32_t* sim_keys;
+};
+
+struct StepState {
+  bool allocated = false, rooted = false;
+  int32_t* node_visits = nullptr; float* raw_values = nullptr; float* node_values = nullptr;
+  int32_t* parents = nullptr; int32_t* action_from_parent = nullptr;
+  int32_t* children_index = nullptr; float* children_prior_logits = nullptr;
+  float* children_prior_probs = nullptr; float* children_values = nullptr;
+  int32_t* children_visits = nullptr; float* children_rewards = nullptr;
+  float* children_discounts = nullptr; float* embeddings = nullptr;
+  uint8_t* root_invalid = nullptr;
+  int32_t *sel_parent = nullptr, *sel_action = nullptr, *sel_depth = nullptr, *depth_sum = nullptr,
+          *path = nullptr;
+  uint32_t* sim_keys = nullptr;
+  void* slab = nullptr;
+
+  // one slab, carved: the only allocation the handle ever makes
+  hipError_t allocate(int B, int N, int A, int E) {
+    size_t BN = (size_t)B * N;
+    size_t words = 5 * BN + 7 * BN * A + BN * E + 4 * (size_t)B + BN + 2 * (size_t)N;
+    size_t bytes = words * 4 + (size_t)B * A + 256;
+    hipError_t e = hipMalloc(&slab, bytes);
+    if (e != hipSuccess) return e;
+    uint32_t* w = static_cast<uint32_t*>(slab);
+    auto take = [&](size_t n) { uint32_t* p = w; w += n; return p; };
+    node_visits = (int32_t*)take(BN); raw_values = (float*)take(BN); node_values = (float*)take(BN);
+    parents = (int32_t*)take(BN); action_from_parent = (int32_t*)take(BN);
+    children_index = (int32_t*)take(BN * A); children_prior_logits = (float*)take(BN * A);
+    children_prior_probs = (float*)take(BN * A); children_values = (float*)take(BN * A);
+    children_visits = (int32_t*)take(BN * A); children_rewards = (float*)take(BN * A);
+    children_discounts = (float*)take(BN * A); embeddings = (float*)take(BN * E);
+    sel_parent = (int32_t*)take(B); sel_action = (int32_t*)take(B); sel_depth = (int32_t*)take(B);
+    depth_sum = (int32_t*)take(B); path = (int32_t*)take(BN); sim_keys = take(2 * (size_t)N);
+    root_invalid = reinterpret_cast<uint8_t*>(w);
+    allocated = true;
+    return hipSuccess;
+  }
+  void release() {
+    if (slab) hipFree(slab);
+    slab = nullptr;
+    allocated = rooted = false;
+  }
+  StepArgs args(const mzs_config& c) const {
+    StepArgs a;
+    a.B = c.batch; a.N = c.num_simulations + 1; a.A = c.num_actions; a.E = c.embed_dim;
+    a.S = c.num_simulations; a.max_depth = c.max_depth > 0 ? c.max_depth : c.num_simulations;
+    a.tiebreak = c.tiebreak; a.pb_c_init = c.pb_c_init; a.pb_c_base = c.pb_c_base;
+    a.global_batch = (uint64_t)c.global_batch; a.root_offset = (uint64_t)c.root_offset;
+    a.node_visits = node_visits; a.raw_values = raw_values; a.node_values = node_values;
+    a.parents = parents; a.action_from_parent = action_from_parent;
+    a.children_index = children_index; a.children_prior_logits = children_prior_logits;
+    a.children_prior_probs = children_prior_probs; a.children_values = children_values;
+    a.children_visits = children_visits; a.children_rewards = children_rewards;
+    a.children_discounts = children_discounts; a.embeddings = embeddings;
+    a.root_invalid = root_invalid;
+    a.sel_parent = sel_parent; a.sel_action = sel_action; a.sel_depth = sel_depth;
+    a.depth_sum = depth_sum; a.path = path; a.sim_keys = sim_keys;
+    return a;
+  }
+};
+
+// canonical softmax over a row-distributed vector with run-time length A
+MZ_DEV void row_softmax_rt(const float (&x)[kMaxAS], int A, int j, float (&p)[kMaxAS]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) m = (j + 16 * t < A) ? fmaxf(m, x[t]) : m;
+  m = row_max<4>(m);
+  float e[kMaxAS];
+  float part = 0.0f;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    bool ok = j + 16 * t < A;
+    e[t] = ok ? exp_neg(x[t] - m) : 0.0f;
+    part = (t == 0) ? e[0] : (ok ? part + e[t] : part);
+  }
+  float s = row_sum(part);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) p[t] = e[t] / s;
+}
+
+#define MZ_ROW_SETUP                                              \
+  const int lane = threadIdx.x & 63;                              \
+  const int j = lane & 15;                                        \
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4); \
+  if (r >= s.B) return;                                           \
+  const int N = s.N, A = s.A, E = s.E;                            \
+  const size_t rb = (size_t)r * N;
+
+// mctx instantiate_tree_from_root + muzero_policy prelude (dirichlet, mask)
+__global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float* prior_logits,
+                                                         const float* value, const float* embedding,
+                                                         const uint8_t* invalid, const float* noise,
+                                                         float fraction) {
+  MZ_ROW_SETUP
+  for (int n = j; n < N; n += 16) {
+    s.node_visits[rb + n] = 0;
+    s.raw_values[rb + n] = 0.0f;
+    s.node_values[rb + n] = 0.0f;
+    s.parents[rb + n] = -1;
+    s.action_from_parent[rb + n] = -1;
+  }
+  for (int i = j; i < N * A; i += 16) {
+    size_t o = rb * A + i;
+    s.children_index[o] = -1;
+    s.children_prior_logits[o] = 0.0f;
+    s.children_prior_probs[o] = 0.0f;
+    s.children_values[o] = 0.0f;
+    s.children_visits[o] = 0;
+    s.children_rewards[o] = 0.0f;
+    s.children_discounts[o] = 0.0f;
+  }
+  for (size_t i = j; i < (size_t)N * E; i += 16) s.embeddings[rb * E + i] = 0.0f;
+  float x[kMaxAS], pr[kMaxAS], lg[kMaxAS];
+  bool inv[kMaxAS];
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    x[t] = a < A ? prior_logits[(size_t)r * A + a] : 0.0f;
+    inv[t] = (invalid != nullptr && a < A) ? invalid[(size_t)r * A + a] != 0 : false;
+    if (a < A) s.root_invalid[(size_t)r * A + a] = inv[t] ? 1 : 0;
+  }
+  row_softmax_rt(x, A, j, pr);
+  float keep = 1.0f - fraction;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    float nz = (noise != nullptr && a < A) ? noise[(size_t)r * A + a] : 0.0f;
+    float noisy = keep * pr[t] + fraction * nz;
+    lg[t] = log_pos(fmaxf(noisy, kFltTiny));
+    mx = a < A ? fmaxf(mx, lg[t]) : mx;
+  }
+  if (invalid != nullptr) {
+    mx = row_max<4>(mx);
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) lg[t] = inv[t] ? kFltLowest : lg[t] - mx;
+  }
+  float pq[kMaxAS];
+  row_softmax_rt(lg, A, j, pq);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    if (a < A) {
+      s.children_prior_logits[rb * A + a] = lg[t];
+      s.children_prior_probs[rb * A + a] = pq[t];
+    }
+  }
+  for (int i = j; i < E; i += 16) s.embeddings[rb * E + i] = embedding[(size_t)r * E + i];
+  if (j == 0) {
+    s.node_visits[rb] = 1;
+    s.raw_values[rb] = value[r];
+    s.node_values[rb] = value[r];
+    s.depth_sum[r] = 0;
+  }
+}
+
+// mctx search.simulate (+ the parent-embedding gather of search.expand)
+__global__ __launch_bounds__(256) void step_select_kernel(StepArgs s, int sim, int32_t* action_out,
+                                                           float* parent_embedding_out) {
+  MZ_ROW_SETUP
+  const uint64_t rg = s.root_offset + (uint64_t)r;
+  uint32_t k0 = 0, k1 = 0;
+  if (s.tiebreak) {
+    uint32_t x0, x1;
+    bool second;
+    bits_block(2 * s.global_batch, 2 * rg + (uint64_t)(j & 1), x0, x1, second);
+    threefry2x32(s.sim_keys[2 * sim], s.sim_keys[2 * sim + 1], x0, x1);
+    uint32_t word = second ? x1 : x0;
+    k0 = bcast_u<0>(word);
+    k1 = bcast_u<1>(word);
+  }
+  const int NB = (A + 1) / 2;
+  int node = 0, depth = 0, parent = 0, action = 0;
+  for (;;) {
+    const size_t nb = (rb + node) * A;
+    int nvis = s.node_visits[rb + node];
+    float nval = s.node_values[rb + node];
+    float tn = puct_scale(nvis, s.pb_c_init, s.pb_c_base);
+    uint32_t s0 = 0, s1 = 0;
+    if (s.tiebreak) {
+      // rng_key, action_selection_key = split(rng_key)
+      uint32_t x0 = (uint32_t)(j & 1), x1 = 2u + (uint32_t)(j & 1);
+      threefry2x32(k0, k1, x0, x1);
+      k0 = bcast_u<0>(x0); k1 = bcast_u<1>(x0);
+      s0 = bcast_u<0>(x1); s1 = bcast_u<1>(x1);
+    }
+    float q[kMaxAS];
+    int cidx[kMaxAS], cvis[kMaxAS];
+    float prob[kMaxAS];
+    float lo = nval, hi = nval;
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      int a = j + 16 * t;
+      bool ok = a < A;
+      size_t o = nb + (ok ? a : 0);
+      cidx[t] = s.children_index[o];
+      cvis[t] = s.children_visits[o];
+      prob[t] = s.children_prior_probs[o];
+      q[t] = s.children_rewards[o] + s.children_discounts[o] * s.children_values[o];
+      float safe = (ok && cvis[t] > 0) ? q[t] : nval;
+      lo = fminf(lo, safe);
+      hi = fmaxf(hi, safe);
+    }
+    lo = row_min<4>(lo);
+    hi = row_max<4>(hi);
+    float span = fmaxf(hi - lo, 1e-8f);
+    float bscore = -INFINITY;
+    int best = 1 << 20, bnext = -1;
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      int a = j + 16 * t;
+      bool ok = a < A;
+      float value_score = ((cvis[t] > 0 ? q[t] : lo) - lo) / span;
+      float policy_score = (tn * prob[t]) / (float)(cvis[t] + 1);
+      float score = value_score + policy_score;
+      if (s.tiebreak) {
+        int jb = a < NB ? a : a - NB;
+        uint32_t x0 = (uint32_t)jb, x1 = (NB + jb < A) ? (uint32_t)(NB + jb) : 0u;
+        threefry2x32(s0, s1, x0, x1);
+        score = score + 1e-7f * uniform_from_bits(a < NB ? x0 : x1);
+      }
+      if (depth == 0 && ok && s.root_invalid[(size_t)r * A + a]) score = -INFINITY;
+      if (!ok) score = -INFINITY;
+      bool take = (t == 0) || (score > bscore);  // first max wins inside the lane
+      if (take) { bscore = score; best = ok ? a : (1 << 20); bnext = cidx[t]; }
+    }
+    row_argmax<4>(bscore, best, bnext);
+    if (j == 0) s.path[rb + depth] = node | (best << 16);
+    parent = node;
+    action = best;
+    depth += 1;
+    if (bnext == -1 || depth >= s.max_depth) break;
+    node = bnext;
+  }
+  if (j == 0) {
+    s.sel_parent[r] = parent;
+    s.sel_action[r] = action;
+    s.sel_depth[r] = depth;
+    s.depth_sum[r] += depth;
+    action_out[r] = action;
+  }
+  const float* src = s.embeddings + (rb + parent) * E;
+  for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+}
+
+// mctx search.expand (update_tree_node + edge) and search.backward
+__global__ __launch_bounds__(256) void step_expand_backup_kernel(StepArgs s, int sim, const float* reward,
+                                                                  const float* discount,
+                                                                  const float* prior_logits,
+                                                                  const float* value,
+                                                                  const float* next_embedding) {
+  MZ_ROW_SETUP
+  const int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
+  const size_t eo = (rb + parent) * A + action;
+  int next = s.children_index[eo];
+  const int newn = next == -1 ? sim + 1 : next;
+  const float v = value[r];
+  float x[kMaxAS], pr[kMaxAS];
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    x[t] = a < A ? prior_logits[(size_t)r * A + a] : 0.0f;
+  }
+  row_softmax_rt(x, A, j, pr);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    if (a < A) {
+      s.children_prior_logits[(rb + newn) * A + a] = x[t];
+      s.children_prior_probs[(rb + newn) * A + a] = pr[t];
+    }
+  }
+  for (int i = j; i < E; i += 16) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
+  const float rew_new = reward[r], dis_new = discount[r];
+  if (j == 0) {
+    s.raw_values[rb + newn] = v;
+    s.node_values[rb + newn] = v;
+    s.node_visits[rb + newn] = s.node_visits[rb + newn] + 1;
+    s.children_index[eo] = newn;
+    s.children_rewards[eo] = rew_new;
+    s.children_discounts[eo] = dis_new;
+    s.parents[rb + newn] = parent;
+    s.action_from_parent[rb + newn] = action;
+    // backward along the staged path (only this lane touches these words)
+    float leaf = v, childv = v;
+    for (int d = depth - 1; d >= 0; --d) {
+      int pk = s.path[rb + d];
+      int pn = pk & 0xffff, pa = pk >> 16;
+      size_t e2 = (rb + pn) * A + pa;
+      int cnt = s.node_visits[rb + pn];
+      float rw = (d == depth - 1) ? rew_new : s.children_rewards[e2];
+      float ds = (d == depth - 1) ? dis_new : s.children_discounts[e2];
+      leaf = rw + ds * leaf;
+      float newv = (s.node_values[rb + pn] * (float)cnt + leaf) / ((float)cnt + 1.0f);
+      s.node_values[rb + pn] = newv;
+      s.node_visits[rb + pn] = cnt + 1;
+      s.children_values[e2] = childv;
+      s.children_visits[e2] = s.children_visits[e2] + 1;
+      childv = newv;
+    }
+  }
+}
+
+// mctx Tree.summary + _apply_temperature + jax.random.categorical
+__global__ __launch_bounds__(256) void step_finish_kernel(StepArgs s, float temperature, const float* gumbel,
+                                                           uint32_t ks0, uint32_t ks1, int32_t* action_out,
+                                                           float* action_weights_out, float* search_value_out,
+                                                           int32_t* depth_sum_out) {
+  MZ_ROW_SETUP
+  const uint64_t rg = s.root_offset + (uint64_t)r;
+  int vc[kMaxAS];
+  int part = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    vc[t] = a < A ? s.children_visits[rb * A + a] : 0;
+    part += vc[t];
+  }
+  float total = (float)row_sum_i(part);
+  float denom = fmaxf(total, 1.0f);
+  float lg[kMaxAS], prob[kMaxAS];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    float p = (float)vc[t] / denom;
+    p = total > 0.0f ? p : 1.0f / (float)A;
+    prob[t] = p;
+    lg[t] = log_pos(fmaxf(p, kFltTiny));
+    mx = a < A ? fmaxf(mx, lg[t]) : mx;
+  }
+  mx = row_max<4>(mx);
+  float tden = fmaxf(temperature, kFltTiny);
+  float bscore = -INFINITY;
+  int best = 1 << 20, dummy = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    bool ok = a < A;
+    float g;
+    if (gumbel != nullptr) {
+      g = ok ? gumbel[(size_t)r * A + a] : 0.0f;
+    } else {
+      uint32_t x0, x1;
+      bool second;
+      bits_block(s.global_batch * (uint64_t)A, rg * (uint64_t)A + (uint64_t)(ok ? a : 0), x0, x1, second);
+      threefry2x32(ks0, ks1, x0, x1);
+      g = gumbel_from_bits(second ? x1 : x0);
+    }
+    float score = ok ? (lg[t] - mx) / tden + g : -INFINITY;
+    if (ok) action_weights_out[(size_t)r * A + a] = prob[t];
+    bool take = (t == 0) || (ok && score > bscore);
+    if (take) { bscore = score; best = ok ? a : (1 << 20); }
+  }
+  row_argmax<4>(bscore, best, dummy);
+  if (j == 0) {
+    action_out[r] = best;
+    if (search_value_out) search_value_out[r] = s.node_values[rb];
+    if (depth_sum_out) depth_sum_out[r] = s.depth_sum[r];
+  }
+}
+
+#undef MZ_ROW_SETUP
+
+}  // namespace mz

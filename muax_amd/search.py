@@ -1,0 +1,280 @@
+"""Host side of the HIP search: torch tensors in, C-ABI calls out.
+
+Counterpart of what ``muax.MuZero._plan`` hands to ``mctx.muzero_policy``
+(reference muax/model.py:222-243, muax/policy.py:13-30).  PyTorch is used for
+device memory and streams only; all search arithmetic runs in
+``libmzsearch.so`` (hand-written gfx950 kernels).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (MLP_WEIGHT_NAMES, TREE_FIELDS, TREE_INT_FIELDS, MzsActArgs, MzsConfig,
+                   MzsMlpWeights, MzsTreeView)
+
+
+class SearchTree(NamedTuple):
+    """mctx.Tree arrays ([B,N], [B,N,A], [B,N,E]) as torch tensors."""
+    node_visits: torch.Tensor
+    raw_values: torch.Tensor
+    node_values: torch.Tensor
+    parents: torch.Tensor
+    action_from_parent: torch.Tensor
+    children_index: torch.Tensor
+    children_prior_logits: torch.Tensor
+    children_values: torch.Tensor
+    children_visits: torch.Tensor
+    children_rewards: torch.Tensor
+    children_discounts: torch.Tensor
+    embeddings: torch.Tensor
+
+
+class PolicyOutput(NamedTuple):
+    """mctx.PolicyOutput (action, action_weights, search_tree)."""
+    action: torch.Tensor
+    action_weights: torch.Tensor
+    search_tree: Optional[SearchTree]
+
+
+@dataclass
+class SearchConfig:
+    """Keyword arguments of MuZero.act that reach mctx.muzero_policy (muax/model.py:86-95)."""
+    num_actions: int
+    num_simulations: int
+    embed_dim: int
+    max_depth: Optional[int] = None
+    tiebreak: bool = True          # mctx adds 1e-7*uniform tie-break noise at every selection
+    pb_c_init: float = 1.25
+    pb_c_base: float = 19652.0
+    global_batch: Optional[int] = None
+    root_offset: int = 0
+
+
+def key_words(key) -> tuple:
+    """Accept an int seed, a uint32[2] array/tensor (JAX PRNGKey data) or a (hi, lo) tuple."""
+    if isinstance(key, (int, np.integer)):
+        k = int(key)
+        return ((k >> 32) & 0xFFFFFFFF, k & 0xFFFFFFFF)  # jax.random.PRNGKey(seed)
+    if isinstance(key, torch.Tensor):
+        key = key.detach().cpu().numpy()
+    a = np.asarray(key).astype(np.uint64).ravel()
+    if a.size != 2:
+        raise ValueError("rng_key must be an int seed or two uint32 words")
+    return (int(a[0]) & 0xFFFFFFFF, int(a[1]) & 0xFFFFFFFF)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class MuZeroSearch:
+    """One handle = one (device, batch shard, search configuration)."""
+
+    def __init__(self, batch: int, cfg: SearchConfig, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("muax_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        self.batch, self.cfg = int(batch), cfg
+        self._L = _lib.load()
+        c = MzsConfig()
+        c.struct_size = C.sizeof(MzsConfig)
+        c.device = self.device.index or 0
+        c.batch, c.num_actions = self.batch, cfg.num_actions
+        c.num_simulations, c.embed_dim = cfg.num_simulations, cfg.embed_dim
+        c.max_depth = cfg.max_depth or 0
+        c.qtransform, c.tiebreak = 0, int(bool(cfg.tiebreak))
+        c.pb_c_init, c.pb_c_base = cfg.pb_c_init, cfg.pb_c_base
+        c.global_batch = cfg.global_batch or self.batch
+        c.root_offset = cfg.root_offset
+        h = C.c_void_p()
+        _lib.check(self._L.mzs_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._weights = None
+        B, A = self.batch, cfg.num_actions
+        with torch.cuda.device(self.device):
+            self.action = torch.empty(B, dtype=torch.int32, device=self.device)
+            self.action_weights = torch.empty(B, A, dtype=torch.float32, device=self.device)
+            self.root_value = torch.empty(B, dtype=torch.float32, device=self.device)
+            self.search_value = torch.empty(B, dtype=torch.float32, device=self.device)
+            self.depth_sum = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._tree = None
+        self._parent_emb = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mzs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, t, shape, name):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, device=self.device)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t.to(torch.float32).contiguous()
+
+    def _u8(self, t, shape, name):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, device=self.device)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return (t != 0).to(torch.uint8).contiguous()
+
+    def _alloc_tree(self) -> SearchTree:
+        if self._tree is None:
+            B, N = self.batch, self.cfg.num_simulations + 1
+            A, E = self.cfg.num_actions, self.cfg.embed_dim
+            shapes = {"embeddings": (B, N, E)}
+            out = {}
+            for f in TREE_FIELDS:
+                shp = shapes.get(f, (B, N, A) if f.startswith("children_") else (B, N))
+                dt = torch.int32 if f in TREE_INT_FIELDS else torch.float32
+                out[f] = torch.empty(shp, dtype=dt, device=self.device)
+            self._tree = SearchTree(**out)
+        return self._tree
+
+    def _tree_view(self, tree: SearchTree) -> MzsTreeView:
+        v = MzsTreeView()
+        for f in TREE_FIELDS:
+            setattr(v, f, getattr(tree, f).data_ptr())
+        return v
+
+    # ------------------------------------------------------------------ fused path
+    def set_mlp_weights(self, weights: dict, obs_dim: int, support_size: int = 10,
+                        discount: float = 0.99, recurrent_pred_on: str = "child"):
+        """Weights of the default MLP trio (muax/nn.py:59-115), haiku layout w[in][out]."""
+        A, E = self.cfg.num_actions, self.cfg.embed_dim
+        F, H = 2 * support_size + 1, 16
+        shapes = {"repr_w": (obs_dim, E), "repr_b": (E,),
+                  "pv_w1": (E, H), "pv_b1": (H,), "pv_w2": (H, F), "pv_b2": (F,),
+                  "pp_w1": (E, H), "pp_b1": (H,), "pp_w2": (H, A), "pp_b2": (A,),
+                  "dr_w1": (E + A, H), "dr_b1": (H,), "dr_w2": (H, F), "dr_b2": (F,),
+                  "dn_w1": (E + A, H), "dn_b1": (H,), "dn_w2": (H, E), "dn_b2": (E,)}
+        keep = {n: self._f32(weights[n], shapes[n], n) for n in MLP_WEIGHT_NAMES}
+        w = MzsMlpWeights()
+        w.struct_size = C.sizeof(MzsMlpWeights)
+        w.obs_dim, w.support_size = obs_dim, support_size
+        w.recurrent_pred_on = {"child": 0, "parent": 1}[recurrent_pred_on]
+        w.discount = discount
+        for n in MLP_WEIGHT_NAMES:
+            setattr(w, n, keep[n].data_ptr())
+        _lib.check(self._L.mzs_mlp_set_weights(self._h, C.byref(w)), self._h)
+        self._weights = (keep, obs_dim)  # keep the device buffers alive
+
+    def act_mlp(self, obs, key, dirichlet_noise=None, dirichlet_fraction: float = 0.25,
+                invalid_actions=None, temperature: float = 1.0, gumbel=None,
+                with_tree: bool = False) -> PolicyOutput:
+        """Whole act(): root inference, S simulations, summary and sampling -- ONE kernel launch.
+        Outputs live in self.action / action_weights / root_value / search_value / depth_sum."""
+        if self._weights is None:
+            raise ValueError("set_mlp_weights() first")
+        B, A = self.batch, self.cfg.num_actions
+        obs = self._f32(obs, (B, self._weights[1]), "obs")
+        noise = self._f32(dirichlet_noise, (B, A), "dirichlet_noise")
+        inv = self._u8(invalid_actions, (B, A), "invalid_actions")
+        gum = self._f32(gumbel, (B, A), "gumbel")
+        a = MzsActArgs()
+        a.struct_size = C.sizeof(MzsActArgs)
+        a.obs, a.dirichlet_noise = obs.data_ptr(), (noise.data_ptr() if noise is not None else None)
+        a.invalid_actions = inv.data_ptr() if inv is not None else None
+        a.gumbel = gum.data_ptr() if gum is not None else None
+        k = key_words(key)
+        a.key[0], a.key[1] = k
+        a.dirichlet_fraction = dirichlet_fraction if noise is not None else 0.0
+        a.temperature = temperature
+        a.action, a.action_weights = self.action.data_ptr(), self.action_weights.data_ptr()
+        a.root_value, a.search_value = self.root_value.data_ptr(), self.search_value.data_ptr()
+        a.depth_sum = self.depth_sum.data_ptr()
+        tree = None
+        if with_tree:
+            tree = self._alloc_tree()
+            view = self._tree_view(tree)
+            a.tree = C.pointer(view)
+        _lib.check(self._L.mzs_act_mlp(self._h, C.byref(a), self._stream()), self._h)
+        self._keep = (obs, noise, inv, gum)  # alive until the stream has consumed them
+        return PolicyOutput(self.action, self.action_weights, tree)
+
+    # ------------------------------------------------------------------ step-wise path
+    def root(self, prior_logits, value, embedding, key=0, invalid_actions=None,
+             dirichlet_noise=None, dirichlet_fraction: float = 0.25):
+        """RootFnOutput -> tree (mctx muzero_policy prelude + instantiate_tree_from_root)."""
+        B, A, E = self.batch, self.cfg.num_actions, self.cfg.embed_dim
+        pl = self._f32(prior_logits, (B, A), "prior_logits")
+        v = self._f32(value, (B,), "value")
+        emb = self._f32(torch.as_tensor(embedding, device=self.device).reshape(B, -1), (B, E),
+                        "embedding")
+        inv = self._u8(invalid_actions, (B, A), "invalid_actions")
+        noise = self._f32(dirichlet_noise, (B, A), "dirichlet_noise")
+        kw = (C.c_uint32 * 2)(*key_words(key))
+        _lib.check(self._L.mzs_root(self._h, _ptr(pl), _ptr(v), _ptr(emb), _ptr(inv), _ptr(noise),
+                                    C.c_float(dirichlet_fraction if noise is not None else 0.0),
+                                    C.byref(kw), self._stream()), self._h)
+        self._keep = (pl, v, emb, inv, noise)
+        if self._parent_emb is None:
+            self._parent_emb = torch.empty(B, E, dtype=torch.float32, device=self.device)
+
+    def select(self, sim: int):
+        """One mctx simulate(): returns (action [B] int32, parent embedding [B,E])."""
+        if self._parent_emb is None:
+            raise ValueError("root() first")
+        _lib.check(self._L.mzs_select(self._h, sim, _ptr(self.action), _ptr(self._parent_emb),
+                                      self._stream()), self._h)
+        return self.action, self._parent_emb
+
+    def expand_backup(self, sim: int, reward, discount, prior_logits, value, next_embedding):
+        """RecurrentFnOutput + next embedding -> expand + backward."""
+        B, A, E = self.batch, self.cfg.num_actions, self.cfg.embed_dim
+        r = self._f32(reward, (B,), "reward")
+        d = self._f32(discount, (B,), "discount")
+        pl = self._f32(prior_logits, (B, A), "prior_logits")
+        v = self._f32(value, (B,), "value")
+        ne = self._f32(torch.as_tensor(next_embedding, device=self.device).reshape(B, -1), (B, E),
+                       "next_embedding")
+        _lib.check(self._L.mzs_expand_backup(self._h, sim, _ptr(r), _ptr(d), _ptr(pl), _ptr(v),
+                                             _ptr(ne), self._stream()), self._h)
+        self._keep = (r, d, pl, v, ne)
+
+    def finish(self, temperature: float = 1.0, gumbel=None, with_tree: bool = False) -> PolicyOutput:
+        B, A = self.batch, self.cfg.num_actions
+        gum = self._f32(gumbel, (B, A), "gumbel")
+        _lib.check(self._L.mzs_finish(self._h, C.c_float(temperature), _ptr(gum), _ptr(self.action),
+                                      _ptr(self.action_weights), _ptr(self.search_value),
+                                      _ptr(self.depth_sum), self._stream()), self._h)
+        self._keep = (gum,)
+        tree = None
+        if with_tree:
+            tree = self._alloc_tree()
+            view = self._tree_view(tree)
+            _lib.check(self._L.mzs_tree_export(self._h, C.byref(view), self._stream()), self._h)
+        return PolicyOutput(self.action, self.action_weights, tree)
+
+    def search(self, root_fn_output, recurrent_fn, key=0, invalid_actions=None,
+               dirichlet_noise=None, dirichlet_fraction=0.25, temperature=1.0, gumbel=None,
+               with_tree=False) -> PolicyOutput:
+        """mctx.muzero_policy with a caller-supplied recurrent_fn(action, embedding) ->
+        (reward, discount, prior_logits, value, next_embedding) of torch tensors."""
+        prior_logits, value, embedding = root_fn_output
+        self.root(prior_logits, value, embedding, key, invalid_actions, dirichlet_noise,
+                  dirichlet_fraction)
+        for sim in range(self.cfg.num_simulations):
+            action, emb = self.select(sim)
+            self.expand_backup(sim, *recurrent_fn(action, emb))
+        return self.finish(temperature, gumbel, with_tree)

@@ -1,0 +1,253 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact on every integer array of the tree (indices, visit counts, parents, actions) and --
+because both sides implement the same MZ-F32 arithmetic spec -- equal floats as well (checked with
+==, and again with the 1e-5 tolerance the north star states).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_trees_equal, make_case
+
+pytestmark = pytest.mark.gpu
+
+F32 = np.float32
+
+
+def _fused(case, tiebreak, key, max_depth=None, temperature=1.0, use_gumbel=True, use_noise=True,
+           pred_on="child", global_batch=None, root_offset=0, rows=None):
+    from muax_amd import MuZeroSearch, SearchConfig
+    sl = slice(None) if rows is None else rows
+    B = case["obs"][sl].shape[0]
+    cfg = SearchConfig(case["A"], case["S"], case["E"], max_depth=max_depth, tiebreak=tiebreak,
+                       global_batch=global_batch, root_offset=root_offset)
+    s = MuZeroSearch(B, cfg)
+    s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"],
+                      case["support"], 0.99, pred_on)
+    out = s.act_mlp(torch.from_numpy(case["obs"][sl]), key,
+                    dirichlet_noise=torch.from_numpy(case["noise"][sl]) if use_noise else None,
+                    invalid_actions=None if case["invalid"] is None else torch.from_numpy(case["invalid"][sl]),
+                    temperature=temperature,
+                    gumbel=torch.from_numpy(case["gumbel"][sl]) if use_gumbel else None, with_tree=True)
+    torch.cuda.synchronize()
+    return s, out
+
+
+def _oracle(oracle, case, tiebreak, key, max_depth=0, temperature=1.0, use_gumbel=True, use_noise=True,
+            pred_on=0):
+    mlp = oracle.Mlp(case["w"], case["obs_dim"], case["E"], case["A"], case["F"], support_size=case["support"],
+                     recurrent_pred_on=pred_on)
+    cfg = oracle.SearchCfg(case["S"], max_depth=max_depth or 0, tiebreak=int(tiebreak))
+    return oracle.act_mlp(mlp, cfg, case["obs"], key, case["noise"] if use_noise else None, 0.25, case["invalid"],
+                          temperature, case["gumbel"] if use_gumbel else None)
+
+
+def _compare(ref, s, out):
+    assert np.array_equal(ref["action"], out.action.cpu().numpy())
+    assert np.array_equal(ref["action_weights"], out.action_weights.cpu().numpy())
+    assert np.array_equal(ref["root_value"], s.root_value.cpu().numpy())
+    assert np.array_equal(ref["depth_sum"], s.depth_sum.cpu().numpy().astype(np.int64))
+    assert np.array_equal(ref["tree"].node_values[:, 0], s.search_value.cpu().numpy())
+    assert_trees_equal(ref["tree"], out.search_tree, exact_floats=True)
+    assert_trees_equal(ref["tree"], out.search_tree, exact_floats=False)
+
+
+@pytest.mark.parametrize("tiebreak", [False, True])
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100)])
+def test_fused_matches_oracle(oracle, A, E, S, B, tiebreak):
+    case = make_case(oracle, 10 * A + E, B, 4 if E == 8 else 8, E, A, S)
+    key = [123, 456 + A]
+    s, out = _fused(case, tiebreak, key)
+    _compare(_oracle(oracle, case, tiebreak, key), s, out)
+
+
+def test_fused_invalid_actions_and_key_gumbel(oracle):
+    case = make_case(oracle, 5, 200, 4, 8, 4, 40, invalid_frac=0.3)
+    key = [9, 8]
+    s, out = _fused(case, True, key, use_gumbel=False)
+    ref = _oracle(oracle, case, True, key, use_gumbel=False)
+    _compare(ref, s, out)
+    a = out.action.cpu().numpy()
+    inv = case["invalid"]
+    ok = inv.sum(1) < inv.shape[1]
+    assert (inv[np.arange(len(a)), a][ok] == 0).all()  # never samples an invalid action
+
+
+@pytest.mark.parametrize("max_depth", [1, 3])
+def test_fused_max_depth_reexpansion(oracle, max_depth):
+    case = make_case(oracle, 6, 64, 4, 8, 2, 30)
+    s, out = _fused(case, True, [1, 2], max_depth=max_depth)
+    ref = _oracle(oracle, case, True, [1, 2], max_depth=max_depth)
+    _compare(ref, s, out)
+    assert (out.search_tree.node_visits.cpu().numpy()[:, 1:].max(axis=1) > 1).any() or max_depth > 1
+
+
+def test_fused_temperature_zero_no_noise_parent_quirk(oracle):
+    case = make_case(oracle, 7, 96, 4, 8, 2, 25)
+    s, out = _fused(case, False, 3, temperature=0.0, use_noise=False, pred_on="parent")
+    ref = _oracle(oracle, case, False, [0, 3], temperature=0.0, use_noise=False, pred_on=1)
+    _compare(ref, s, out)
+    vc = out.search_tree.children_visits.cpu().numpy()[:, 0]
+    a = out.action.cpu().numpy()
+    assert (vc[np.arange(len(a)), a] == vc.max(axis=1)).all()
+
+
+def test_fused_sharding_invariance(oracle):
+    """A shard (global_batch, root_offset) reproduces the same roots of the full batch bit for bit."""
+    case = make_case(oracle, 8, 96, 4, 8, 2, 20)
+    s_full, full = _fused(case, True, 77, use_gumbel=False)
+    s_half, half = _fused(case, True, 77, use_gumbel=False, global_batch=96, root_offset=48, rows=slice(48, 96))
+    assert torch.equal(full.action[48:], half.action)
+    for f in full.search_tree._fields:
+        assert torch.equal(getattr(full.search_tree, f)[48:], getattr(half.search_tree, f)), f
+
+
+def test_fused_small_batch_and_plumbing_config(oracle):
+    """BASELINE config 1: B=1, S=10 (latency/plumbing point)."""
+    case = make_case(oracle, 9, 1, 4, 8, 2, 10)
+    s, out = _fused(case, True, [0, 42])
+    _compare(_oracle(oracle, case, True, [0, 42]), s, out)
+
+
+def test_fused_full_size_properties(oracle):
+    """BASELINE config 2 at full size (4096 roots, S=50): structural invariants that do not need the
+    oracle, plus exact agreement with the oracle on a 256-root sample of the same batch."""
+    case = make_case(oracle, 0, 4096, 4, 8, 2, 50, bias_scale=0.0)
+    s, out = _fused(case, True, [0, 0], use_gumbel=False)
+    t = out.search_tree
+    nv, cv, ci, par, afp = (x.cpu().numpy() for x in
+                            (t.node_visits, t.children_visits, t.children_index, t.parents, t.action_from_parent))
+    S = case["S"]
+    assert (nv[:, 0] == S + 1).all()
+    assert (cv.sum(-1) == nv - 1)[nv > 0].all()
+    assert (cv[:, 0].sum(-1) == S).all()
+    b, n, a = np.nonzero(ci >= 0)
+    c = ci[b, n, a]
+    assert (par[b, c] == n).all() and (afp[b, c] == a).all() and (cv[b, n, a] == nv[b, c]).all()
+    assert (np.sort(c.reshape(4096, S), axis=1) == np.arange(1, S + 1)).all()  # every node expanded exactly once
+    w = out.action_weights.cpu().numpy()
+    assert np.allclose(w.sum(1), 1, atol=1e-6) and np.array_equal(w, (cv[:, 0] / F32(S)).astype(F32))
+    # depth_sum equals the sum of node depths recomputed from the parents array
+    depth = np.zeros_like(par)
+    for k in range(1, S + 1):
+        depth[:, k] = depth[np.arange(4096), par[:, k]] + 1
+    assert np.array_equal(depth.sum(1), s.depth_sum.cpu().numpy())
+    sub = dict(case)
+    for k in ("obs", "noise", "gumbel"):
+        sub[k] = case[k][:256]
+    mlp = oracle.Mlp(case["w"], 4, 8, 2, 21)
+    ref = oracle.act_mlp(mlp, oracle.SearchCfg(S, tiebreak=1, global_batch=4096), sub["obs"], [0, 0], sub["noise"],
+                         0.25, None, 1.0, None)
+    assert np.array_equal(ref["action"], out.action.cpu().numpy()[:256])
+    assert np.array_equal(ref["tree"].children_index, ci[:256])
+    assert np.array_equal(ref["tree"].node_values, t.node_values.cpu().numpy()[:256])
+
+
+def _torch_recurrent(case):
+    """The default MLP trio in plain torch (any plugin net would do): the step-wise path's nets."""
+    w = {k: torch.from_numpy(v).cuda() for k, v in case["w"].items()}
+    A, sup = case["A"], case["support"]
+    bins = torch.arange(-sup, sup + 1, dtype=torch.float32, device="cuda")
+
+    def minmax(s):
+        mn, mx = s.min(1, keepdim=True).values, s.max(1, keepdim=True).values
+        sc = mx - mn
+        sc = torch.where(sc < 1e-5, sc + 1e-5, sc)
+        return (s - mn) / sc
+
+    def inv(x):
+        e = 1e-3
+        return torch.sign(x) * (((torch.sqrt(1 + 4 * e * (x.abs() + 1 + e)) - 1) / (2 * e)) ** 2 - 1)
+
+    def mlp(x, a, b, c, d):
+        return torch.nn.functional.elu(x @ a + b) @ c + d
+
+    def pred(s):
+        v = mlp(s, w["pv_w1"], w["pv_b1"], w["pv_w2"], w["pv_b2"])
+        pl = mlp(s, w["pp_w1"], w["pp_b1"], w["pp_w2"], w["pp_b2"])
+        return pl, inv((torch.softmax(v, -1) * bins).sum(-1))
+
+    def root(obs):
+        s = minmax(obs @ w["repr_w"] + w["repr_b"])
+        pl, v = pred(s)
+        return pl, v, s
+
+    def rec(action, emb):
+        sa = torch.cat([emb, torch.nn.functional.one_hot(action.long(), A).float()], 1)
+        r = inv((torch.softmax(mlp(sa, w["dr_w1"], w["dr_b1"], w["dr_w2"], w["dr_b2"]), -1) * bins).sum(-1))
+        ns = minmax(mlp(sa, w["dn_w1"], w["dn_b1"], w["dn_w2"], w["dn_b2"]))
+        pl, v = pred(ns)
+        return r, torch.full_like(r, 0.99), pl, v, ns
+
+    return root, rec
+
+
+@pytest.mark.parametrize("tiebreak", [False, True])
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 20, 70), (5, 8, 24, 33), (18, 40, 30, 40)])
+def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak):
+    """Plugin-net path: torch nets between mzs_select and mzs_expand_backup; the oracle is fed the very
+    same net outputs, so every tree array must agree exactly."""
+    from muax_amd import MuZeroSearch, SearchConfig
+    case = make_case(oracle, 20 + A, B, 6, E, A, S, invalid_frac=0.2 if A > 2 else 0.0)
+    root, rec = _torch_recurrent(case)
+    key = [4, 5]
+    obs = torch.from_numpy(case["obs"]).cuda()
+    pl, v, emb = root(obs)
+    s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=tiebreak))
+    inv = None if case["invalid"] is None else torch.from_numpy(case["invalid"])
+    s.root(pl, v, emb, key, inv, torch.from_numpy(case["noise"]), 0.25)
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S, tiebreak=int(tiebreak))
+    oracle.tree_init(tree, oracle.root_prior(pl.cpu().numpy(), case["noise"], 0.25, case["invalid"]),
+                     v.cpu().numpy(), emb.cpu().numpy(), case["invalid"])
+    k_sample, _, sims = oracle.sim_keys_from_act_key(key, S)
+    for sim in range(S):
+        action, pemb = s.select(sim)
+        p_ref, a_ref, _ = oracle.step_select(tree, cfg, sim, sims[sim])
+        assert np.array_equal(a_ref, action.cpu().numpy()), sim
+        assert np.array_equal(tree.embeddings[np.arange(B), p_ref], pemb.cpu().numpy())
+        outs = rec(action, pemb)
+        s.expand_backup(sim, *outs)
+        oracle.step_expand_backup(tree, sim, p_ref, a_ref, *[o.cpu().numpy() for o in outs])
+    out = s.finish(1.0, None, with_tree=True)
+    g = oracle.gumbel(k_sample, B * A).reshape(B, A)
+    a_ref, w_ref = oracle.summary_sample(tree, 1.0, g)
+    assert np.array_equal(a_ref, out.action.cpu().numpy())
+    assert np.array_equal(w_ref, out.action_weights.cpu().numpy())
+    assert_trees_equal(tree, out.search_tree, exact_floats=True)
+
+
+def test_stepwise_equals_fused_when_fed_oracle_nets(oracle):
+    """The two product paths agree with each other when the step-wise nets are the oracle's MLPs."""
+    from muax_amd import MuZeroSearch, SearchConfig
+    case = make_case(oracle, 31, 50, 4, 8, 2, 16)
+    mlp = oracle.Mlp(case["w"], 4, 8, 2, 21)
+    _, fused = _fused(case, True, [2, 2], use_gumbel=False)
+    s = MuZeroSearch(50, SearchConfig(2, 16, 8, tiebreak=True))
+    pl, v, emb = oracle.root_inference(mlp, case["obs"])
+    s.root(torch.from_numpy(pl), torch.from_numpy(v), torch.from_numpy(emb), [2, 2], None,
+           torch.from_numpy(case["noise"]), 0.25)
+    for sim in range(16):
+        action, pemb = s.select(sim)
+        outs = oracle.recurrent_inference(mlp, action.cpu().numpy(), pemb.cpu().numpy())
+        s.expand_backup(sim, *[torch.from_numpy(o) for o in outs])
+    out = s.finish(1.0, None, with_tree=True)
+    assert torch.equal(out.action, fused.action)
+    for f in out.search_tree._fields:
+        assert torch.equal(getattr(out.search_tree, f), getattr(fused.search_tree, f)), f
+
+
+def test_error_behaviour():
+    from muax_amd import MuZeroSearch, SearchConfig
+    with pytest.raises(ValueError):
+        MuZeroSearch(0, SearchConfig(2, 5, 8))
+    s = MuZeroSearch(4, SearchConfig(2, 5, 8))
+    with pytest.raises(ValueError):
+        s.act_mlp(torch.zeros(4, 4), 0)  # weights not set
+    with pytest.raises(ValueError):
+        s.select(0)  # root() not called
+    s7 = MuZeroSearch(4, SearchConfig(7, 5, 8))
+    w = {k: torch.zeros(1) for k in ["repr_w"]}
+    with pytest.raises((ValueError, KeyError)):
+        s7.set_mlp_weights(w, 4)

@@ -1,20 +1,31 @@
-// mz_fused.cuh -- the whole MuZero.act() search for the default MLP trio in ONE
-// launch (reference path: muax/model.py:222-282 -> mctx.muzero_policy; nets
-// muax/nn.py:59-115; codec muax/utils.py:70-102).
+// mz_fused.cuh -- the whole MuZero.act() search for the default MLP trio
+// (reference path: muax/model.py:222-282 -> mctx.muzero_policy; nets
+// muax/nn.py:59-115; codec muax/utils.py:70-102) as two launches:
 //
-// Mapping (MI355X-first, not a translation of mctx's vmapped XLA program):
-//   * one search root  = one DPP row (16 lanes); 4 roots per wavefront,
-//     16 roots per 256-thread workgroup, no barrier after the prologue;
-//   * the root's whole tree lives in LDS for the duration of the act
-//     (struct-per-node records, NS words each), HBM is touched only for the
-//     observation, the weights (once, into VGPRs) and the outputs;
+//   mz_noise_kernel      mctx's tie-break noise stream (JAX threefry) for every
+//                        (simulation, root, level), produced in throughput mode
+//                        (one thread per chain, ILP over the three blocks of a level);
+//   mz_act_fused_kernel  root inference, S simulations, summary + sampling.
+//
+// Mapping of the search kernel (MI355X-first, not a translation of mctx's
+// vmapped XLA program).  Measured on gfx950: a lone wavefront pays ~6.5 cycles
+// per dependent VALU op, ~20 per dependent DPP step and ~64 per dependent LDS
+// read, so the design minimises the length of the per-root dependent chain:
+//   * one search root = one DPP row (16 lanes); 4 roots per wavefront, one
+//     wavefront per SIMD, no barrier after the prologue;
+//   * the root's whole tree lives in LDS for the duration of the act; HBM is
+//     touched for the observation, the weights (once, into VGPRs), the noise
+//     rows (prefetched one simulation ahead) and the outputs;
+//   * pUCT scores are CACHED per child: a node's scores only change when the
+//     node lies on a backed-up path, so they are recomputed in the backup
+//     phase, where lane e owns path entry e (all levels in parallel), and the
+//     sequential selection loop shrinks to "load {child, score} x A, add noise,
+//     first-max argmax";
+//   * backup's discounted-return chain runs over row broadcasts, everything
+//     else of backup is lane-parallel;
 //   * the MLPs run as row-distributed fma chains: input element i lives in lane
 //     i&15 (slot i>>4) and is fetched with a row_newbcast DPP modifier; each
-//     lane keeps its own column of every weight matrix in VGPRs;
-//   * pUCT selection: lane a scores action a, first-max argmax is a DPP
-//     butterfly; tie-break noise is JAX's threefry stream, generated one level
-//     ahead by otherwise idle lanes (14/15 split the key, lanes < A draw bits);
-//   * the selected path is staged in LDS so that backup never chases parents.
+//     lane keeps its own column of every weight matrix in VGPRs.
 #pragma once
 #include "mz_spec.cuh"
 
@@ -31,6 +42,7 @@ struct FusedParams {
   const float* dirichlet_noise;  // [B, A] or null
   const uint8_t* invalid;        // [B, A] or null
   const float* gumbel;           // [B, A] or null (null -> threefry from k_sample)
+  const uint32_t* noise_rows;    // [S, B, RW] words from mz_noise_kernel (tiebreak only)
   // weights, haiku layout w[in][out]
   const float *repr_w, *repr_b;
   const float *pv_w1, *pv_b1, *pv_w2, *pv_b2;
@@ -54,6 +66,12 @@ struct FusedParams {
   float pb_c_init, pb_c_base, dirichlet_fraction, discount, temperature;
   uint64_t global_batch, root_offset;
   uint32_t k_sample[2];
+};
+
+struct NoiseParams {
+  uint32_t* rows;  // [S, B, RW]
+  int32_t B, S, max_depth;
+  uint64_t global_batch, root_offset;
   uint32_t sim_keys[kMaxSims][2];
 };
 
@@ -64,21 +82,81 @@ struct FusedCfg {
   static constexpr bool TB = TB_;
   static constexpr int H = kHidden;
   static constexpr int ES = (E + 15) / 16, FS = (F + 15) / 16;
-  static constexpr int ASTEPS = ceil_log2(A);
-  // node record (32-bit words): visits, value, puct scale, pad, A x {index, prob,
-  // value, visits, reward, discount}, embedding
-  static constexpr int CH0 = 4, CHW = 6;
-  static constexpr int EMB0 = CH0 + CHW * A;
-  static constexpr int NS = EMB0 + E;
+  // ---- node record in LDS (32-bit words, 16-byte aligned) ----
+  //   [SEL0 .. ) A x {child index, cached pUCT score}          (selection reads only this)
+  //   [HDR0 .. ) visits, value, pad, pad
+  //   [ST0  .. ) A x {prob, value, visits, reward, discount, pad}
+  //   [EMB0 .. ) embedding
+  static constexpr int SEL0 = 0, SELW = ((2 * A + 3) / 4) * 4;
+  static constexpr int HDR0 = SELW;
+  static constexpr int ST0 = HDR0 + 4, STW = 6;
+  static constexpr int EMB0 = ST0 + STW * A;
+  static constexpr int NS = ((EMB0 + E + 3) / 4) * 4;
   static constexpr int TREE_WORDS = NS * NMAX;
-  static constexpr int PATH_WORDS = NMAX;
-  static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS;
+  static constexpr int PATH_WORDS = ((NMAX + 1 + 3) / 4) * 4;
+  // ---- noise row of one (simulation, root): CAP levels x A floats, then the walking key ----
+  static constexpr int RW = A <= 2 ? 64 : (A <= 3 ? 96 : (A <= 4 ? 128 : 16 * A + 16));
+  static constexpr int CAP = (RW - 4) / A;
+  static constexpr int NOISE_WORDS = TB ? 2 * RW : 0;  // double buffered
+  static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
   static constexpr int TBL_WORDS = ((NMAX + 2 + 3) / 4) * 4;
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
-  static_assert(A <= 14, "lanes 14/15 of the row split the PRNG key");
+  static_assert(A <= 8, "selection keeps all A scores in registers");
   static_assert(F <= 32 && E <= 32 * 16, "row-distributed vectors");
+  static_assert(RW / 4 <= 16 * 4, "a noise row is fetched as <= 4 x 16-byte pieces per lane");
 };
+
+// ---------------------------------------------------------------------------
+// tie-break noise producer (mctx search.simulate key walk, jax.random.split /
+// uniform restated on threefry2x32)
+// ---------------------------------------------------------------------------
+template <int A, int RW>
+__global__ __launch_bounds__(256) void mz_noise_kernel(const NoiseParams p) {
+  constexpr int CAP = (RW - 4) / A;
+  constexpr int NB = (A + 1) / 2;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)p.S * p.B) return;
+  const int sim = (int)(t / p.B);
+  const int b = (int)(t % p.B);
+  const uint64_t rg = p.root_offset + (uint64_t)b;
+  uint32_t* row = p.rows + (size_t)t * RW;
+  // simulate_keys[b] = split(simulate_key, B)[b]: words 2b, 2b+1 of the flat stream
+  uint32_t k0, k1;
+  {
+    uint32_t x0, x1, y0, y1;
+    bool s0, s1;
+    bits_block(2 * p.global_batch, 2 * rg, x0, x1, s0);
+    bits_block(2 * p.global_batch, 2 * rg + 1, y0, y1, s1);
+    threefry2x32(p.sim_keys[sim][0], p.sim_keys[sim][1], x0, x1);
+    threefry2x32(p.sim_keys[sim][0], p.sim_keys[sim][1], y0, y1);
+    k0 = s0 ? x1 : x0;
+    k1 = s1 ? y1 : y0;
+  }
+  int L = sim + 1;  // a simulation can never select deeper than its own index + 1
+  L = L < p.max_depth ? L : p.max_depth;
+  L = L < CAP ? L : CAP;
+  for (int d = 0; d < L; ++d) {
+    // rng_key, action_selection_key = split(rng_key)
+    uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
+    threefry2x32(k0, k1, a0, a1);
+    threefry2x32(k0, k1, b0, b1);
+    k0 = a0; k1 = b0;
+    const uint32_t s0 = a1, s1 = b1;
+    // 1e-7 * uniform(action_selection_key, (A,))
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      uint32_t x0 = (uint32_t)i, x1 = (NB + i < A) ? (uint32_t)(NB + i) : 0u;
+      threefry2x32(s0, s1, x0, x1);
+      row[d * A + i] = f2u(1e-7f * uniform_from_bits(x0));
+      if (NB + i < A) row[d * A + NB + i] = f2u(1e-7f * uniform_from_bits(x1));
+    }
+  }
+  row[RW - 4] = k0;  // walking key after L levels (continuation beyond CAP)
+  row[RW - 3] = k1;
+  row[RW - 2] = (uint32_t)L;
+  row[RW - 1] = 0;
+}
 
 // y = x . W + b for row-distributed vectors; W column(s) of this lane in VGPRs.
 template <int NIN, int NOUT>
@@ -96,18 +174,15 @@ struct RowLinear {
     }
   }
   // k-ordered fma chain from 0, bias added last (haiku Linear: dot then + b)
-  MZ_DEV void dot(const float (&x)[IS], float (&acc)[OS]) const {
+  MZ_DEV void apply(const float (&x)[IS], float (&y)[OS]) const {
 #pragma unroll
-    for (int t = 0; t < OS; ++t) acc[t] = 0.0f;
+    for (int t = 0; t < OS; ++t) y[t] = 0.0f;
     StaticFor<0, NIN>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       float xb = bcast<(i & 15)>(x[i >> 4]);
 #pragma unroll
-      for (int t = 0; t < OS; ++t) acc[t] = __builtin_fmaf(xb, w[i][t], acc[t]);
+      for (int t = 0; t < OS; ++t) y[t] = __builtin_fmaf(xb, w[i][t], y[t]);
     });
-  }
-  MZ_DEV void apply(const float (&x)[IS], float (&y)[OS]) const {
-    dot(x, y);
 #pragma unroll
     for (int t = 0; t < OS; ++t) y[t] = y[t] + b[t];
   }
@@ -143,14 +218,16 @@ struct RowLinearOneHot {
   }
 };
 
-// jax.nn.softmax over a row-distributed vector of N elements (N <= 32)
+// jax.nn.softmax over a row-distributed vector of N elements (N <= 32).  For
+// N < 16 the result is only valid in lanes < 2^ceil(log2 N) (all that is used).
 template <int N>
 MZ_DEV void row_softmax(const float (&x)[(N + 15) / 16], int j, float (&p)[(N + 15) / 16]) {
   constexpr int NSLOT = (N + 15) / 16;
+  constexpr int STEPS = N >= 16 ? 4 : ceil_log2(N);
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NSLOT; ++t) m = (j + 16 * t < N) ? fmaxf(m, x[t]) : m;
-  m = row_max<4>(m);
+  m = row_max<STEPS>(m);
   float e[NSLOT];
   float part = 0.0f;
 #pragma unroll
@@ -159,7 +236,8 @@ MZ_DEV void row_softmax(const float (&x)[(N + 15) / 16], int j, float (&p)[(N + 
     e[t] = ok ? exp_neg(x[t] - m) : 0.0f;
     part = (t == 0) ? e[0] : (ok ? part + e[t] : part);
   }
-  float s = row_sum(part);
+  // lanes >= N hold +0: the butterfly steps that would only add those zeros are exact no-ops
+  float s = row_sum_steps<STEPS>(part);
 #pragma unroll
   for (int t = 0; t < NSLOT; ++t) p[t] = e[t] / s;
 }
@@ -184,6 +262,7 @@ MZ_DEV float row_decode(const float (&logits)[(F + 15) / 16], int j, int support
 template <int E>
 MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
   constexpr int NSLOT = (E + 15) / 16;
+  constexpr int STEPS = E >= 16 ? 4 : ceil_log2(E);
   float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NSLOT; ++t) {
@@ -191,8 +270,9 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
     mn = ok ? fminf(mn, s[t]) : mn;
     mx = ok ? fmaxf(mx, s[t]) : mx;
   }
-  mn = row_min<4>(mn);
-  mx = row_max<4>(mx);
+  // lanes >= E hold the neutral element; lanes < 2^STEPS agree after STEPS steps
+  mn = row_min<STEPS>(mn);  // (lanes >= 2^STEPS see garbage; their slots are never used)
+  mx = row_max<STEPS>(mx);
   float scale = mx - mn;
   scale = scale < 1e-5f ? scale + 1e-5f : scale;
 #pragma unroll
@@ -242,27 +322,30 @@ struct Nets {
   }
 };
 
-// One threefry pass for the row: lanes 14/15 split `key`, lanes < A draw the
-// tie-break bits from `sel`.  Returns this lane's noise bits (for the level
-// AFTER the one `sel` belonged to -- see the pipeline in the kernel).
+// mctx muzero_action_selection (value_score + policy_score) for every child of
+// one node, with qtransform_by_parent_and_siblings; tie-break noise and the
+// root mask are applied at selection time.
 template <int A>
-struct RowRng {
-  uint32_t k0, k1;  // walking key (mctx simulate: rng_key)
-  uint32_t s0, s1;  // action_selection_key of the next level
-  MZ_DEV uint32_t pass(int j) {
-    constexpr int NB = (A + 1) / 2;
-    bool splitter = j >= 14;
-    int jb = j < NB ? j : j - NB;  // noise block of action j
-    uint32_t x0 = splitter ? (uint32_t)(j - 14) : (uint32_t)jb;
-    uint32_t x1 = splitter ? (uint32_t)(j - 12) : ((NB + jb < A) ? (uint32_t)(NB + jb) : 0u);
-    uint32_t kk0 = splitter ? k0 : s0, kk1 = splitter ? k1 : s1;
-    threefry2x32(kk0, kk1, x0, x1);
-    // split(key) -> flat [y0(blk0), y0(blk1), y1(blk0), y1(blk1)]
-    k0 = bcast_u<14>(x0); k1 = bcast_u<15>(x0);
-    s0 = bcast_u<14>(x1); s1 = bcast_u<15>(x1);
-    return j < NB ? x0 : x1;
+MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const float (&val)[A],
+                        const int (&vis)[A], const float (&rew)[A], const float (&dis)[A],
+                        float (&score)[A]) {
+  float q[A];
+  float lo = nval, hi = nval;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    q[a] = rew[a] + dis[a] * val[a];
+    float safe = vis[a] > 0 ? q[a] : nval;
+    lo = fminf(lo, safe);
+    hi = fmaxf(hi, safe);
   }
-};
+  float span = fmaxf(hi - lo, 1e-8f);
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    float value_score = ((vis[a] > 0 ? q[a] : lo) - lo) / span;
+    float policy_score = (tn * prob[a]) / (float)(vis[a] + 1);
+    score[a] = value_score + policy_score;
+  }
+}
 
 template <class C>
 __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const FusedParams p) {
@@ -274,7 +357,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   const int root_in_wg = (tid >> 6) * 4 + (lane >> 4);
   const int r = blockIdx.x * C::ROOTS_PER_WG + root_in_wg;
 
-  float* tbl = lds;  // puct scale by visit count
+  float* tbl = lds;  // sqrt(n) * pb_c(n) by visit count
   for (int i = tid; i < C::TBL_WORDS; i += C::THREADS) tbl[i] = puct_scale(i, p.pb_c_init, p.pb_c_base);
   __syncthreads();
   if (r >= p.B) return;  // whole row leaves together; no barrier below
@@ -282,6 +365,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   float* tree = lds + C::TBL_WORDS + root_in_wg * C::ROOT_WORDS;
   int* itree = reinterpret_cast<int*>(tree);
   int* path = itree + C::TREE_WORDS;
+  float* nzbuf = tree + C::TREE_WORDS + C::PATH_WORDS;  // [2][RW]
   const uint64_t rg = p.root_offset + (uint64_t)r;
   const int S = p.S;
   const int max_depth = p.max_depth > 0 ? p.max_depth : S;
@@ -292,10 +376,32 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   Nets<C> nets;
   nets.load(p, j);
 
+  // noise rows travel HBM -> VGPR -> LDS in 16-byte pieces (lane j takes pieces j, j+16, ...),
+  // fetched one simulation ahead so that the HBM latency hides behind a whole simulation
+  constexpr int NPIECE = C::TB ? (C::RW / 4 + 15) / 16 : 1;
+  uint4 npf[NPIECE];
+  auto noise_fetch = [&](int sim) {
+    if constexpr (C::TB) {
+      const uint4* src = reinterpret_cast<const uint4*>(p.noise_rows + ((size_t)sim * p.B + r) * C::RW);
+#pragma unroll
+      for (int t = 0; t < NPIECE; ++t)
+        if (j + 16 * t < C::RW / 4) npf[t] = src[j + 16 * t];
+    }
+  };
+  auto noise_commit = [&](int sim) {
+    if constexpr (C::TB) {
+      uint4* dst = reinterpret_cast<uint4*>(nzbuf + (sim & 1) * C::RW);
+#pragma unroll
+      for (int t = 0; t < NPIECE; ++t)
+        if (j + 16 * t < C::RW / 4) dst[j + 16 * t] = npf[t];
+    }
+  };
+  noise_fetch(0);
+
   // ---- tree init (mctx instantiate_tree_from_root) ----
   for (int n = 0; n < N; ++n) {
     for (int wq = j; wq < NS; wq += 16) {
-      bool is_index = wq >= C::CH0 && wq < C::EMB0 && ((wq - C::CH0) % C::CHW == 0);
+      bool is_index = wq < 2 * A && (wq & 1) == 0;
       itree[n * NS + wq] = is_index ? -1 : 0;
     }
   }
@@ -327,7 +433,11 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   }
   float v0, pl0;
   nets.predict(s, j, support, v0, pl0);
-  const bool inv_lane = (p.invalid != nullptr) && (j < A) && p.invalid[(size_t)r * A + (j < A ? j : 0)];
+  uint32_t inv_bits = 0;  // root_invalid_actions as a bit mask (row uniform)
+  if (p.invalid != nullptr) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) inv_bits |= p.invalid[(size_t)r * A + a] ? (1u << a) : 0u;
+  }
   {
     // mctx muzero_policy prelude: dirichlet mix, log, invalid-action mask
     float x[1] = {pl0}, pr[1];
@@ -338,84 +448,104 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float lg = log_pos(fmaxf(noisy, kFltTiny));
     if (p.invalid != nullptr) {
       float mx = row_max<4>(j < A ? lg : -INFINITY);
-      lg = inv_lane ? kFltLowest : lg - mx;
+      lg = ((inv_bits >> j) & 1u) ? kFltLowest : lg - mx;
     }
     float lx[1] = {lg}, pq[1];
     row_softmax<A>(lx, j, pq);
-    if (j < A) tree[C::CH0 + C::CHW * j + 1] = pq[0];
+    if (j < A) tree[C::ST0 + C::STW * j + 0] = pq[0];
     if (ex && j < A) p.t_children_prior_logits[(size_t)r * N * A + j] = lg;
     if (j == 0) {
-      itree[0] = 1;
-      tree[1] = v0;
-      tree[2] = tbl[1];
+      itree[C::HDR0] = 1;
+      tree[C::HDR0 + 1] = v0;
       p.root_value[r] = v0;
       if (ex) p.t_raw_values[(size_t)r * N] = v0;
     }
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
       if (j + 16 * t < E) tree[C::EMB0 + j + 16 * t] = s[t];
+    // cached scores of the root's children (all unvisited)
+    float prob[A], val[A], rew[A], dis[A], sc[A];
+    int vis[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      prob[a] = tree[C::ST0 + C::STW * a + 0];
+      val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = 0.0f;
+    }
+    puct_scores<A>(v0, tbl[1], prob, val, vis, rew, dis, sc);
+    if (j == 0) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) tree[C::SEL0 + 2 * a + 1] = sc[a];
+    }
   }
+  noise_commit(0);
 
   int depth_total = 0;
-  const int ja = j < A ? j : A - 1;  // lanes >= A shadow the last action (masked later)
 
   // ---- simulations (mctx search.search body_fun) ----
   for (int sim = 0; sim < S; ++sim) {
-    RowRng<A> rng;
-    uint32_t nbits = 0;
+    if (sim + 1 < S) noise_fetch(sim + 1);
+    const float* nz = nzbuf + (sim & 1) * C::RW;
+    uint32_t fk0 = 0, fk1 = 0;  // walking key beyond the produced levels
+    int avail = 0;
     if constexpr (C::TB) {
-      // simulate_keys[b] = split(simulate_key, B)[b]: words 2b, 2b+1 of the flat stream
-      uint32_t x0, x1;
-      bool second;
-      bits_block(2 * p.global_batch, 2 * rg + (uint64_t)(j & 1), x0, x1, second);
-      threefry2x32(p.sim_keys[sim][0], p.sim_keys[sim][1], x0, x1);
-      uint32_t word = second ? x1 : x0;
-      rng.k0 = bcast_u<0>(word);
-      rng.k1 = bcast_u<1>(word);
-      rng.s0 = 0; rng.s1 = 0;
-      rng.pass(j);          // -> key_1, sel_0
-      nbits = rng.pass(j);  // -> key_2, sel_1, bits of level 0
+      const uint32_t* nzu = reinterpret_cast<const uint32_t*>(nz);
+      fk0 = nzu[C::RW - 4];
+      fk1 = nzu[C::RW - 3];
+      avail = (int)nzu[C::RW - 2];
     }
 
-    // -- simulate (mctx search.simulate) --
+    // -- simulate (mctx search.simulate): every lane of the row walks identically --
     int node = 0, depth = 0, parent = 0, action = 0, next = -1;
     for (;;) {
       const float* nd = tree + node * NS;
       const int* ndi = itree + node * NS;
-      int nvis = ndi[0];
-      float nval = nd[1];
-      float tn = nd[2];
-      const int co = C::CH0 + C::CHW * ja;
-      int cidx = ndi[co + 0];
-      float prob = nd[co + 1];
-      float cval = nd[co + 2];
-      int cvis = ndi[co + 3];
-      float crew = nd[co + 4];
-      float cdis = nd[co + 5];
-      float noise = 0.0f;
-      if constexpr (C::TB) {
-        noise = 1e-7f * uniform_from_bits(nbits);
-        nbits = rng.pass(j);  // bits for the next level, off the critical path
+      int cidx[A];
+      float score[A];
+      {
+        // the selection record {child, score} x A: 16-byte LDS reads
+        const uint4* rec = reinterpret_cast<const uint4*>(ndi + C::SEL0);
+        uint4 sel[C::SELW / 4];
+#pragma unroll
+        for (int q = 0; q < C::SELW / 4; ++q) sel[q] = rec[q];
+        const uint32_t* sw = reinterpret_cast<const uint32_t*>(sel);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          cidx[a] = (int)sw[2 * a];
+          score[a] = __uint_as_float(sw[2 * a + 1]);
+        }
+        (void)nd;
       }
-      // qtransform_by_parent_and_siblings
-      float q = crew + cdis * cval;
-      bool has = cvis > 0;
-      float safe = (has && j < A) ? q : nval;
-      float lo = fminf(nval, row_min<C::ASTEPS>(safe));
-      float hi = fmaxf(nval, row_max<C::ASTEPS>(safe));
-      float span = fmaxf(hi - lo, 1e-8f);
-      float value_score = ((has ? q : lo) - lo) / span;
-      // muzero_action_selection
-      float policy_score = (tn * prob) / (float)(cvis + 1);
-      float score = value_score + policy_score;
-      if constexpr (C::TB) score = score + noise;
-      score = (depth == 0 && inv_lane) ? -INFINITY : score;
-      score = j < A ? score : -INFINITY;
-      int best = j, nxt = cidx;
-      row_argmax<C::ASTEPS>(score, best, nxt);
-      best = bcast_i<0>(best);  // lanes >= 2^ASTEPS did not take part: keep the row uniform
-      nxt = bcast_i<0>(nxt);
-      (void)nvis;
+      if constexpr (C::TB) {
+        if (depth < avail) {
+#pragma unroll
+          for (int a = 0; a < A; ++a) score[a] = score[a] + nz[depth * A + a];
+        } else {
+          // beyond the produced rows: continue the key walk in place (rare: depth >= CAP)
+          constexpr int NB = (A + 1) / 2;
+          uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
+          threefry2x32(fk0, fk1, a0, a1);
+          threefry2x32(fk0, fk1, b0, b1);
+          fk0 = a0; fk1 = b0;
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            uint32_t x0 = (uint32_t)i, x1 = (NB + i < A) ? (uint32_t)(NB + i) : 0u;
+            threefry2x32(a1, b1, x0, x1);
+            score[i] = score[i] + 1e-7f * uniform_from_bits(x0);
+            if (NB + i < A) score[NB + i] = score[NB + i] + 1e-7f * uniform_from_bits(x1);
+          }
+        }
+      }
+      const uint32_t mask = depth == 0 ? inv_bits : 0u;
+      int best = 0, nxt = cidx[0];
+      float bs = (mask & 1u) ? -INFINITY : score[0];
+#pragma unroll
+      for (int a = 1; a < A; ++a) {
+        float sa = ((mask >> a) & 1u) ? -INFINITY : score[a];
+        bool take = sa > bs;  // first max wins
+        bs = take ? sa : bs;
+        best = take ? a : best;
+        nxt = take ? cidx[a] : nxt;
+      }
       if (j == 0) path[depth] = node | (best << 16);
       parent = node;
       action = best;
@@ -443,19 +573,18 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     {
       float* nn = tree + newn * NS;
       int* nni = itree + newn * NS;
-      int vis = nni[0] + 1;
-      if (j < A) nn[C::CH0 + C::CHW * j + 1] = pp[0];
+      int vis = nni[C::HDR0] + 1;
+      if (j < A) nn[C::ST0 + C::STW * j + 0] = pp[0];
 #pragma unroll
       for (int t = 0; t < C::ES; ++t)
         if (j + 16 * t < E) nn[C::EMB0 + j + 16 * t] = ns[t];
       if (j == 0) {
-        nni[0] = vis;
-        nn[1] = value;
-        nn[2] = tbl[vis];
-        int eo = parent * NS + C::CH0 + C::CHW * action;
-        itree[eo + 0] = newn;
-        tree[eo + 4] = reward;
-        tree[eo + 5] = p.discount;
+        nni[C::HDR0] = vis;
+        nn[C::HDR0 + 1] = value;
+        itree[parent * NS + C::SEL0 + 2 * action] = newn;
+        tree[parent * NS + C::ST0 + C::STW * action + 3] = reward;
+        tree[parent * NS + C::ST0 + C::STW * action + 4] = p.discount;
+        path[depth] = newn;  // leaf entry of the update phase
       }
       if (ex) {
         size_t o = (size_t)r * N + newn;
@@ -468,38 +597,88 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       }
     }
 
-    // -- backward (mctx search.backward), walking the staged path --
+    // -- backward (mctx search.backward) + score refresh, lane e <-> path entry e --
+    // entries 0..depth-1 are the (parent, action) edges of the path, entry `depth` is the leaf.
     {
-      float leaf = value;
-      float childv = value;
-      for (int d = depth - 1; d >= 0; --d) {
-        int pk = path[d];
-        int pn = pk & 0xffff, pa = pk >> 16;
+      float G = value;      // leaf_value walking up (row uniform)
+      float carry = value;  // node value of the entry just below this chunk
+      for (int c = depth >> 4; c >= 0; --c) {
+        const int e = 16 * c + j;
+        const bool valid = e <= depth;
+        const bool isleaf = e == depth;
+        const bool edge = e < depth;
+        const int pk = valid ? path[e] : 0;
+        const int pn = pk & 0xffff, pa = isleaf ? 0 : (pk >> 16);
         float* nd = tree + pn * NS;
         int* ndi = itree + pn * NS;
-        int cnt = ndi[0];
-        float pv = nd[1];
-        int eo = C::CH0 + C::CHW * pa;
-        int cv = ndi[eo + 3];
-        float rew = nd[eo + 4];
-        float dis = nd[eo + 5];
-        leaf = rew + dis * leaf;
-        float newv = (pv * (float)cnt + leaf) / ((float)cnt + 1.0f);
-        if (j == 0) {
-          nd[1] = newv;
-          ndi[0] = cnt + 1;
-          nd[2] = tbl[cnt + 1];
-          nd[eo + 2] = childv;
-          ndi[eo + 3] = cv + 1;
+        const int cnt = ndi[C::HDR0];
+        const float pv = nd[C::HDR0 + 1];
+        float prob[A], val[A], rew[A], dis[A];
+        int vis[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          prob[a] = nd[C::ST0 + C::STW * a + 0];
+          val[a] = nd[C::ST0 + C::STW * a + 1];
+          vis[a] = ndi[C::ST0 + C::STW * a + 2];
+          rew[a] = nd[C::ST0 + C::STW * a + 3];
+          dis[a] = nd[C::ST0 + C::STW * a + 4];
         }
-        childv = newv;
+        float re = rew[0], ge = dis[0];
+#pragma unroll
+        for (int a = 1; a < A; ++a) {
+          re = (pa == a) ? rew[a] : re;
+          ge = (pa == a) ? dis[a] : ge;
+        }
+        re = edge ? re : 0.0f;  // identity step for the leaf entry and for idle lanes
+        ge = edge ? ge : 1.0f;
+        // leaf_value = reward + discount * leaf_value, deepest entry first
+        float Gown = G;
+        StaticFor<0, 16>::run([&](auto ic) {
+          constexpr int k = 15 - decltype(ic)::value;
+          G = bcast<k>(re) + bcast<k>(ge) * G;
+          Gown = (j == k) ? G : Gown;
+        });
+        const float newv = (pv * (float)cnt + Gown) / ((float)cnt + 1.0f);
+        // children_values[parent, action] = node_values[child]: the child is the next entry
+        float childv = __int_as_float(__builtin_amdgcn_update_dpp(
+            __float_as_int(carry), __float_as_int(newv), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+        childv = (e == depth - 1) ? value : childv;
+        carry = bcast<0>(newv);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          val[a] = (edge && pa == a) ? childv : val[a];
+          vis[a] = (edge && pa == a) ? vis[a] + 1 : vis[a];
+        }
+        const int nvis = edge ? cnt + 1 : cnt;
+        const float nval = edge ? newv : pv;
+        float sc[A];
+        puct_scores<A>(nval, tbl[valid ? nvis : 0], prob, val, vis, rew, dis, sc);
+        if (valid) {
+#pragma unroll
+          for (int a = 0; a < A; ++a) nd[C::SEL0 + 2 * a + 1] = sc[a];
+        }
+        if (edge) {
+          ndi[C::HDR0] = nvis;
+          nd[C::HDR0 + 1] = newv;
+          float cvn = val[0];
+          int cin = vis[0];
+#pragma unroll
+          for (int a = 1; a < A; ++a) {
+            cvn = (pa == a) ? val[a] : cvn;
+            cin = (pa == a) ? vis[a] : cin;
+          }
+          nd[C::ST0 + C::STW * pa + 1] = cvn;
+          ndi[C::ST0 + C::STW * pa + 2] = cin;
+        }
       }
     }
+    if (sim + 1 < S) noise_commit(sim + 1);
   }
 
   // ---- summary + sample (mctx Tree.summary, _apply_temperature, categorical) ----
   {
-    int vc = itree[C::CH0 + C::CHW * ja + 3];
+    const int ja = j < A ? j : A - 1;
+    int vc = itree[C::ST0 + C::STW * ja + 2];
     vc = j < A ? vc : 0;
     float total = (float)row_sum_i(vc);
     float denom = fmaxf(total, 1.0f);
@@ -521,11 +700,11 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     }
     float score = j < A ? al + g : -INFINITY;
     int best = j, dummy = 0;
-    row_argmax<C::ASTEPS>(score, best, dummy);
+    row_argmax<4>(score, best, dummy);
     if (j < A) p.action_weights[(size_t)r * A + j] = prob;
     if (j == 0) {
       p.action[r] = best;
-      if (p.search_value) p.search_value[r] = tree[1];
+      if (p.search_value) p.search_value[r] = tree[C::HDR0 + 1];
       if (p.depth_sum) p.depth_sum[r] = depth_total;
     }
   }
@@ -536,16 +715,16 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       const float* nd = tree + n * NS;
       const int* ndi = itree + n * NS;
       if (j == 0) {
-        p.t_node_visits[o] = ndi[0];
-        p.t_node_values[o] = nd[1];
+        p.t_node_visits[o] = ndi[C::HDR0];
+        p.t_node_values[o] = nd[C::HDR0 + 1];
       }
       if (j < A) {
-        int co = C::CH0 + C::CHW * j;
-        p.t_children_index[o * A + j] = ndi[co + 0];
-        p.t_children_values[o * A + j] = nd[co + 2];
-        p.t_children_visits[o * A + j] = ndi[co + 3];
-        p.t_children_rewards[o * A + j] = nd[co + 4];
-        p.t_children_discounts[o * A + j] = nd[co + 5];
+        int so = C::ST0 + C::STW * j;
+        p.t_children_index[o * A + j] = ndi[C::SEL0 + 2 * j];
+        p.t_children_values[o * A + j] = nd[so + 1];
+        p.t_children_visits[o * A + j] = ndi[so + 2];
+        p.t_children_rewards[o * A + j] = nd[so + 3];
+        p.t_children_discounts[o * A + j] = nd[so + 4];
       }
       for (int i = j; i < E; i += 16) p.t_embeddings[o * E + i] = nd[C::EMB0 + i];
     }

@@ -82,6 +82,16 @@ MZ_DEV float row_sum(float p) {
   p = p + dpp_f<kDppMirror>(p);
   return p;
 }
+// first STEPS butterfly steps only: exact when the lanes beyond 2^STEPS hold +0 and only
+// lanes < 2^STEPS use the result
+template <int STEPS>
+MZ_DEV float row_sum_steps(float p) {
+  StaticFor<0, STEPS>::run([&](auto ic) {
+    constexpr int s = decltype(ic)::value;
+    p = p + dpp_f<Bfly<s>::ctrl>(p);
+  });
+  return p;
+}
 // max / min over the first 2^STEPS-aligned group of lanes (order independent)
 template <int STEPS>
 MZ_DEV float row_max(float x) {

@@ -529,31 +529,32 @@ void mzo_act_mlp(const mzo_mlp *m, const mzo_search_cfg *cfg, mzo_tree *t,
     }
   }
 
-  float *emb0 = (float *)malloc(sizeof(float) * (size_t)B * E);
-  float *pl0 = (float *)malloc(sizeof(float) * (size_t)B * A);
-  float *v0 = (float *)malloc(sizeof(float) * (size_t)B);
-  for (int b = 0; b < B; ++b) {
-    float raw_logits[256];
-    mzo_root_inference(m, obs + (int64_t)b * m->obs_dim, emb0 + (int64_t)b * E, raw_logits,
-                       v0 + b);
-    root_value_out[b] = v0[b];
-    mzo_root_prior(raw_logits, A,
-                   dirichlet_noise ? dirichlet_noise + (int64_t)b * A : NULL,
-                   dirichlet_fraction,
-                   invalid_actions ? invalid_actions + (int64_t)b * A : NULL,
-                   pl0 + (int64_t)b * A);
-  }
-  mzo_tree_init(t, pl0, v0, emb0, invalid_actions);
-  free(emb0);
-  free(pl0);
-  free(v0);
-
+  const int N = t->N;
   /* Roots never interact, so the simulation loop is run
    * root-major here; mctx runs it simulation-major over the whole batch. */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 1 ? nthreads : 1)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 1 ? nthreads : 1)
 #endif
   for (int b = 0; b < B; ++b) {
+    /* root inference + muzero_policy prelude + instantiate_tree_from_root, one root */
+    {
+      float raw_logits[256], pl0[256], emb0[1024], v0;
+      mzo_root_inference(m, obs + (int64_t)b * m->obs_dim, emb0, raw_logits, &v0);
+      root_value_out[b] = v0;
+      mzo_root_prior(raw_logits, A, dirichlet_noise ? dirichlet_noise + (int64_t)b * A : NULL,
+                     dirichlet_fraction, invalid_actions ? invalid_actions + (int64_t)b * A : NULL,
+                     pl0);
+      mzo_tree t1 = *t;
+      int64_t n0 = (int64_t)b * N;
+      t1.B = 1;
+      t1.node_visits += n0; t1.raw_values += n0; t1.node_values += n0;
+      t1.parents += n0; t1.action_from_parent += n0;
+      t1.children_index += n0 * A; t1.children_prior_logits += n0 * A;
+      t1.children_values += n0 * A; t1.children_visits += n0 * A;
+      t1.children_rewards += n0 * A; t1.children_discounts += n0 * A;
+      t1.embeddings += n0 * E; t1.root_invalid_actions += (int64_t)b * A;
+      mzo_tree_init(&t1, pl0, &v0, emb0, invalid_actions ? invalid_actions + (int64_t)b * A : NULL);
+    }
     int64_t dsum = 0;
     for (int s = 0; s < S; ++s) {
       uint32_t rk[2] = {0, 0};

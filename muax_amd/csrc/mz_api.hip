@@ -56,7 +56,7 @@ struct mzs_handle {
   mz::StepState step;  // device buffers of the step-wise path (lazily allocated)
   uint32_t k_sample[2] = {0, 0};
   uint32_t sim_keys[mz::kMaxSims][2];
-  uint32_t* noise_rows = nullptr;  // [S, B, RW] tie-break noise table (fused path)
+  uint32_t* noise_rows = nullptr;  // tie-break noise table of the fused path (see mz_noise_kernel)
   size_t noise_bytes = 0;
 };
 
@@ -103,7 +103,7 @@ int launch_fused(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
     return fail(h, MZS_E_RUNTIME, "hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
   if constexpr (C::TB) {
     // mctx's tie-break stream for every (simulation, root, level), produced ahead of the search
-    const size_t need = (size_t)p.S * p.B * C::RW * sizeof(uint32_t);
+    const size_t need = C::noise_table_words(p.S, p.B) * sizeof(uint32_t);
     if (h->noise_bytes < need) {
       if (h->noise_rows) MZS_HIP(h, hipFree(h->noise_rows));
       h->noise_rows = nullptr;
@@ -117,7 +117,7 @@ int launch_fused(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
     np.global_batch = p.global_batch; np.root_offset = p.root_offset;
     memcpy(np.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)p.S);
     const int64_t chains = (int64_t)p.S * p.B;
-    hipLaunchKernelGGL((mz::mz_noise_kernel<C::A, C::RW>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((mz::mz_noise_kernel<C::A, C::CAP>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0,
                        stream, np);
     MZS_HIP(h, hipGetLastError());
     p.noise_rows = h->noise_rows;

@@ -42,7 +42,7 @@ struct FusedParams {
   const float* dirichlet_noise;  // [B, A] or null
   const uint8_t* invalid;        // [B, A] or null
   const float* gumbel;           // [B, A] or null (null -> threefry from k_sample)
-  const uint32_t* noise_rows;    // [S, B, RW] words from mz_noise_kernel (tiebreak only)
+  const uint32_t* noise_rows;    // noise [S,CAP,B,A] f32 then walking keys [S,B,2] (tiebreak only)
   // weights, haiku layout w[in][out]
   const float *repr_w, *repr_b;
   const float *pv_w1, *pv_b1, *pv_w2, *pv_b2;
@@ -69,7 +69,7 @@ struct FusedParams {
 };
 
 struct NoiseParams {
-  uint32_t* rows;  // [S, B, RW]
+  uint32_t* rows;  // noise [S,CAP,B,A] f32, then walking keys [S,B,2]
   int32_t B, S, max_depth;
   uint64_t global_batch, root_offset;
   uint32_t sim_keys[kMaxSims][2];
@@ -94,33 +94,33 @@ struct FusedCfg {
   static constexpr int NS = ((EMB0 + E + 3) / 4) * 4;
   static constexpr int TREE_WORDS = NS * NMAX;
   static constexpr int PATH_WORDS = ((NMAX + 1 + 3) / 4) * 4;
-  // ---- noise row of one (simulation, root): CAP levels x A floats, then the walking key ----
-  static constexpr int RW = A <= 2 ? 64 : (A <= 3 ? 96 : (A <= 4 ? 128 : 16 * A + 16));
-  static constexpr int CAP = (RW - 4) / A;
-  static constexpr int NOISE_WORDS = TB ? 2 * RW : 0;  // double buffered
+  // ---- tie-break noise of one (simulation, root): CAP levels x A floats in LDS, double buffered ----
+  static constexpr int CAP = 32;
+  static constexpr int NOISE_WORDS = TB ? 2 * CAP * A : 0;
+  static constexpr size_t noise_table_words(int S, int B) { return (size_t)S * B * (CAP * A + 2); }
   static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
   static constexpr int TBL_WORDS = ((NMAX + 2 + 3) / 4) * 4;
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
   static_assert(A <= 8, "selection keeps all A scores in registers");
   static_assert(F <= 32 && E <= 32 * 16, "row-distributed vectors");
-  static_assert(RW / 4 <= 16 * 4, "a noise row is fetched as <= 4 x 16-byte pieces per lane");
 };
 
 // ---------------------------------------------------------------------------
 // tie-break noise producer (mctx search.simulate key walk, jax.random.split /
 // uniform restated on threefry2x32)
 // ---------------------------------------------------------------------------
-template <int A, int RW>
+template <int A, int CAP>
 __global__ __launch_bounds__(256) void mz_noise_kernel(const NoiseParams p) {
-  constexpr int CAP = (RW - 4) / A;
   constexpr int NB = (A + 1) / 2;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (int64_t)p.S * p.B) return;
   const int sim = (int)(t / p.B);
   const int b = (int)(t % p.B);
   const uint64_t rg = p.root_offset + (uint64_t)b;
-  uint32_t* row = p.rows + (size_t)t * RW;
+  // noise[sim][level][b][a]: consecutive threads (roots) write consecutive words -> coalesced
+  float* nz = reinterpret_cast<float*>(p.rows) + ((size_t)sim * CAP * p.B + b) * A;
+  uint32_t* keys = p.rows + (size_t)p.S * CAP * p.B * A + (size_t)t * 2;
   // simulate_keys[b] = split(simulate_key, B)[b]: words 2b, 2b+1 of the flat stream
   uint32_t k0, k1;
   {
@@ -144,18 +144,20 @@ __global__ __launch_bounds__(256) void mz_noise_kernel(const NoiseParams p) {
     k0 = a0; k1 = b0;
     const uint32_t s0 = a1, s1 = b1;
     // 1e-7 * uniform(action_selection_key, (A,))
+    float out[A];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       uint32_t x0 = (uint32_t)i, x1 = (NB + i < A) ? (uint32_t)(NB + i) : 0u;
       threefry2x32(s0, s1, x0, x1);
-      row[d * A + i] = f2u(1e-7f * uniform_from_bits(x0));
-      if (NB + i < A) row[d * A + NB + i] = f2u(1e-7f * uniform_from_bits(x1));
+      out[i] = 1e-7f * uniform_from_bits(x0);
+      if (NB + i < A) out[NB + i] = 1e-7f * uniform_from_bits(x1);
     }
+    float* dst = nz + (size_t)d * p.B * A;
+#pragma unroll
+    for (int a = 0; a < A; ++a) dst[a] = out[a];
   }
-  row[RW - 4] = k0;  // walking key after L levels (continuation beyond CAP)
-  row[RW - 3] = k1;
-  row[RW - 2] = (uint32_t)L;
-  row[RW - 1] = 0;
+  keys[0] = k0;  // walking key after L levels (continuation beyond CAP)
+  keys[1] = k1;
 }
 
 // y = x . W + b for row-distributed vectors; W column(s) of this lane in VGPRs.
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   float* tree = lds + C::TBL_WORDS + root_in_wg * C::ROOT_WORDS;
   int* itree = reinterpret_cast<int*>(tree);
   int* path = itree + C::TREE_WORDS;
-  float* nzbuf = tree + C::TREE_WORDS + C::PATH_WORDS;  // [2][RW]
+  float* nzbuf = tree + C::TREE_WORDS + C::PATH_WORDS;  // [2][CAP][A]
   const uint64_t rg = p.root_offset + (uint64_t)r;
   const int S = p.S;
   const int max_depth = p.max_depth > 0 ? p.max_depth : S;
@@ -376,24 +378,40 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   Nets<C> nets;
   nets.load(p, j);
 
-  // noise rows travel HBM -> VGPR -> LDS in 16-byte pieces (lane j takes pieces j, j+16, ...),
-  // fetched one simulation ahead so that the HBM latency hides behind a whole simulation
-  constexpr int NPIECE = C::TB ? (C::RW / 4 + 15) / 16 : 1;
-  uint4 npf[NPIECE];
+  // tie-break noise travels HBM -> VGPR -> LDS: lane j carries levels j and j+16 of the next
+  // simulation, fetched one simulation ahead so the HBM latency hides behind a whole simulation
+  float npf[2][A];
+  auto level_limit = [&](int sim) {
+    int L = sim + 1;
+    L = L < max_depth ? L : max_depth;
+    return L < C::CAP ? L : C::CAP;
+  };
   auto noise_fetch = [&](int sim) {
     if constexpr (C::TB) {
-      const uint4* src = reinterpret_cast<const uint4*>(p.noise_rows + ((size_t)sim * p.B + r) * C::RW);
+      const float* src = reinterpret_cast<const float*>(p.noise_rows) + ((size_t)sim * C::CAP * p.B + r) * A;
+      const int L = level_limit(sim);
 #pragma unroll
-      for (int t = 0; t < NPIECE; ++t)
-        if (j + 16 * t < C::RW / 4) npf[t] = src[j + 16 * t];
+      for (int t = 0; t < 2; ++t) {
+        const int d = j + 16 * t;
+        if (d < L) {
+#pragma unroll
+          for (int a = 0; a < A; ++a) npf[t][a] = src[(size_t)d * p.B * A + a];
+        }
+      }
     }
   };
   auto noise_commit = [&](int sim) {
     if constexpr (C::TB) {
-      uint4* dst = reinterpret_cast<uint4*>(nzbuf + (sim & 1) * C::RW);
+      float* dst = nzbuf + (sim & 1) * C::CAP * A;
+      const int L = level_limit(sim);
 #pragma unroll
-      for (int t = 0; t < NPIECE; ++t)
-        if (j + 16 * t < C::RW / 4) dst[j + 16 * t] = npf[t];
+      for (int t = 0; t < 2; ++t) {
+        const int d = j + 16 * t;
+        if (d < L) {
+#pragma unroll
+          for (int a = 0; a < A; ++a) dst[d * A + a] = npf[t][a];
+        }
+      }
     }
   };
   noise_fetch(0);
@@ -484,21 +502,15 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   // ---- simulations (mctx search.search body_fun) ----
   for (int sim = 0; sim < S; ++sim) {
     if (sim + 1 < S) noise_fetch(sim + 1);
-    const float* nz = nzbuf + (sim & 1) * C::RW;
-    uint32_t fk0 = 0, fk1 = 0;  // walking key beyond the produced levels
-    int avail = 0;
-    if constexpr (C::TB) {
-      const uint32_t* nzu = reinterpret_cast<const uint32_t*>(nz);
-      fk0 = nzu[C::RW - 4];
-      fk1 = nzu[C::RW - 3];
-      avail = (int)nzu[C::RW - 2];
-    }
+    const float* nz = nzbuf + (sim & 1) * C::CAP * A;
+    const int avail = C::TB ? level_limit(sim) : 0;
 
     // -- simulate (mctx search.simulate): every lane of the row walks identically --
     int node = 0, depth = 0, parent = 0, action = 0, next = -1;
-    for (;;) {
-      const float* nd = tree + node * NS;
-      const int* ndi = itree + node * NS;
+    uint32_t fk0 = 0, fk1 = 0;  // walking key beyond the produced levels
+    auto select_level = [&](auto fb_tag) {
+      constexpr bool FB = decltype(fb_tag)::value;
+      const int* ndi = itree + __umul24((unsigned)node, (unsigned)NS);
       int cidx[A];
       float score[A];
       {
@@ -513,14 +525,13 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           cidx[a] = (int)sw[2 * a];
           score[a] = __uint_as_float(sw[2 * a + 1]);
         }
-        (void)nd;
       }
       if constexpr (C::TB) {
-        if (depth < avail) {
+        if (!FB || depth < avail) {
 #pragma unroll
           for (int a = 0; a < A; ++a) score[a] = score[a] + nz[depth * A + a];
         } else {
-          // beyond the produced rows: continue the key walk in place (rare: depth >= CAP)
+          // beyond the produced levels: continue the key walk in place (only when depth >= CAP)
           constexpr int NB = (A + 1) / 2;
           uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
           threefry2x32(fk0, fk1, a0, a1);
@@ -546,13 +557,30 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         best = take ? a : best;
         nxt = take ? cidx[a] : nxt;
       }
-      if (j == 0) path[depth] = node | (best << 16);
+      path[depth] = node | (best << 16);  // every lane of the row stores the same word
       parent = node;
       action = best;
       next = nxt;
       depth += 1;
-      if (next == -1 || depth >= max_depth) break;
-      node = next;
+    };
+    // a simulation selects at most min(sim + 1, max_depth) levels: the in-place key walk is
+    // reachable only when that exceeds CAP (wave-uniform test)
+    const int reach = sim + 1 < max_depth ? sim + 1 : max_depth;
+    if (C::TB && reach > C::CAP) {
+      const uint32_t* kw = p.noise_rows + (size_t)p.S * C::CAP * p.B * A + ((size_t)sim * p.B + r) * 2;
+      fk0 = kw[0];
+      fk1 = kw[1];
+      for (;;) {
+        select_level(std::true_type{});
+        if (next == -1 || depth >= max_depth) break;
+        node = next;
+      }
+    } else {
+      for (;;) {
+        select_level(std::false_type{});
+        if (next == -1 || depth >= max_depth) break;
+        node = next;
+      }
     }
     depth_total += depth;
     const bool fresh = next == -1;
@@ -562,7 +590,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float sp[C::ES];
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
-      sp[t] = (j + 16 * t < E) ? tree[parent * NS + C::EMB0 + j + 16 * t] : 0.0f;
+      sp[t] = (j + 16 * t < E) ? tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + j + 16 * t] : 0.0f;
     float reward, value, pil;
     float ns[C::ES];
     nets.dynamics(sp, action, j, support, reward, ns);
@@ -571,8 +599,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float px[1] = {pil}, pp[1];
     row_softmax<A>(px, j, pp);
     {
-      float* nn = tree + newn * NS;
-      int* nni = itree + newn * NS;
+      float* nn = tree + __umul24((unsigned)newn, (unsigned)NS);
+      int* nni = reinterpret_cast<int*>(nn);
       int vis = nni[C::HDR0] + 1;
       if (j < A) nn[C::ST0 + C::STW * j + 0] = pp[0];
 #pragma unroll
@@ -581,11 +609,12 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       if (j == 0) {
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
-        itree[parent * NS + C::SEL0 + 2 * action] = newn;
-        tree[parent * NS + C::ST0 + C::STW * action + 3] = reward;
-        tree[parent * NS + C::ST0 + C::STW * action + 4] = p.discount;
-        path[depth] = newn;  // leaf entry of the update phase
+        const unsigned po = __umul24((unsigned)parent, (unsigned)NS);
+        itree[po + C::SEL0 + 2 * action] = newn;
+        tree[po + C::ST0 + C::STW * action + 3] = reward;
+        tree[po + C::ST0 + C::STW * action + 4] = p.discount;
       }
+      path[depth] = newn;  // leaf entry of the update phase (every lane stores the same word)
       if (ex) {
         size_t o = (size_t)r * N + newn;
         if (j < A) p.t_children_prior_logits[o * A + j] = pil;
@@ -609,8 +638,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         const bool edge = e < depth;
         const int pk = valid ? path[e] : 0;
         const int pn = pk & 0xffff, pa = isleaf ? 0 : (pk >> 16);
-        float* nd = tree + pn * NS;
-        int* ndi = itree + pn * NS;
+        float* nd = tree + __umul24((unsigned)pn, (unsigned)NS);
+        int* ndi = reinterpret_cast<int*>(nd);
         const int cnt = ndi[C::HDR0];
         const float pv = nd[C::HDR0 + 1];
         float prob[A], val[A], rew[A], dis[A];

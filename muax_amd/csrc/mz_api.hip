@@ -56,8 +56,7 @@ struct mzs_handle {
   mz::StepState step;  // device buffers of the step-wise path (lazily allocated)
   uint32_t k_sample[2] = {0, 0};
   uint32_t sim_keys[mz::kMaxSims][2];
-  uint32_t* noise_rows = nullptr;  // tie-break noise table of the fused path (see mz_noise_kernel)
-  size_t noise_bytes = 0;
+  uint64_t* prof = nullptr;        // MZ_PROFILE builds only
 };
 
 namespace {
@@ -101,27 +100,6 @@ int launch_fused(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
   });
   if (attr_err != hipSuccess)
     return fail(h, MZS_E_RUNTIME, "hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-  if constexpr (C::TB) {
-    // mctx's tie-break stream for every (simulation, root, level), produced ahead of the search
-    const size_t need = C::noise_table_words(p.S, p.B) * sizeof(uint32_t);
-    if (h->noise_bytes < need) {
-      if (h->noise_rows) MZS_HIP(h, hipFree(h->noise_rows));
-      h->noise_rows = nullptr;
-      h->noise_bytes = 0;
-      MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->noise_rows), need));
-      h->noise_bytes = need;
-    }
-    mz::NoiseParams np;
-    np.rows = h->noise_rows;
-    np.B = p.B; np.S = p.S; np.max_depth = p.max_depth > 0 ? p.max_depth : p.S;
-    np.global_batch = p.global_batch; np.root_offset = p.root_offset;
-    memcpy(np.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)p.S);
-    const int64_t chains = (int64_t)p.S * p.B;
-    hipLaunchKernelGGL((mz::mz_noise_kernel<C::A, C::CAP>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0,
-                       stream, np);
-    MZS_HIP(h, hipGetLastError());
-    p.noise_rows = h->noise_rows;
-  }
   int grid = (p.B + C::ROOTS_PER_WG - 1) / C::ROOTS_PER_WG;
   hipLaunchKernelGGL(mz::mz_act_fused_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, p);
   MZS_HIP(h, hipGetLastError());
@@ -176,7 +154,6 @@ int mzs_destroy(mzs_handle* h) {
   if (!h) return MZS_OK;
   hipSetDevice(h->cfg.device);
   h->step.release();
-  if (h->noise_rows) hipFree(h->noise_rows);
   delete h;
   return MZS_OK;
 }
@@ -237,8 +214,10 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.pb_c_init = c.pb_c_init; p.pb_c_base = c.pb_c_base;
   p.dirichlet_fraction = a->dirichlet_fraction; p.discount = w.discount; p.temperature = a->temperature;
   p.global_batch = (uint64_t)c.global_batch; p.root_offset = (uint64_t)c.root_offset;
+  p.prof = h->prof;
   derive_keys(h, a->key);
   p.k_sample[0] = h->k_sample[0]; p.k_sample[1] = h->k_sample[1];
+  memcpy(p.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)c.num_simulations);
 
   const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, N = c.num_simulations + 1;
 #define MZS_INST(A_, E_, F_, NMAX_, WAVES_) \
@@ -246,11 +225,20 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   MZS_INST(2, 8, 21, 51, 4)    // CartPole   (BASELINE cfg1/cfg2; README.md:102-132)
   MZS_INST(4, 32, 21, 51, 2)   // LunarLander (BASELINE cfg3)
   MZS_INST(3, 8, 21, 33, 4)    // odd action count (tests)
-  MZS_INST(4, 8, 21, 51, 2)
+  MZS_INST(4, 8, 21, 51, 4)
 #undef MZS_INST
   return fail(h, MZS_E_UNSUPPORTED,
               "mzs_act_mlp: no fused kernel instance for this (A, E, F, S); use the step-wise path");
 }
+
+#ifdef MZ_PROFILE
+// tools-only entry point (not part of the ABI): per-wave phase cycle counters [waves][8]
+int mzs_debug_profile(mzs_handle* h, uint64_t* device_buffer) {
+  if (!h) return MZS_E_INVALID;
+  h->prof = device_buffer;
+  return MZS_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // step-wise path

@@ -1,11 +1,7 @@
 // mz_fused.cuh -- the whole MuZero.act() search for the default MLP trio
 // (reference path: muax/model.py:222-282 -> mctx.muzero_policy; nets
-// muax/nn.py:59-115; codec muax/utils.py:70-102) as two launches:
-//
-//   mz_noise_kernel      mctx's tie-break noise stream (JAX threefry) for every
-//                        (simulation, root, level), produced in throughput mode
-//                        (one thread per chain, ILP over the three blocks of a level);
-//   mz_act_fused_kernel  root inference, S simulations, summary + sampling.
+// muax/nn.py:59-115; codec muax/utils.py:70-102) in ONE launch:
+// root inference, S simulations, summary + sampling.
 //
 // Mapping of the search kernel (MI355X-first, not a translation of mctx's
 // vmapped XLA program).  Measured on gfx950: a lone wavefront pays ~6.5 cycles
@@ -14,13 +10,16 @@
 //   * one search root = one DPP row (16 lanes); 4 roots per wavefront, one
 //     wavefront per SIMD, no barrier after the prologue;
 //   * the root's whole tree lives in LDS for the duration of the act; HBM is
-//     touched for the observation, the weights (once, into VGPRs), the noise
-//     rows (prefetched one simulation ahead) and the outputs;
-//   * pUCT scores are CACHED per child: a node's scores only change when the
+//     touched for the observation, the weights (once, into VGPRs) and the outputs;
+//   * pUCT decisions are CACHED per node: a node's scores only change when the
 //     node lies on a backed-up path, so they are recomputed in the backup
-//     phase, where lane e owns path entry e (all levels in parallel), and the
-//     sequential selection loop shrinks to "load {child, score} x A, add noise,
-//     first-max argmax";
+//     phase, where lane e owns path entry e (all levels in parallel).  mctx's
+//     tie-break noise is < 1e-7, so a decision whose runner-up satisfies
+//     fl(score + 1e-7) < best is provably independent of the noise (rounding is
+//     monotone); such nodes store {next node, path word} and the sequential
+//     selection loop is one 8-byte LDS read per level.  Only near-tie nodes
+//     evaluate score + noise, drawing JAX's threefry stream on demand (lazy key
+//     walk per simulation) -- bit-identical to drawing it at every level;
 //   * backup's discounted-return chain runs over row broadcasts, everything
 //     else of backup is lane-parallel;
 //   * the MLPs run as row-distributed fma chains: input element i lives in lane
@@ -33,6 +32,18 @@
 
 namespace mz {
 
+// opt-in phase timers (tools/profile_phases.py builds with -DMZ_PROFILE); no code otherwise
+#ifdef MZ_PROFILE
+#define MZ_TICK(slot)                                  \
+  do {                                                 \
+    uint64_t now_ = __builtin_amdgcn_s_memtime();      \
+    prof_acc[slot] += now_ - prof_t;                   \
+    prof_t = now_;                                     \
+  } while (0)
+#else
+#define MZ_TICK(slot) do {} while (0)
+#endif
+
 constexpr int kMaxSims = 256;
 constexpr int kHidden = 16;  // hk.Linear(16) everywhere in muax/nn.py:73-115
 
@@ -42,7 +53,6 @@ struct FusedParams {
   const float* dirichlet_noise;  // [B, A] or null
   const uint8_t* invalid;        // [B, A] or null
   const float* gumbel;           // [B, A] or null (null -> threefry from k_sample)
-  const uint32_t* noise_rows;    // noise [S,CAP,B,A] f32 then walking keys [S,B,2] (tiebreak only)
   // weights, haiku layout w[in][out]
   const float *repr_w, *repr_b;
   const float *pv_w1, *pv_b1, *pv_w2, *pv_b2;
@@ -66,13 +76,8 @@ struct FusedParams {
   float pb_c_init, pb_c_base, dirichlet_fraction, discount, temperature;
   uint64_t global_batch, root_offset;
   uint32_t k_sample[2];
-};
-
-struct NoiseParams {
-  uint32_t* rows;  // noise [S,CAP,B,A] f32, then walking keys [S,B,2]
-  int32_t B, S, max_depth;
-  uint64_t global_batch, root_offset;
-  uint32_t sim_keys[kMaxSims][2];
+  uint32_t sim_keys[kMaxSims][2];  // simulate_key of every simulation (mctx search body_fun)
+  uint64_t* prof;  // MZ_PROFILE builds only: [waves][8] cycle counters
 };
 
 template <int A_, int E_, int F_, int NMAX_, bool TB_, int WAVES_ = 4>
@@ -83,21 +88,19 @@ struct FusedCfg {
   static constexpr int H = kHidden;
   static constexpr int ES = (E + 15) / 16, FS = (F + 15) / 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
-  //   [SEL0 .. ) A x {child index, cached pUCT score}          (selection reads only this)
-  //   [HDR0 .. ) visits, value, pad, pad
-  //   [ST0  .. ) A x {prob, value, visits, reward, discount, pad}
-  //   [EMB0 .. ) embedding
-  static constexpr int SEL0 = 0, SELW = ((2 * A + 3) / 4) * 4;
+  //   [FAST0 ..) {byte offset of the next node | -1 unvisited | -2 near tie, path word node|action<<16}
+  //   [SEL0  ..) A x {child index, cached pUCT score}
+  //   [HDR0  ..) visits, value, pad, pad
+  //   [ST0   ..) A x {prob, value, visits, reward, discount, pad}
+  //   [EMB0  ..) embedding
+  static constexpr int FAST0 = 0, SEL0 = 2, SELW = ((2 + 2 * A + 3) / 4) * 4;
   static constexpr int HDR0 = SELW;
   static constexpr int ST0 = HDR0 + 4, STW = 6;
   static constexpr int EMB0 = ST0 + STW * A;
   static constexpr int NS = ((EMB0 + E + 3) / 4) * 4;
   static constexpr int TREE_WORDS = NS * NMAX;
   static constexpr int PATH_WORDS = ((NMAX + 1 + 3) / 4) * 4;
-  // ---- tie-break noise of one (simulation, root): CAP levels x A floats in LDS, double buffered ----
-  static constexpr int CAP = 32;
-  static constexpr int NOISE_WORDS = TB ? 2 * CAP * A : 0;
-  static constexpr size_t noise_table_words(int S, int B) { return (size_t)S * B * (CAP * A + 2); }
+  static constexpr int NOISE_WORDS = 0;
   static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
   static constexpr int TBL_WORDS = ((NMAX + 2 + 3) / 4) * 4;
@@ -105,60 +108,6 @@ struct FusedCfg {
   static_assert(A <= 8, "selection keeps all A scores in registers");
   static_assert(F <= 32 && E <= 32 * 16, "row-distributed vectors");
 };
-
-// ---------------------------------------------------------------------------
-// tie-break noise producer (mctx search.simulate key walk, jax.random.split /
-// uniform restated on threefry2x32)
-// ---------------------------------------------------------------------------
-template <int A, int CAP>
-__global__ __launch_bounds__(256) void mz_noise_kernel(const NoiseParams p) {
-  constexpr int NB = (A + 1) / 2;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)p.S * p.B) return;
-  const int sim = (int)(t / p.B);
-  const int b = (int)(t % p.B);
-  const uint64_t rg = p.root_offset + (uint64_t)b;
-  // noise[sim][level][b][a]: consecutive threads (roots) write consecutive words -> coalesced
-  float* nz = reinterpret_cast<float*>(p.rows) + ((size_t)sim * CAP * p.B + b) * A;
-  uint32_t* keys = p.rows + (size_t)p.S * CAP * p.B * A + (size_t)t * 2;
-  // simulate_keys[b] = split(simulate_key, B)[b]: words 2b, 2b+1 of the flat stream
-  uint32_t k0, k1;
-  {
-    uint32_t x0, x1, y0, y1;
-    bool s0, s1;
-    bits_block(2 * p.global_batch, 2 * rg, x0, x1, s0);
-    bits_block(2 * p.global_batch, 2 * rg + 1, y0, y1, s1);
-    threefry2x32(p.sim_keys[sim][0], p.sim_keys[sim][1], x0, x1);
-    threefry2x32(p.sim_keys[sim][0], p.sim_keys[sim][1], y0, y1);
-    k0 = s0 ? x1 : x0;
-    k1 = s1 ? y1 : y0;
-  }
-  int L = sim + 1;  // a simulation can never select deeper than its own index + 1
-  L = L < p.max_depth ? L : p.max_depth;
-  L = L < CAP ? L : CAP;
-  for (int d = 0; d < L; ++d) {
-    // rng_key, action_selection_key = split(rng_key)
-    uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
-    threefry2x32(k0, k1, a0, a1);
-    threefry2x32(k0, k1, b0, b1);
-    k0 = a0; k1 = b0;
-    const uint32_t s0 = a1, s1 = b1;
-    // 1e-7 * uniform(action_selection_key, (A,))
-    float out[A];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      uint32_t x0 = (uint32_t)i, x1 = (NB + i < A) ? (uint32_t)(NB + i) : 0u;
-      threefry2x32(s0, s1, x0, x1);
-      out[i] = 1e-7f * uniform_from_bits(x0);
-      if (NB + i < A) out[NB + i] = 1e-7f * uniform_from_bits(x1);
-    }
-    float* dst = nz + (size_t)d * p.B * A;
-#pragma unroll
-    for (int a = 0; a < A; ++a) dst[a] = out[a];
-  }
-  keys[0] = k0;  // walking key after L levels (continuation beyond CAP)
-  keys[1] = k1;
-}
 
 // y = x . W + b for row-distributed vectors; W column(s) of this lane in VGPRs.
 template <int NIN, int NOUT>
@@ -349,6 +298,33 @@ MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const floa
   }
 }
 
+// First-max argmax of the cached scores and the noise-independence test: mctx adds
+// 1e-7 * uniform[0,1) to every score; if fl(score_a + 1e-7) < score_best for every other
+// action, then for ANY draw fl(score_a + n_a) <= fl(score_a + 1e-7) < score_best <=
+// fl(score_best + n_best) (rounding is monotone), so the argmax cannot change.
+template <int A, bool TB, int NODE_BYTES>
+MZ_DEV void decide(const float (&sc)[A], const int (&cidx)[A], int node, int& next_off, int& pathword) {
+  int best = 0;
+  float bs = sc[0];
+  int nxt = cidx[0];
+#pragma unroll
+  for (int a = 1; a < A; ++a) {
+    bool take = sc[a] > bs;  // first max wins
+    bs = take ? sc[a] : bs;
+    best = take ? a : best;
+    nxt = take ? cidx[a] : nxt;
+  }
+  bool safe = true;
+  if constexpr (TB) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) safe = safe && (a == best || (sc[a] + 1e-7f) < bs);
+  }
+  // byte offset of the chosen child's record; -1: child not expanded yet; -2: near tie
+  const int off = nxt < 0 ? -1 : (int)__umul24((unsigned)nxt, (unsigned)NODE_BYTES);
+  next_off = safe ? off : -2;
+  pathword = node | (best << 16);
+}
+
 template <class C>
 __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const FusedParams p) {
   constexpr int A = C::A, E = C::E, NS = C::NS;
@@ -367,7 +343,6 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   float* tree = lds + C::TBL_WORDS + root_in_wg * C::ROOT_WORDS;
   int* itree = reinterpret_cast<int*>(tree);
   int* path = itree + C::TREE_WORDS;
-  float* nzbuf = tree + C::TREE_WORDS + C::PATH_WORDS;  // [2][CAP][A]
   const uint64_t rg = p.root_offset + (uint64_t)r;
   const int S = p.S;
   const int max_depth = p.max_depth > 0 ? p.max_depth : S;
@@ -378,48 +353,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   Nets<C> nets;
   nets.load(p, j);
 
-  // tie-break noise travels HBM -> VGPR -> LDS: lane j carries levels j and j+16 of the next
-  // simulation, fetched one simulation ahead so the HBM latency hides behind a whole simulation
-  float npf[2][A];
-  auto level_limit = [&](int sim) {
-    int L = sim + 1;
-    L = L < max_depth ? L : max_depth;
-    return L < C::CAP ? L : C::CAP;
-  };
-  auto noise_fetch = [&](int sim) {
-    if constexpr (C::TB) {
-      const float* src = reinterpret_cast<const float*>(p.noise_rows) + ((size_t)sim * C::CAP * p.B + r) * A;
-      const int L = level_limit(sim);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int d = j + 16 * t;
-        if (d < L) {
-#pragma unroll
-          for (int a = 0; a < A; ++a) npf[t][a] = src[(size_t)d * p.B * A + a];
-        }
-      }
-    }
-  };
-  auto noise_commit = [&](int sim) {
-    if constexpr (C::TB) {
-      float* dst = nzbuf + (sim & 1) * C::CAP * A;
-      const int L = level_limit(sim);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int d = j + 16 * t;
-        if (d < L) {
-#pragma unroll
-          for (int a = 0; a < A; ++a) dst[d * A + a] = npf[t][a];
-        }
-      }
-    }
-  };
-  noise_fetch(0);
-
   // ---- tree init (mctx instantiate_tree_from_root) ----
   for (int n = 0; n < N; ++n) {
     for (int wq = j; wq < NS; wq += 16) {
-      bool is_index = wq < 2 * A && (wq & 1) == 0;
+      bool is_index = wq >= C::SEL0 && wq < C::SEL0 + 2 * A && ((wq - C::SEL0) & 1) == 0;
       itree[n * NS + wq] = is_index ? -1 : 0;
     }
   }
@@ -490,101 +427,106 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = 0.0f;
     }
     puct_scores<A>(v0, tbl[1], prob, val, vis, rew, dis, sc);
+    int cidx[A], nx, pw;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      cidx[a] = -1;
+      sc[a] = ((inv_bits >> a) & 1u) ? -INFINITY : sc[a];  // the root is only ever selected at depth 0
+    }
+    decide<A, C::TB, 4 * NS>(sc, cidx, 0, nx, pw);
     if (j == 0) {
 #pragma unroll
       for (int a = 0; a < A; ++a) tree[C::SEL0 + 2 * a + 1] = sc[a];
+      itree[C::FAST0] = nx;
+      itree[C::FAST0 + 1] = pw;
     }
   }
-  noise_commit(0);
 
   int depth_total = 0;
+#ifdef MZ_PROFILE
+  uint64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- simulations (mctx search.search body_fun) ----
   for (int sim = 0; sim < S; ++sim) {
-    if (sim + 1 < S) noise_fetch(sim + 1);
-    const float* nz = nzbuf + (sim & 1) * C::CAP * A;
-    const int avail = C::TB ? level_limit(sim) : 0;
-
-    // -- simulate (mctx search.simulate): every lane of the row walks identically --
-    int node = 0, depth = 0, parent = 0, action = 0, next = -1;
-    uint32_t fk0 = 0, fk1 = 0;  // walking key beyond the produced levels
-    auto select_level = [&](auto fb_tag) {
-      constexpr bool FB = decltype(fb_tag)::value;
-      const int* ndi = itree + __umul24((unsigned)node, (unsigned)NS);
-      int cidx[A];
-      float score[A];
-      {
-        // the selection record {child, score} x A: 16-byte LDS reads
-        const uint4* rec = reinterpret_cast<const uint4*>(ndi + C::SEL0);
-        uint4 sel[C::SELW / 4];
+    MZ_TICK(0);
+    // -- simulate (mctx search.simulate): every lane of the row walks identically.  The loop
+    // body is predicated instead of branching per row: a row that has finished keeps re-reading
+    // its last node (idempotent), so the only branch per level is the wave-uniform back edge. --
+    int depth = 0, next = -1, pw = 0;
+    {
+      const char* tbytes = reinterpret_cast<const char*>(itree);
+      int node_off = 0;
+      bool active = true;
+      uint32_t fk0 = 0, fk1 = 0, fs0 = 0, fs1 = 0;  // lazy key walk: rng_key / action_selection_key
+      int fk_level = -1;                             // levels already split off (-1: not started)
+      do {
+        const int2 fr = *reinterpret_cast<const int2*>(tbytes + node_off + 4 * C::FAST0);
+        int nx = fr.x, pword = fr.y;
+        if constexpr (C::TB) {
+          if (active && nx == -2) {
+            // near tie: evaluate score + 1e-7 * uniform(action_selection_key_depth) exactly as mctx
+            const int* ndi = reinterpret_cast<const int*>(tbytes + node_off);
+            if (fk_level < 0) {
+              // simulate_keys[b] = split(simulate_key, B)[b]: words 2b, 2b+1 of the flat stream
+              uint32_t x0, x1;
+              bool second;
+              bits_block(2 * p.global_batch, 2 * rg + (uint64_t)(j & 1), x0, x1, second);
+              threefry2x32(p.sim_keys[sim][0], p.sim_keys[sim][1], x0, x1);
+              uint32_t word = second ? x1 : x0;
+              fk0 = bcast_u<0>(word);
+              fk1 = bcast_u<1>(word);
+              fk_level = 0;
+            }
+            while (fk_level <= depth) {
+              // rng_key, action_selection_key = split(rng_key): lanes 0/1 hash one block each
+              uint32_t x0 = (uint32_t)(j & 1), x1 = 2u + (uint32_t)(j & 1);
+              threefry2x32(fk0, fk1, x0, x1);
+              fk0 = bcast_u<0>(x0); fk1 = bcast_u<1>(x0);
+              fs0 = bcast_u<0>(x1); fs1 = bcast_u<1>(x1);
+              fk_level += 1;
+            }
+            constexpr int NB = (A + 1) / 2;
+            const int jb = j % NB;
+            uint32_t x0 = (uint32_t)jb, x1 = (NB + jb < A) ? (uint32_t)(NB + jb) : 0u;
+            threefry2x32(fs0, fs1, x0, x1);
+            int cidx[A];
+            float score[A];
+            StaticFor<0, A>::run([&](auto ic) {
+              constexpr int a = decltype(ic)::value;
+              const uint32_t bits = bcast_u<(a % NB)>(a < NB ? x0 : x1);
+              cidx[a] = ndi[C::SEL0 + 2 * a];
+              score[a] = __int_as_float(ndi[C::SEL0 + 2 * a + 1]) + 1e-7f * uniform_from_bits(bits);
+            });
+            int best = 0, bn = cidx[0];
+            float bs = score[0];
 #pragma unroll
-        for (int q = 0; q < C::SELW / 4; ++q) sel[q] = rec[q];
-        const uint32_t* sw = reinterpret_cast<const uint32_t*>(sel);
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-          cidx[a] = (int)sw[2 * a];
-          score[a] = __uint_as_float(sw[2 * a + 1]);
-        }
-      }
-      if constexpr (C::TB) {
-        if (!FB || depth < avail) {
-#pragma unroll
-          for (int a = 0; a < A; ++a) score[a] = score[a] + nz[depth * A + a];
-        } else {
-          // beyond the produced levels: continue the key walk in place (only when depth >= CAP)
-          constexpr int NB = (A + 1) / 2;
-          uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
-          threefry2x32(fk0, fk1, a0, a1);
-          threefry2x32(fk0, fk1, b0, b1);
-          fk0 = a0; fk1 = b0;
-#pragma unroll
-          for (int i = 0; i < NB; ++i) {
-            uint32_t x0 = (uint32_t)i, x1 = (NB + i < A) ? (uint32_t)(NB + i) : 0u;
-            threefry2x32(a1, b1, x0, x1);
-            score[i] = score[i] + 1e-7f * uniform_from_bits(x0);
-            if (NB + i < A) score[NB + i] = score[NB + i] + 1e-7f * uniform_from_bits(x1);
+            for (int a = 1; a < A; ++a) {
+              bool take = score[a] > bs;  // first max wins
+              bs = take ? score[a] : bs;
+              best = take ? a : best;
+              bn = take ? cidx[a] : bn;
+            }
+            nx = bn < 0 ? -1 : (int)__umul24((unsigned)bn, (unsigned)(4 * NS));
+            pword = (pword & 0xffff) | (best << 16);
           }
         }
-      }
-      const uint32_t mask = depth == 0 ? inv_bits : 0u;
-      int best = 0, nxt = cidx[0];
-      float bs = (mask & 1u) ? -INFINITY : score[0];
-#pragma unroll
-      for (int a = 1; a < A; ++a) {
-        float sa = ((mask >> a) & 1u) ? -INFINITY : score[a];
-        bool take = sa > bs;  // first max wins
-        bs = take ? sa : bs;
-        best = take ? a : best;
-        nxt = take ? cidx[a] : nxt;
-      }
-      path[depth] = node | (best << 16);  // every lane of the row stores the same word
-      parent = node;
-      action = best;
-      next = nxt;
-      depth += 1;
-    };
-    // a simulation selects at most min(sim + 1, max_depth) levels: the in-place key walk is
-    // reachable only when that exceeds CAP (wave-uniform test)
-    const int reach = sim + 1 < max_depth ? sim + 1 : max_depth;
-    if (C::TB && reach > C::CAP) {
-      const uint32_t* kw = p.noise_rows + (size_t)p.S * C::CAP * p.B * A + ((size_t)sim * p.B + r) * 2;
-      fk0 = kw[0];
-      fk1 = kw[1];
-      for (;;) {
-        select_level(std::true_type{});
-        if (next == -1 || depth >= max_depth) break;
-        node = next;
-      }
-    } else {
-      for (;;) {
-        select_level(std::false_type{});
-        if (next == -1 || depth >= max_depth) break;
-        node = next;
-      }
+        path[depth] = pword;  // (a finished row rewrites slot `depth`, which expand overwrites)
+        const bool done = nx < 0 || depth + 1 >= max_depth;
+        next = active ? nx : next;
+        pw = active ? pword : pw;
+        depth += active ? 1 : 0;
+        node_off = (active && !done) ? nx : node_off;
+        active = active && !done;
+      } while (__builtin_amdgcn_ballot_w64(active) != 0);
     }
+    const int parent = pw & 0xffff, action = pw >> 16;
     depth_total += depth;
-    const bool fresh = next == -1;
-    const int newn = fresh ? sim + 1 : next;
+    MZ_TICK(1);  // select
+    const bool fresh = next < 0;
+    // max_depth cut an already expanded child (mctx re-expands it): its index sits in the parent's record
+    const int newn = fresh ? sim + 1 : itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
 
     // -- expand (mctx search.expand, recurrent_fn = muax/model.py:265-282) --
     float sp[C::ES];
@@ -594,8 +536,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float reward, value, pil;
     float ns[C::ES];
     nets.dynamics(sp, action, j, support, reward, ns);
+    MZ_TICK(2);  // dynamics (+ parent embedding gather)
     if (p.pred_on_parent) nets.predict(sp, j, support, value, pil);
     else nets.predict(ns, j, support, value, pil);
+    MZ_TICK(3);  // prediction
     float px[1] = {pil}, pp[1];
     row_softmax<A>(px, j, pp);
     {
@@ -626,6 +570,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       }
     }
 
+    MZ_TICK(4);  // prior softmax + expand stores
     // -- backward (mctx search.backward) + score refresh, lane e <-> path entry e --
     // entries 0..depth-1 are the (parent, action) edges of the path, entry `depth` is the leaf.
     {
@@ -682,9 +627,19 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         const float nval = edge ? newv : pv;
         float sc[A];
         puct_scores<A>(nval, tbl[valid ? nvis : 0], prob, val, vis, rew, dis, sc);
+        int cidx[A], nx, pw2;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          cidx[a] = ndi[C::SEL0 + 2 * a];
+          // root_invalid_actions mask: the root is only ever selected at depth 0
+          sc[a] = (pn == 0 && ((inv_bits >> a) & 1u)) ? -INFINITY : sc[a];
+        }
+        decide<A, C::TB, 4 * NS>(sc, cidx, pn, nx, pw2);
         if (valid) {
 #pragma unroll
           for (int a = 0; a < A; ++a) nd[C::SEL0 + 2 * a + 1] = sc[a];
+          ndi[C::FAST0] = nx;
+          ndi[C::FAST0 + 1] = pw2;
         }
         if (edge) {
           ndi[C::HDR0] = nvis;
@@ -701,8 +656,14 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         }
       }
     }
-    if (sim + 1 < S) noise_commit(sim + 1);
+    MZ_TICK(5);  // backward + score refresh
   }
+#ifdef MZ_PROFILE
+  if (p.prof != nullptr && lane == 0) {
+    uint64_t* dst = p.prof + ((size_t)blockIdx.x * C::WAVES + (tid >> 6)) * 8;
+    for (int q = 0; q < 8; ++q) dst[q] = prof_acc[q];
+  }
+#endif
 
   // ---- summary + sample (mctx Tree.summary, _apply_temperature, categorical) ----
   {

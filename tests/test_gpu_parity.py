@@ -93,6 +93,31 @@ def test_fused_temperature_zero_no_noise_parent_quirk(oracle):
     assert (vc[np.arange(len(a)), a] == vc.max(axis=1)).all()
 
 
+@pytest.mark.parametrize("A,E,S", [(2, 8, 50), (4, 8, 30), (3, 8, 24)])
+def test_fused_all_ties_noise_decides(oracle, A, E, S):
+    """Degenerate nets (all-zero weights): uniform priors, zero values and rewards, so EVERY selection
+    is an exact tie and mctx's 1e-7*uniform tie-break noise decides it.  Exercises the kernel's
+    near-tie path (on-demand threefry key walk) at every level; the result must still be bit-exact,
+    and it must differ from the no-noise search."""
+    case = make_case(oracle, 77, 48, 4, E, A, S)
+    case["w"] = {k: np.zeros_like(v) for k, v in case["w"].items()}
+    key = [11, 22]
+    s, out = _fused(case, True, key, use_noise=False)
+    ref = _oracle(oracle, case, True, key, use_noise=False)
+    _compare(ref, s, out)
+    s0, out0 = _fused(case, False, key, use_noise=False)
+    _compare(_oracle(oracle, case, False, key, use_noise=False), s0, out0)
+    assert not torch.equal(out.search_tree.children_index, out0.search_tree.children_index)
+
+
+def test_fused_small_margins(oracle):
+    """Tiny weights: score margins straddle the 1e-7 noise scale, mixing cached and noisy decisions."""
+    case = make_case(oracle, 78, 64, 4, 8, 2, 40)
+    case["w"] = {k: (v * 1e-4).astype(np.float32) for k, v in case["w"].items()}
+    s, out = _fused(case, True, [5, 5], use_noise=False)
+    _compare(_oracle(oracle, case, True, [5, 5], use_noise=False), s, out)
+
+
 def test_fused_sharding_invariance(oracle):
     """A shard (global_batch, root_offset) reproduces the same roots of the full batch bit for bit."""
     case = make_case(oracle, 8, 96, 4, 8, 2, 20)

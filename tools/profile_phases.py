@@ -1,0 +1,62 @@
+"""In-kernel phase timing of the fused search kernel (s_memtime), via a -DMZ_PROFILE build.
+
+    python tools/profile_phases.py build      # here (cross-compiles)  -> tools/bin/libmzsearch_prof.so
+    python tools/profile_phases.py run        # on the GPU box
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "tools", "bin", "libmzsearch_prof.so")
+PHASES = ["loop top", "select", "dynamics", "prediction", "prior softmax + expand", "backward + scores",
+          "noise commit", "-"]
+
+
+def build():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                           "-fPIC", "-shared", "-Wno-unused-value", "-DMZ_PROFILE", "-o", LIB,
+                           os.path.join(ROOT, "muax_amd", "csrc", "mz_api.hip")])
+    print(LIB)
+
+
+def run():
+    import numpy as np
+    import torch
+    from muax_amd import _build, _lib
+    _build.LIB_PATH = LIB
+    _lib._lib = None
+    import bench
+    from muax_amd import MuZeroSearch, SearchConfig
+    B, obs_dim, E, A, support, S = bench.WORKLOADS["cartpole"]
+    w = bench.haiku_style_weights(0, obs_dim, E, A, 2 * support + 1)
+    g = torch.Generator().manual_seed(1000)
+    obs = (torch.rand(B, obs_dim, generator=g) * 2 - 1).cuda()
+    noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)).cuda()
+    s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True))
+    s.set_mlp_weights(w, obs_dim, support)
+    waves = B // 4
+    prof = torch.zeros(waves, 8, dtype=torch.int64, device="cuda")
+    L = _lib.load()
+    L.mzs_debug_profile.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.mzs_debug_profile(s._h, C.c_void_p(prof.data_ptr())) == 0
+    for i in range(3):
+        s.act_mlp(obs, (0, i), dirichlet_noise=noise)
+    torch.cuda.synchronize()
+    p = prof.cpu().numpy().astype(np.float64)
+    tot = p.sum(1)
+    print(f"waves {waves}; cycles per wave: mean {tot.mean():.0f} max {tot.max():.0f} min {tot.min():.0f}")
+    depth = s.depth_sum.cpu().numpy().reshape(waves, 4)
+    print(f"mean selection depth {depth.mean() / S:.2f}; per-wave sum of max-of-4 is not tracked here")
+    for k, name in enumerate(PHASES[:7]):
+        print(f"  {name:26s} {p[:, k].mean() / S:9.0f} cycles/sim  ({100 * p[:, k].sum() / tot.sum():5.1f}%)   "
+              f"slowest wave {p[:, k].max() / S:9.0f}")
+    slow = int(tot.argmax())
+    print("slowest wave", slow, "phases/sim:", (p[slow] / S).round(0).tolist(), "depth sums", depth[slow].tolist())
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1]]()

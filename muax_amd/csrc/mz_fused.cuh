@@ -16,10 +16,16 @@
 //     phase, where lane e owns path entry e (all levels in parallel).  mctx's
 //     tie-break noise is < 1e-7, so a decision whose runner-up satisfies
 //     fl(score + 1e-7) < best is provably independent of the noise (rounding is
-//     monotone); such nodes store {next node, path word} and the sequential
-//     selection loop is one 8-byte LDS read per level.  Only near-tie nodes
-//     evaluate score + noise, drawing JAX's threefry stream on demand (lazy key
-//     walk per simulation) -- bit-identical to drawing it at every level;
+//     monotone).  Only near-tie nodes evaluate score + noise, drawing JAX's
+//     threefry stream on demand (lazy key walk per simulation) -- bit-identical
+//     to drawing it at every level;
+//   * selection does not walk level by level: every node carries a JUMP word,
+//     the end point (parent, action, depth) of the greedy descent below it,
+//     valid because sub-trees off the backed-up path never change; the path
+//     nodes' words are refreshed with a log-step DPP scan.  Every node also
+//     stores its own root path as packed bytes (written once at expansion), so
+//     the backup lanes find their entries without a walk.  One simulation's
+//     selection is O(1) LDS reads plus one exact noisy evaluation per near tie;
 //   * backup's discounted-return chain runs over row broadcasts, everything
 //     else of backup is lane-parallel;
 //   * the MLPs run as row-distributed fma chains: input element i lives in lane
@@ -88,23 +94,32 @@ struct FusedCfg {
   static constexpr int H = kHidden;
   static constexpr int ES = (E + 15) / 16, FS = (F + 15) / 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
-  //   [FAST0 ..) {byte offset of the next node | -1 unvisited | -2 near tie, path word node|action<<16}
   //   [SEL0  ..) A x {child index, cached pUCT score}
-  //   [HDR0  ..) visits, value, pad, pad
+  //   [HDR0  ..) visits, value, JUMP word, pad
   //   [ST0   ..) A x {prob, value, visits, reward, discount, pad}
   //   [EMB0  ..) embedding
-  static constexpr int FAST0 = 0, SEL0 = 2, SELW = ((2 + 2 * A + 3) / 4) * 4;
-  static constexpr int HDR0 = SELW;
+  //   [PATH0 ..) this node's own root path, one packed (node, action) entry per level
+  // JUMP word: end point of the greedy descent below this node:
+  //   parent[0:12) | action[12:16) | depth of parent[16:24) | bit 31: the end point is a near tie
+  static constexpr int SEL0 = 0, SELW = ((2 * A + 3) / 4) * 4;
+  static constexpr int HDR0 = SELW, JUMP = HDR0 + 2;
   static constexpr int ST0 = HDR0 + 4, STW = 6;
   static constexpr int EMB0 = ST0 + STW * A;
-  static constexpr int NS = ((EMB0 + E + 3) / 4) * 4;
+  static constexpr int ENTRY_BITS = (NMAX <= 64 && A <= 4) ? 8 : 16;
+  static constexpr int ENTRY_ACT_SHIFT = ENTRY_BITS == 8 ? 6 : 12;
+  static constexpr int PATH0 = EMB0 + E;
+  static constexpr int PATHW = (NMAX * ENTRY_BITS + 31) / 32;
+  static constexpr int NS = ((PATH0 + PATHW + 3) / 4) * 4;
   static constexpr int TREE_WORDS = NS * NMAX;
-  static constexpr int PATH_WORDS = ((NMAX + 1 + 3) / 4) * 4;
+  static constexpr int PATH_WORDS = 0;
   static constexpr int NOISE_WORDS = 0;
+  static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
+  static_assert(PATHW <= 16, "a node's path is copied by one lane per word");
   static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
   static constexpr int TBL_WORDS = ((NMAX + 2 + 3) / 4) * 4;
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
+  static_assert(LDS_BYTES <= 160 * 1024, "tree does not fit the 160 KiB LDS of a CU: lower WAVES");
   static_assert(A <= 8, "selection keeps all A scores in registers");
   static_assert(F <= 32 && E <= 32 * 16, "row-distributed vectors");
 };
@@ -302,27 +317,26 @@ MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const floa
 // 1e-7 * uniform[0,1) to every score; if fl(score_a + 1e-7) < score_best for every other
 // action, then for ANY draw fl(score_a + n_a) <= fl(score_a + 1e-7) < score_best <=
 // fl(score_best + n_best) (rounding is monotone), so the argmax cannot change.
-template <int A, bool TB, int NODE_BYTES>
-MZ_DEV void decide(const float (&sc)[A], const int (&cidx)[A], int node, int& next_off, int& pathword) {
-  int best = 0;
+template <int A, bool TB>
+MZ_DEV void decide(const float (&sc)[A], const int (&cidx)[A], int& best, int& child, bool& safe) {
+  best = 0;
   float bs = sc[0];
-  int nxt = cidx[0];
+  child = cidx[0];
 #pragma unroll
   for (int a = 1; a < A; ++a) {
     bool take = sc[a] > bs;  // first max wins
     bs = take ? sc[a] : bs;
     best = take ? a : best;
-    nxt = take ? cidx[a] : nxt;
+    child = take ? cidx[a] : child;
   }
-  bool safe = true;
+  safe = true;
   if constexpr (TB) {
 #pragma unroll
     for (int a = 0; a < A; ++a) safe = safe && (a == best || (sc[a] + 1e-7f) < bs);
   }
-  // byte offset of the chosen child's record; -1: child not expanded yet; -2: near tie
-  const int off = nxt < 0 ? -1 : (int)__umul24((unsigned)nxt, (unsigned)NODE_BYTES);
-  next_off = safe ? off : -2;
-  pathword = node | (best << 16);
+}
+MZ_DEV int jump_word(int node, int action, int depth, bool near_tie) {
+  return node | (action << 12) | (depth << 16) | (near_tie ? (int)0x80000000 : 0);
 }
 
 template <class C>
@@ -333,16 +347,17 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   const int lane = tid & 63;
   const int j = lane & 15;
   const int root_in_wg = (tid >> 6) * 4 + (lane >> 4);
-  const int r = blockIdx.x * C::ROOTS_PER_WG + root_in_wg;
+  // rows past the end of the batch shadow the last root (identical values, identical stores): every
+  // lane stays live, so wave-uniform control flow below can read any row with v_readlane
+  const int r_raw = blockIdx.x * C::ROOTS_PER_WG + root_in_wg;
+  const int r = r_raw < p.B ? r_raw : p.B - 1;
 
   float* tbl = lds;  // sqrt(n) * pb_c(n) by visit count
   for (int i = tid; i < C::TBL_WORDS; i += C::THREADS) tbl[i] = puct_scale(i, p.pb_c_init, p.pb_c_base);
-  __syncthreads();
-  if (r >= p.B) return;  // whole row leaves together; no barrier below
+  __syncthreads();  // the only barrier
 
   float* tree = lds + C::TBL_WORDS + root_in_wg * C::ROOT_WORDS;
   int* itree = reinterpret_cast<int*>(tree);
-  int* path = itree + C::TREE_WORDS;
   const uint64_t rg = p.root_offset + (uint64_t)r;
   const int S = p.S;
   const int max_depth = p.max_depth > 0 ? p.max_depth : S;
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   // ---- tree init (mctx instantiate_tree_from_root) ----
   for (int n = 0; n < N; ++n) {
     for (int wq = j; wq < NS; wq += 16) {
-      bool is_index = wq >= C::SEL0 && wq < C::SEL0 + 2 * A && ((wq - C::SEL0) & 1) == 0;
+      bool is_index = wq < 2 * A && (wq & 1) == 0;
       itree[n * NS + wq] = is_index ? -1 : 0;
     }
   }
@@ -427,18 +442,18 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = 0.0f;
     }
     puct_scores<A>(v0, tbl[1], prob, val, vis, rew, dis, sc);
-    int cidx[A], nx, pw;
+    int cidx[A], best, child;
+    bool safe;
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       cidx[a] = -1;
       sc[a] = ((inv_bits >> a) & 1u) ? -INFINITY : sc[a];  // the root is only ever selected at depth 0
     }
-    decide<A, C::TB, 4 * NS>(sc, cidx, 0, nx, pw);
+    decide<A, C::TB>(sc, cidx, best, child, safe);
     if (j == 0) {
 #pragma unroll
       for (int a = 0; a < A; ++a) tree[C::SEL0 + 2 * a + 1] = sc[a];
-      itree[C::FAST0] = nx;
-      itree[C::FAST0 + 1] = pw;
+      itree[C::JUMP] = jump_word(0, best, 0, !safe);
     }
   }
 
@@ -451,23 +466,21 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   // ---- simulations (mctx search.search body_fun) ----
   for (int sim = 0; sim < S; ++sim) {
     MZ_TICK(0);
-    // -- simulate (mctx search.simulate): every lane of the row walks identically.  The loop
-    // body is predicated instead of branching per row: a row that has finished keeps re-reading
-    // its last node (idempotent), so the only branch per level is the wave-uniform back edge. --
-    int depth = 0, next = -1, pw = 0;
+    // -- simulate (mctx search.simulate) through the JUMP words: one iteration per near tie --
+    int parent, action, dP;
     {
-      const char* tbytes = reinterpret_cast<const char*>(itree);
-      int node_off = 0;
-      bool active = true;
+      int cur = 0;
       uint32_t fk0 = 0, fk1 = 0, fs0 = 0, fs1 = 0;  // lazy key walk: rng_key / action_selection_key
       int fk_level = -1;                             // levels already split off (-1: not started)
-      do {
-        const int2 fr = *reinterpret_cast<const int2*>(tbytes + node_off + 4 * C::FAST0);
-        int nx = fr.x, pword = fr.y;
+      for (;;) {
+        const int jw = itree[__umul24((unsigned)cur, (unsigned)NS) + C::JUMP];
+        parent = jw & 0xfff;
+        action = (jw >> 12) & 0xf;
+        dP = (jw >> 16) & 0xff;
         if constexpr (C::TB) {
-          if (active && nx == -2) {
-            // near tie: evaluate score + 1e-7 * uniform(action_selection_key_depth) exactly as mctx
-            const int* ndi = reinterpret_cast<const int*>(tbytes + node_off);
+          if (jw < 0 && dP + 1 <= max_depth) {
+            // near tie at `parent` (level dP): score + 1e-7 * uniform(action_selection_key_dP), as mctx
+            const int* ndi = itree + __umul24((unsigned)parent, (unsigned)NS);
             if (fk_level < 0) {
               // simulate_keys[b] = split(simulate_key, B)[b]: words 2b, 2b+1 of the flat stream
               uint32_t x0, x1;
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
               fk1 = bcast_u<1>(word);
               fk_level = 0;
             }
-            while (fk_level <= depth) {
+            while (fk_level <= dP) {
               // rng_key, action_selection_key = split(rng_key): lanes 0/1 hash one block each
               uint32_t x0 = (uint32_t)(j & 1), x1 = 2u + (uint32_t)(j & 1);
               threefry2x32(fk0, fk1, x0, x1);
@@ -508,25 +521,31 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
               best = take ? a : best;
               bn = take ? cidx[a] : bn;
             }
-            nx = bn < 0 ? -1 : (int)__umul24((unsigned)bn, (unsigned)(4 * NS));
-            pword = (pword & 0xffff) | (best << 16);
+            action = best;
+            if (bn >= 0 && dP + 1 < max_depth) {
+              cur = bn;  // the noisy choice is an expanded child within reach: keep descending from it
+              continue;
+            }
           }
         }
-        path[depth] = pword;  // (a finished row rewrites slot `depth`, which expand overwrites)
-        const bool done = nx < 0 || depth + 1 >= max_depth;
-        next = active ? nx : next;
-        pw = active ? pword : pw;
-        depth += active ? 1 : 0;
-        node_off = (active && !done) ? nx : node_off;
-        active = active && !done;
-      } while (__builtin_amdgcn_ballot_w64(active) != 0);
+        break;
+      }
     }
-    const int parent = pw & 0xffff, action = pw >> 16;
+    int depth = dP + 1;
+    if (depth > max_depth) {
+      // the cached descent overshoots max_depth: stop at level max_depth - 1 of the same path
+      depth = max_depth;
+      const int* pb = itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
+      const int e = depth - 1;
+      const int ent = (pb[(e * C::ENTRY_BITS) >> 5] >> ((e * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
+      parent = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
+      action = ent >> C::ENTRY_ACT_SHIFT;
+    }
+    const int next = itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
     depth_total += depth;
     MZ_TICK(1);  // select
     const bool fresh = next < 0;
-    // max_depth cut an already expanded child (mctx re-expands it): its index sits in the parent's record
-    const int newn = fresh ? sim + 1 : itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
+    const int newn = fresh ? sim + 1 : next;  // (an expanded child is only re-expanded at the max_depth cut)
 
     // -- expand (mctx search.expand, recurrent_fn = muax/model.py:265-282) --
     float sp[C::ES];
@@ -550,15 +569,25 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #pragma unroll
       for (int t = 0; t < C::ES; ++t)
         if (j + 16 * t < E) nn[C::EMB0 + j + 16 * t] = ns[t];
+      const unsigned po = __umul24((unsigned)parent, (unsigned)NS);
       if (j == 0) {
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
-        const unsigned po = __umul24((unsigned)parent, (unsigned)NS);
         itree[po + C::SEL0 + 2 * action] = newn;
         tree[po + C::ST0 + C::STW * action + 3] = reward;
         tree[po + C::ST0 + C::STW * action + 4] = p.discount;
       }
-      path[depth] = newn;  // leaf entry of the update phase (every lane stores the same word)
+      if (fresh && j < C::PATHW) {
+        // the new node's root path = its parent's path + (parent, action); written once
+        const int e = depth - 1;
+        int w = itree[po + C::PATH0 + j];
+        const int sh = (e * C::ENTRY_BITS) & 31;
+        const int ent = parent | (action << C::ENTRY_ACT_SHIFT);
+        w = (j == ((e * C::ENTRY_BITS) >> 5))
+                ? (int)(((unsigned)w & ~(((1u << C::ENTRY_BITS) - 1u) << sh)) | ((unsigned)ent << sh))
+                : w;
+        nni[C::PATH0 + j] = w;
+      }
       if (ex) {
         size_t o = (size_t)r * N + newn;
         if (j < A) p.t_children_prior_logits[o * A + j] = pil;
@@ -571,26 +600,45 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     }
 
     MZ_TICK(4);  // prior softmax + expand stores
-    // -- backward (mctx search.backward) + score refresh, lane e <-> path entry e --
+    // -- backward (mctx search.backward) + decision refresh, lane e <-> path entry e --
     // entries 0..depth-1 are the (parent, action) edges of the path, entry `depth` is the leaf.
     {
-      float G = value;      // leaf_value walking up (row uniform)
-      float carry = value;  // node value of the entry just below this chunk
-      for (int c = depth >> 4; c >= 0; --c) {
+      // wave-uniform trip counts: the deepest of the wave's four rows
+      int wmax = __builtin_amdgcn_readlane(depth, 0);
+      wmax = max(wmax, __builtin_amdgcn_readlane(depth, 16));
+      wmax = max(wmax, __builtin_amdgcn_readlane(depth, 32));
+      wmax = max(wmax, __builtin_amdgcn_readlane(depth, 48));
+      const int* ppath = itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
+      float G = value;        // leaf_value walking up (row uniform)
+      float carry_v = value;  // node value of the entry just below this chunk
+      int carry_n = -1;       // node index of the entry just below this chunk
+      int carry_j = 0;        // resolved JUMP word of the entry just below this chunk
+      for (int c = wmax >> 4; c >= 0; --c) {
         const int e = 16 * c + j;
         const bool valid = e <= depth;
         const bool isleaf = e == depth;
         const bool edge = e < depth;
-        const int pk = valid ? path[e] : 0;
-        const int pn = pk & 0xffff, pa = isleaf ? 0 : (pk >> 16);
+        int pn, pa;
+        {
+          const int ec = e < depth - 1 ? e : 0;
+          const int ent = (ppath[(ec * C::ENTRY_BITS) >> 5] >> ((ec * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
+          pn = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
+          pa = ent >> C::ENTRY_ACT_SHIFT;
+          pn = e == depth - 1 ? parent : pn;
+          pa = e == depth - 1 ? action : pa;
+          pn = isleaf ? newn : pn;
+          pa = isleaf ? 0 : pa;
+          pn = valid ? pn : 0;
+        }
         float* nd = tree + __umul24((unsigned)pn, (unsigned)NS);
         int* ndi = reinterpret_cast<int*>(nd);
         const int cnt = ndi[C::HDR0];
         const float pv = nd[C::HDR0 + 1];
         float prob[A], val[A], rew[A], dis[A];
-        int vis[A];
+        int vis[A], cidx[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) {
+          cidx[a] = ndi[C::SEL0 + 2 * a];
           prob[a] = nd[C::ST0 + C::STW * a + 0];
           val[a] = nd[C::ST0 + C::STW * a + 1];
           vis[a] = ndi[C::ST0 + C::STW * a + 2];
@@ -605,19 +653,30 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         }
         re = edge ? re : 0.0f;  // identity step for the leaf entry and for idle lanes
         ge = edge ? ge : 1.0f;
-        // leaf_value = reward + discount * leaf_value, deepest entry first
+        // leaf_value = reward + discount * leaf_value, deepest entry first; steps above the
+        // wave's deepest entry are identities for every row and are jumped over
         float Gown = G;
-        StaticFor<0, 16>::run([&](auto ic) {
-          constexpr int k = 15 - decltype(ic)::value;
-          G = bcast<k>(re) + bcast<k>(ge) * G;
-          Gown = (j == k) ? G : Gown;
-        });
+        const int kstart = min(15, wmax - 16 * c);
+#define MZ_GSTEP(k)                              \
+  case k:                                        \
+    G = bcast<k>(re) + bcast<k>(ge) * G;         \
+    Gown = (j == k) ? G : Gown;                  \
+    [[fallthrough]];
+        switch (kstart) {
+          MZ_GSTEP(15) MZ_GSTEP(14) MZ_GSTEP(13) MZ_GSTEP(12) MZ_GSTEP(11) MZ_GSTEP(10) MZ_GSTEP(9)
+          MZ_GSTEP(8) MZ_GSTEP(7) MZ_GSTEP(6) MZ_GSTEP(5) MZ_GSTEP(4) MZ_GSTEP(3) MZ_GSTEP(2) MZ_GSTEP(1)
+          MZ_GSTEP(0)
+          default: break;
+        }
+#undef MZ_GSTEP
         const float newv = (pv * (float)cnt + Gown) / ((float)cnt + 1.0f);
         // children_values[parent, action] = node_values[child]: the child is the next entry
         float childv = __int_as_float(__builtin_amdgcn_update_dpp(
-            __float_as_int(carry), __float_as_int(newv), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+            __float_as_int(carry_v), __float_as_int(newv), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
         childv = (e == depth - 1) ? value : childv;
-        carry = bcast<0>(newv);
+        carry_v = bcast<0>(newv);
+        const int next_pn = __builtin_amdgcn_update_dpp(carry_n, pn, 0x101, 0xf, 0xf, false);
+        carry_n = bcast_i<0>(pn);
 #pragma unroll
         for (int a = 0; a < A; ++a) {
           val[a] = (edge && pa == a) ? childv : val[a];
@@ -627,19 +686,34 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         const float nval = edge ? newv : pv;
         float sc[A];
         puct_scores<A>(nval, tbl[valid ? nvis : 0], prob, val, vis, rew, dis, sc);
-        int cidx[A], nx, pw2;
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-          cidx[a] = ndi[C::SEL0 + 2 * a];
-          // root_invalid_actions mask: the root is only ever selected at depth 0
+        for (int a = 0; a < A; ++a)  // root_invalid_actions: the root is only ever selected at depth 0
           sc[a] = (pn == 0 && ((inv_bits >> a) & 1u)) ? -INFINITY : sc[a];
-        }
-        decide<A, C::TB, 4 * NS>(sc, cidx, pn, nx, pw2);
+        int best, child;
+        bool safe;
+        decide<A, C::TB>(sc, cidx, best, child, safe);
+        // JUMP word: own end point, the off-path best child's cached word, or (when the best child
+        // is the next entry of this very path) whatever that entry resolves to
+        const bool inherit0 = valid && safe && child >= 0 && !isleaf && child == next_pn;
+        int jwd = jump_word(pn, best, e, !safe);
+        if (valid && safe && child >= 0 && !inherit0)
+          jwd = itree[__umul24((unsigned)child, (unsigned)NS) + C::JUMP];
+        int inh = inherit0 ? 1 : 0;
+#define MZ_JSCAN(d)                                                                              \
+  {                                                                                              \
+    const int jn = __builtin_amdgcn_update_dpp(carry_j, jwd, 0x100 + d, 0xf, 0xf, false);        \
+    const int in_ = __builtin_amdgcn_update_dpp(0, inh, 0x100 + d, 0xf, 0xf, false);             \
+    jwd = inh ? jn : jwd;                                                                        \
+    inh = inh ? in_ : 0;                                                                         \
+  }
+        MZ_JSCAN(1) MZ_JSCAN(2) MZ_JSCAN(4) MZ_JSCAN(8)
+#undef MZ_JSCAN
+        jwd = inh ? carry_j : jwd;  // 15 hops covered; a lane still inheriting reaches past the row end
+        carry_j = bcast_i<0>(jwd);
         if (valid) {
 #pragma unroll
           for (int a = 0; a < A; ++a) nd[C::SEL0 + 2 * a + 1] = sc[a];
-          ndi[C::FAST0] = nx;
-          ndi[C::FAST0 + 1] = pw2;
+          ndi[C::JUMP] = jwd;
         }
         if (edge) {
           ndi[C::HDR0] = nvis;
@@ -707,6 +781,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       if (j == 0) {
         p.t_node_visits[o] = ndi[C::HDR0];
         p.t_node_values[o] = nd[C::HDR0 + 1];
+#ifdef MZ_DEBUG_JUMP
+        p.t_raw_values[o] = nd[C::JUMP];  // debugging aid: raw JUMP word bits
+#endif
       }
       if (j < A) {
         int so = C::ST0 + C::STW * j;

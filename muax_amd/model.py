@@ -1,0 +1,261 @@
+"""MuZero model object with the reference's act() contract (muax/model.py:16-283; README-era
+constructor muax/frameworks/coax/model.py:101-110), backed by the HIP search.
+
+    model = MuZero(network)                       # muax/model.py:43-50
+    model = MuZero(repr_fn, pred_fn, dy_fn)       # muax/frameworks/coax/model.py:101-110
+    model.init(rng_key, sample_input)
+    a, pi, v = model.act(rng_key, obs, with_pi=True, with_value=True, num_simulations=50)
+
+What runs where: the default MLP trio of muax/nn.py is evaluated inside the fused gfx950 kernel (one
+launch per act); any other torch plugin nets run as torch modules between the step-wise kernels, at
+the points where mctx calls root_fn / recurrent_fn.  There is no CPU search path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import nn as mz_nn
+from . import prng
+from . import utils as mx_utils
+from .nn import MZNetwork, MZNetworkParams
+from .policy import MuZeroPolicy, Policy
+from .search import MuZeroSearch, PolicyOutput, SearchConfig
+
+
+def _dirichlet(key_words, alpha: float, shape, device) -> torch.Tensor:
+    """Root exploration noise Dir(alpha) drawn with torch from the dirichlet sub-key.  JAX's gamma
+    sampler is not restated: the draw is deterministic in the key but is NOT
+    bit-identical to jax.random.dirichlet; pass `dirichlet_noise=` to inject an exact array."""
+    g = torch.Generator(device="cpu").manual_seed((int(key_words[0]) << 32) | int(key_words[1]))
+    conc = torch.full(shape, float(alpha), dtype=torch.float64)
+    x = torch._standard_gamma(conc, generator=g).clamp_min(1e-300)
+    return (x / x.sum(dim=-1, keepdim=True)).to(torch.float32).to(device)
+
+
+class MuZero:
+    r"""MuZero algorithm (muax/model.py:16-50).
+
+    Parameters mirror the reference: `network` (MZNetwork) or the three plugin callables, `policy_class`
+    / `policy`, `optimizer`, `loss_fn`, `discount`, `support_size`.  `recurrent_pred_on` selects which
+    embedding the prediction net sees inside the search: "child" as muax/model.py:272, "parent" as the
+    pip-release class muax/frameworks/coax/model.py:447-448.
+    """
+
+    def __init__(self, network=None, prediction_fn=None, dynamic_fn=None, policy_class=MuZeroPolicy,
+                 policy: Optional[str] = None, optimizer=None, loss_fn=None, discount: float = 0.99,
+                 support_size: int = 10, recurrent_pred_on: str = "child", device=None,
+                 representation_fn=None):
+        if isinstance(network, MZNetwork):
+            self.network = network
+        else:
+            rep = representation_fn if representation_fn is not None else network
+            if rep is None or prediction_fn is None or dynamic_fn is None:
+                raise ValueError("give either an MZNetwork or representation_fn, prediction_fn and dynamic_fn")
+            self.network = MZNetwork(rep, prediction_fn, dynamic_fn)
+        if policy is not None:
+            if policy != "muzero":
+                raise NotImplementedError(f"policy={policy!r}: only 'muzero' is built (SURVEY.md 8(f))")
+            policy_class = MuZeroPolicy
+        if not (isinstance(policy_class, type) and issubclass(policy_class, Policy)):
+            raise TypeError("policy_class must be a subclass of muax_amd.policy.Policy")
+        self.repr_func, self.pred_func, self.dy_func = self.network
+        self._policy = policy_class()
+        self._optimizer = optimizer
+        self.loss_fn = loss_fn
+        self._discount = float(discount)
+        self._support_size = int(support_size)
+        if recurrent_pred_on not in ("child", "parent"):
+            raise ValueError("recurrent_pred_on must be 'child' or 'parent'")
+        self._recurrent_pred_on = recurrent_pred_on
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        self._params = None
+        self._opt_state = None
+        self._fused = {}
+        self._weights_version = 0
+
+    # ------------------------------------------------------------------ init / params
+    def init(self, rng_key, sample_input):
+        """muax/model.py:62-80: materialise the three nets for `sample_input` ([B, ...])."""
+        seed = int(prng.as_key(rng_key)[0]) << 32 | int(prng.as_key(rng_key)[1])
+        torch.manual_seed(seed & 0x7FFFFFFFFFFFFFFF)
+        x = torch.as_tensor(np.asarray(sample_input), dtype=torch.float32)
+        for m in self.network:  # lazily built layers are created on the host, then everything moves
+            if isinstance(m, torch.nn.Module):
+                m.to("cpu")
+        with torch.no_grad():
+            s = self.repr_func(x)
+            self.pred_func(s)
+            self.dy_func(s, torch.zeros(s.shape[0], dtype=torch.long))
+        for m in self.network:
+            if isinstance(m, torch.nn.Module):
+                m.to(self.device)
+        self._params = MZNetworkParams(*[dict(m.named_parameters()) if isinstance(m, torch.nn.Module) else None
+                                         for m in self.network])
+        self._weights_version += 1
+        return self._params
+
+    @property
+    def params(self):
+        return self._params
+
+    @property
+    def optimizer_state(self):
+        return self._opt_state
+
+    def weights_changed(self):
+        """Call after modifying parameters in place (the fused kernel reads the live tensors, but
+        shape/dtype checks are cached per version)."""
+        self._weights_version += 1
+
+    # ------------------------------------------------------------------ sub-networks (coax API)
+    def representation(self, obs):
+        """muax/frameworks/coax/model.py:144-157."""
+        with torch.no_grad():
+            return self.repr_func(torch.as_tensor(obs, dtype=torch.float32, device=self.device))
+
+    def prediction(self, s):
+        """muax/frameworks/coax/model.py:159-173."""
+        with torch.no_grad():
+            return self.pred_func(torch.as_tensor(s, dtype=torch.float32, device=self.device))
+
+    def dynamic(self, s, a):
+        """muax/frameworks/coax/model.py:175-191."""
+        with torch.no_grad():
+            return self.dy_func(torch.as_tensor(s, dtype=torch.float32, device=self.device),
+                                torch.as_tensor(a, device=self.device))
+
+    # ------------------------------------------------------------------ inference glue
+    def _root_inference(self, params, rng_key, obs):
+        """muax/model.py:251-263 -> (prior_logits [B,A], value [B], embedding [B,...])."""
+        with torch.no_grad():
+            s = self.repr_func(obs)
+            v, logits = self.pred_func(s)
+            v = mx_utils.support_to_scalar(torch.softmax(v, dim=-1), self._support_size).flatten()
+        return logits, v, s
+
+    def _recurrent_inference(self, params, rng_key, action, embedding):
+        """muax/model.py:265-282 -> ((reward, discount, prior_logits, value), next_embedding)."""
+        with torch.no_grad():
+            r, next_embedding = self.dy_func(embedding, action)
+            v, logits = self.pred_func(embedding if self._recurrent_pred_on == "parent" else next_embedding)
+            r = mx_utils.support_to_scalar(torch.softmax(r, dim=-1), self._support_size).flatten()
+            v = mx_utils.support_to_scalar(torch.softmax(v, dim=-1), self._support_size).flatten()
+            discount = torch.ones_like(r) * self._discount
+        return (r, discount, logits, v), next_embedding
+
+    # ------------------------------------------------------------------ act
+    def _fused_handle(self, B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak):
+        key = (B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak)
+        h = self._fused.get(key)
+        if h is None or h[1] != self._weights_version:
+            s = MuZeroSearch(B, SearchConfig(A, S, E, max_depth=max_depth, tiebreak=tiebreak,
+                                             pb_c_init=pb_c_init, pb_c_base=float(pb_c_base)), self.device)
+            w = {k: v.detach() for k, v in mz_nn.mlp_trio_weights(self.network).items()}
+            s.set_mlp_weights(w, obs_dim, self._support_size, self._discount, self._recurrent_pred_on)
+            h = (s, self._weights_version)
+            self._fused[key] = h
+        return h[0]
+
+    def _plan(self, params, rng_key, obs, num_simulations=5, temperature=1., invalid_actions=None,
+              max_depth=None, loop_fn=None, qtransform=None, dirichlet_fraction=0.25, dirichlet_alpha=0.3,
+              pb_c_init=1.25, pb_c_base=19652, dirichlet_noise=None, gumbel=None, tiebreak=True,
+              with_tree=False):
+        """muax/model.py:222-243 -> (PolicyOutput, root value)."""
+        if self._params is None:
+            raise ValueError("call init() first")
+        if qtransform is not None and getattr(qtransform, "__name__", qtransform) != "qtransform_by_parent_and_siblings":
+            raise ValueError("only qtransform_by_parent_and_siblings is implemented")
+        key = prng.as_key(rng_key)
+        B = obs.shape[0]
+        A = self.pred_func.num_actions if hasattr(self.pred_func, "num_actions") else None
+        if dirichlet_noise is None and dirichlet_fraction:
+            k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
+            if A is None:
+                with torch.no_grad():
+                    A = self.pred_func(self.repr_func(obs[:1]))[1].shape[-1]
+            dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (B, A), self.device)
+        fused = mz_nn.is_default_mlp_trio(self.network) and obs.dim() == 2 and isinstance(self._policy, MuZeroPolicy)
+        if fused:
+            E = self.repr_func.embedding_dim
+            try:
+                h = self._fused_handle(B, A, E, obs.shape[1], num_simulations, max_depth, pb_c_init, pb_c_base,
+                                       tiebreak)
+                out = h.act_mlp(obs, key, dirichlet_noise=dirichlet_noise, dirichlet_fraction=dirichlet_fraction,
+                                invalid_actions=invalid_actions, temperature=temperature, gumbel=gumbel,
+                                with_tree=with_tree)
+                return out, h.root_value
+            except ValueError as e:
+                if "no fused kernel instance" not in str(e):
+                    raise
+        root = self._root_inference(params, key, obs)
+        out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
+                           temperature=temperature, invalid_actions=invalid_actions, max_depth=max_depth,
+                           dirichlet_fraction=dirichlet_fraction, dirichlet_noise=dirichlet_noise,
+                           pb_c_init=pb_c_init, pb_c_base=pb_c_base, gumbel=gumbel, tiebreak=tiebreak,
+                           with_tree=with_tree)
+        return out, root[1]
+
+    def act(self, rng_key, obs, with_pi: bool = False, with_value: bool = False, obs_from_batch: bool = False,
+            num_simulations: int = 5, temperature: float = 1., invalid_actions=None, max_depth: int = None,
+            loop_fn=None, qtransform=None, dirichlet_fraction: float = 0.25, dirichlet_alpha: float = 0.3,
+            pb_c_init: float = 1.25, pb_c_base: float = 19652, *, dirichlet_noise=None, gumbel=None,
+            tiebreak: bool = True, device_outputs: bool = False):
+        r"""Acts given environment observations (muax/model.py:82-179, same arguments and defaults).
+
+        Returns `action[, action_weights][, root_value]` in the reference's order.  Unbatched: action is a
+        python int, action_weights keeps its leading 1 ([1, A], as muax/model.py:176 leaves it), root_value
+        a python float.  Batched (`obs_from_batch=True`): arrays of shape [B], [B, A], [B] -- NumPy by
+        default (one host sync, like the reference's np.asarray), or device tensors with
+        `device_outputs=True` (no sync).  `root_value` is the NETWORK value of the root, as the reference.
+        Keyword-only extras: exact `dirichlet_noise` / `gumbel` arrays, `tiebreak=False` to drop mctx's
+        1e-7 tie-break noise.
+        """
+        obs = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs, dtype=torch.float32)
+        if not obs_from_batch:
+            obs = obs.unsqueeze(0)
+        obs = obs.to(self.device)
+        plan_output, root_value = self._plan(
+            self.params, rng_key, obs, num_simulations=num_simulations, temperature=temperature,
+            invalid_actions=invalid_actions, max_depth=max_depth, loop_fn=loop_fn, qtransform=qtransform,
+            dirichlet_fraction=dirichlet_fraction, dirichlet_alpha=dirichlet_alpha, pb_c_init=pb_c_init,
+            pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak)
+        if not obs_from_batch:
+            action = int(plan_output.action.item())
+            weights = plan_output.action_weights.cpu().numpy()
+            root_value = float(root_value.item())
+        elif device_outputs:
+            action, weights = plan_output.action, plan_output.action_weights
+        else:
+            action = plan_output.action.cpu().numpy()
+            weights = plan_output.action_weights.cpu().numpy()
+            root_value = root_value.cpu().numpy()
+        if with_pi and with_value:
+            return action, weights, root_value
+        elif not with_pi and with_value:
+            return action, root_value
+        elif with_pi and not with_value:
+            return action, weights
+        return action
+
+    # ------------------------------------------------------------------ next tier
+    def update(self, batch, *args, **kwargs):
+        """muax/model.py:181-201 (k-step unroll training step): next tier, SURVEY.md 8(f) n1."""
+        raise NotImplementedError("the training step is not built yet (SURVEY.md section 8(f), n1)")
+
+    def save_load(self, file, save=True):
+        """muax/model.py:203-212, on torch state dicts (the reference pickles haiku params)."""
+        mods = {n: m for n, m in zip(("representation", "prediction", "dynamic"), self.network)
+                if isinstance(m, torch.nn.Module)}
+        if save:
+            torch.save({"params": {n: m.state_dict() for n, m in mods.items()}, "optimizer_state": self._opt_state},
+                       file)
+        else:
+            saved = torch.load(file, map_location=self.device)
+            for n, m in mods.items():
+                m.load_state_dict(saved["params"][n])
+            self._opt_state = saved.get("optimizer_state")
+            self._weights_version += 1

@@ -1,0 +1,76 @@
+"""Policy adapters of the reference (muax/policy.py): a uniform __call__(params, rng_key, root,
+recurrent_fn, **kwargs) over the search implementations -- here the HIP search instead of mctx."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+from .search import MuZeroSearch, PolicyOutput, SearchConfig
+
+
+class Policy(ABC):
+    """muax/policy.py:7-10."""
+
+    @abstractmethod
+    def __call__(self, params, rng_key, root, recurrent_fn=None, decision_recurrent_fn=None,
+                 chance_recurrent_fn=None, **kwargs):
+        pass
+
+
+class MuZeroPolicy(Policy):
+    """muax/policy.py:13-30: mctx.muzero_policy with the same keyword defaults.
+
+    `root` is (prior_logits [B,A], value [B], embedding [B,...]) as in mctx.RootFnOutput;
+    `recurrent_fn(params, rng_key, action, embedding)` returns ((reward, discount, prior_logits, value),
+    next_embedding) as in muax/model.py:265-282.  Runs the step-wise HIP search (any plugin nets)."""
+
+    def __init__(self):
+        self._handles = {}
+
+    def _handle(self, batch, cfg_key, cfg, device):
+        key = (batch, cfg_key, str(device))
+        if key not in self._handles:
+            self._handles[key] = MuZeroSearch(batch, cfg, device)
+        return self._handles[key]
+
+    def __call__(self, params, rng_key, root, recurrent_fn, **kwargs) -> PolicyOutput:
+        prior_logits, value, embedding = root
+        if kwargs.get("qtransform") not in (None, "qtransform_by_parent_and_siblings"):
+            raise ValueError("only qtransform_by_parent_and_siblings is implemented")
+        B, A = prior_logits.shape
+        emb = embedding.reshape(B, -1)
+        S = kwargs.get("num_simulations", 5)
+        cfg_key = (A, S, emb.shape[1], kwargs.get("max_depth"), kwargs.get("tiebreak", True),
+                   kwargs.get("pb_c_init", 1.25), kwargs.get("pb_c_base", 19652))
+        cfg = SearchConfig(A, S, emb.shape[1], max_depth=kwargs.get("max_depth"),
+                           tiebreak=kwargs.get("tiebreak", True), pb_c_init=kwargs.get("pb_c_init", 1.25),
+                           pb_c_base=float(kwargs.get("pb_c_base", 19652)))
+        h = self._handle(B, cfg_key, cfg, prior_logits.device)
+        shape = tuple(embedding.shape[1:])
+
+        def rec(action, flat_emb):
+            (reward, discount, logits, v), nxt = recurrent_fn(params, None, action, flat_emb.reshape((B,) + shape))
+            return reward, discount, logits, v, nxt.reshape(B, -1)
+
+        return h.search((prior_logits, value, emb), rec, key=rng_key,
+                        invalid_actions=kwargs.get("invalid_actions"),
+                        dirichlet_noise=kwargs.get("dirichlet_noise"),
+                        dirichlet_fraction=kwargs.get("dirichlet_fraction", 0.25),
+                        temperature=kwargs.get("temperature", 1.0), gumbel=kwargs.get("gumbel"),
+                        with_tree=kwargs.get("with_tree", False))
+
+
+class GumbelMuZeroPolicy(Policy):
+    """muax/policy.py:33-47 (mctx.gumbel_muzero_policy): next on the list."""
+
+    def __call__(self, params, rng_key, root, recurrent_fn=None, decision_recurrent_fn=None,
+                 chance_recurrent_fn=None, **kwargs):
+        raise NotImplementedError("Gumbel MuZero search is not built yet (SURVEY.md section 8(f), n2)")
+
+
+class StochasticMuZeroPolicy(Policy):
+    """muax/policy.py:50-67: out of scope (chance nodes; nothing in the core reference supplies the
+    decision/chance recurrent functions)."""
+
+    def __call__(self, params, rng_key, root, recurrent_fn=None, decision_recurrent_fn=None,
+                 chance_recurrent_fn=None, **kwargs):
+        raise NotImplementedError("stochastic MuZero is out of scope (SURVEY.md section 2, row 2)")

@@ -1,0 +1,197 @@
+"""GPU tests of the host mirror: MuZero.act()'s contract (muax/model.py:82-179), the plugin-net path,
+the fit/test inner loops, and the golden fixtures through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import muax_amd as mx
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32 = np.float32
+
+
+def _model(E=8, A=2, obs_dim=4, seed=0, **kw):
+    g = torch.Generator().manual_seed(seed)
+    net = mx.nn.MZNetwork(mx.nn.Representation(E, generator=g), mx.nn.Prediction(A, 21, generator=g),
+                          mx.nn.Dynamic(E, A, 21, generator=g))
+    m = mx.MuZero(net, **kw)
+    m.init(mx.prng.PRNGKey(seed), np.zeros((1, obs_dim)))
+    return m
+
+
+@pytest.mark.parametrize("name", ["cartpole_s10", "cartpole_s50", "lunarlander_s50"])
+def test_fused_path_reproduces_golden_fixtures(name):
+    """Frozen oracle vectors (tests/golden/make_golden.py) through the C-ABI: bit-exact."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"act_mlp_{name}.npz"))
+    B, obs_dim, E, A, S, tb = (int(x) for x in g["meta"])
+    s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, E, tiebreak=bool(tb)))
+    s.set_mlp_weights({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")}, obs_dim)
+    out = s.act_mlp(torch.from_numpy(g["obs"]), g["key"], dirichlet_noise=torch.from_numpy(g["dirichlet_noise"]),
+                    with_tree=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.action.cpu().numpy(), g["action"])
+    assert np.array_equal(out.action_weights.cpu().numpy(), g["action_weights"])
+    assert np.array_equal(s.root_value.cpu().numpy(), g["root_value"])
+    assert np.array_equal(s.depth_sum.cpu().numpy(), g["depth_sum"])
+    for f in out.search_tree._fields:
+        assert np.array_equal(getattr(out.search_tree, f).cpu().numpy(), g["tree_" + f]), f
+
+
+def test_act_return_conventions():
+    """muax/model.py:173-179: unbatched -> (int, [1,A] weights, float); batched -> arrays; flag order."""
+    m = _model()
+    obs = np.random.default_rng(0).uniform(-1, 1, 4).astype(F32)
+    a = m.act(0, obs, num_simulations=10)
+    assert isinstance(a, int) and a in (0, 1)
+    a, pi, v = m.act(0, obs, with_pi=True, with_value=True, num_simulations=10)
+    assert isinstance(a, int) and isinstance(v, float) and pi.shape == (1, 2) and abs(pi.sum() - 1) < 1e-6
+    a2, v2 = m.act(0, obs, with_value=True, num_simulations=10)
+    a3, pi3 = m.act(0, obs, with_pi=True, num_simulations=10)
+    assert (a2, v2) == (a, v) and a3 == a and np.array_equal(pi3, pi)  # same key -> same result
+    batch = np.random.default_rng(1).uniform(-1, 1, (33, 4)).astype(F32)
+    ab, pib, vb = m.act(1, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=10)
+    assert isinstance(ab, np.ndarray) and ab.shape == (33,) and pib.shape == (33, 2) and vb.shape == (33,)
+    ad, pid, vd = m.act(1, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=10,
+                        device_outputs=True)
+    assert ad.is_cuda and np.array_equal(ad.cpu().numpy(), ab) and np.array_equal(vd.cpu().numpy(), vb)
+    # root_value is the network's value of the root, not the search value (muax/model.py:243)
+    with torch.no_grad():
+        s = m.repr_func(torch.from_numpy(batch).cuda())
+        vl, _ = m.pred_func(s)
+        v_net = mx.utils.support_to_scalar(torch.softmax(vl, -1), 10).cpu().numpy()
+    assert np.allclose(vb, v_net, rtol=2e-3, atol=2e-3)
+    # the default of act() is num_simulations=5 (muax/model.py:86)
+    _, pi5 = m.act(0, obs, with_pi=True)
+    assert abs(pi5[0, 0] * 5 - round(pi5[0, 0] * 5)) < 1e-5
+
+
+def test_act_greedy_and_invalid_actions():
+    m = _model(A=4, obs_dim=6)
+    batch = np.random.default_rng(2).uniform(-1, 1, (64, 6)).astype(F32)
+    a, pi = m.act(5, batch, with_pi=True, obs_from_batch=True, num_simulations=20, temperature=0.)
+    assert (pi[np.arange(64), a] == pi.max(1)).all()
+    inv = np.zeros((64, 4), np.uint8)
+    inv[:, 2] = 1
+    a, pi = m.act(5, batch, with_pi=True, obs_from_batch=True, num_simulations=20, invalid_actions=inv)
+    assert (a != 2).all() and (pi[:, 2] == 0).all()
+
+
+def test_plugin_nets_go_through_stepwise_path_and_agree_with_fused():
+    """Any torch module is a plugin net.  Wrapping the default trio hides it from the fused kernel; the
+    step-wise path (torch nets between the HIP kernels) must then produce the same search up to the
+    float rounding of torch's own matmul/exp (visit counts may differ only where scores nearly tie)."""
+    m = _model(seed=3)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+            for k in ("num_actions", "embedding_dim"):
+                if hasattr(inner, k):
+                    setattr(self, k, getattr(inner, k))
+
+        def forward(self, *a):
+            return self.inner(*a)
+
+    net = m.network
+    m2 = mx.MuZero(Wrap(net.representation_fn), Wrap(net.prediction_fn), Wrap(net.dynamic_fn), policy="muzero")
+    m2.init(0, np.zeros((1, 4)))
+    assert not mx.nn.is_default_mlp_trio(m2.network)
+    batch = np.random.default_rng(4).uniform(-1, 1, (128, 4)).astype(F32)
+    noise = np.random.default_rng(5).dirichlet([0.3, 0.3], 128).astype(F32)
+    kw = dict(with_pi=True, with_value=True, obs_from_batch=True, num_simulations=25, dirichlet_noise=noise,
+              tiebreak=False, temperature=0.)
+    a1, pi1, v1 = m.act(7, batch, **kw)
+    a2, pi2, v2 = m2.act(7, batch, **kw)
+    assert np.allclose(v1, v2, rtol=2e-3, atol=2e-3)
+    same = (pi1 == pi2).all(1)
+    assert same.mean() > 0.9 and (a1[same] == a2[same]).all()
+
+
+def test_custom_plugin_network_with_2d_embedding():
+    """A non-MLP plugin (conv-shaped embedding [B, 2, 3, 4], A=5): the embedding is opaque to the search."""
+    torch.manual_seed(0)
+
+    class Rep(torch.nn.Module):
+        def forward(self, obs):
+            return torch.tanh(obs[:, :24]).reshape(-1, 2, 3, 4)
+
+    class Pred(torch.nn.Module):
+        num_actions = 5
+
+        def __init__(self):
+            super().__init__()
+            self.v, self.p = torch.nn.Linear(24, 21), torch.nn.Linear(24, 5)
+
+        def forward(self, s):
+            f = s.reshape(s.shape[0], -1)
+            return self.v(f), self.p(f)
+
+    class Dyn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.r, self.n = torch.nn.Linear(29, 21), torch.nn.Linear(29, 24)
+
+        def forward(self, s, a):
+            x = torch.cat([s.reshape(s.shape[0], -1), torch.nn.functional.one_hot(a.long(), 5).float()], 1)
+            return self.r(x), torch.sigmoid(self.n(x)).reshape(-1, 2, 3, 4)
+
+    m = mx.MuZero(Rep(), Pred(), Dyn())
+    m.init(0, np.zeros((1, 30)))
+    obs = np.random.default_rng(6).normal(size=(40, 30)).astype(F32)
+    a, pi, v = m.act(3, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=16)
+    assert a.shape == (40,) and pi.shape == (40, 5) and np.allclose(pi.sum(1), 1, atol=1e-6)
+    assert (pi * 16 == np.round(pi * 16)).all()
+    a1 = m.act(3, obs[0], num_simulations=16)
+    assert isinstance(a1, int)
+
+
+class _ToyEnv:
+    """CartPole-shaped toy (4 floats, 2 actions): enough to drive the reference's loops."""
+
+    class spec:
+        max_episode_steps = 12
+
+    def __init__(self):
+        self.rng = np.random.default_rng(0)
+
+    def reset(self):
+        self.t, self.x = 0, self.rng.uniform(-0.05, 0.05, 4).astype(F32)
+        return self.x, {}
+
+    def step(self, a):
+        self.t += 1
+        self.x = (self.x + (0.1 if a else -0.1) * np.array([1, 0.5, -0.5, 1], F32)).astype(F32)
+        return self.x, 1.0, abs(self.x[0]) > 0.5, False, {}
+
+
+def test_fit_and_test_inner_loops():
+    """muax/train.py:153-170 and muax/test.py:25-41: one key split per step, act contract, greedy eval."""
+    m = _model(seed=9)
+    traj, key = mx.rollout(m, _ToyEnv(), mx.prng.PRNGKey(1), num_simulations=8,
+                           temperature=mx._temperature_fn(100, 0))
+    assert 1 <= len(traj) <= 12
+    obs, a, r, done, v, pi = traj[0]
+    assert isinstance(a, int) and isinstance(v, float) and pi.shape == (1, 2)
+    k = mx.prng.PRNGKey(1)
+    for _ in range(len(traj)):
+        k = mx.prng.split(k)[0]
+    assert np.array_equal(k, key)
+    g = mx.test(m, _ToyEnv(), mx.prng.PRNGKey(2), num_simulations=8, num_test_episodes=2)
+    assert 1.0 <= g <= 12.0
+
+
+def test_stepwise_search_reuses_handle_and_errors():
+    s = mx.MuZeroSearch(8, mx.SearchConfig(3, 6, 5))
+    with pytest.raises(ValueError):
+        s.root(torch.zeros(8, 2), torch.zeros(8), torch.zeros(8, 5))  # wrong A
+    with pytest.raises(ValueError):
+        s.expand_backup(0, torch.zeros(8), torch.zeros(8), torch.zeros(8, 3), torch.zeros(8), torch.zeros(8, 5))
+    for rep in range(2):  # the handle's tree storage is reused across searches
+        out = s.search((torch.zeros(8, 3), torch.zeros(8), torch.zeros(8, 5)),
+                       lambda a, e: (torch.zeros(8), torch.ones(8), torch.zeros(8, 3), torch.zeros(8), e),
+                       key=rep, with_tree=True)
+        assert int(out.search_tree.node_visits[:, 0].min()) == 7

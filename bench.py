@@ -59,6 +59,22 @@ def algorithmic_bytes(depth_sum_total, roots, S, A, E, obs_dim):
                                                                + (4 * obs_dim + 4 * E + 8 * A + 20))
 
 
+def usable_cores():
+    """Host threads this process may really use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} hw threads visible"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                note += f", cgroup cpu.max quota {q}"
+                n = q
+    except Exception:
+        pass
+    return n, note
+
+
 def cpu_baseline(weights, obs, noise, A, E, F, S, support, budget_s=12.0):
     """The CPU oracle (a port: our restatement of the mctx semantics, NOT the reference itself --
     jax/mctx are not installable here) timed on this box's host cores on the same workload."""
@@ -66,7 +82,7 @@ def cpu_baseline(weights, obs, noise, A, E, F, S, support, budget_s=12.0):
     po.build()
     w = {k: v.numpy() for k, v in weights.items()}
     mlp = po.Mlp(w, obs.shape[1], E, A, F, support_size=support)
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cores()
     B = obs.shape[0]
     out = {}
     for label, nthreads in (("1", 1), ("all", cores)):
@@ -85,7 +101,7 @@ def cpu_baseline(weights, obs, noise, A, E, F, S, support, budget_s=12.0):
             "single_thread_value": round(out["1"][0], 1),
             "sample": f"{B} roots x S={S}, {out['all'][1]} acts on {cores} threads ({out['all'][2]:.1f}s) "
                       f"and {out['1'][1]} acts on 1 thread ({out['1'][2]:.1f}s); gcc -O2 C oracle, "
-                      f"root-major OpenMP"}
+                      f"root-major OpenMP; {cores_note}"}
 
 
 def pmc_traffic(workload):

@@ -657,17 +657,13 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         // wave's deepest entry are identities for every row and are jumped over
         float Gown = G;
         const int kstart = min(15, wmax - 16 * c);
-#define MZ_GSTEP(k)                              \
-  case k:                                        \
-    G = bcast<k>(re) + bcast<k>(ge) * G;         \
-    Gown = (j == k) ? G : Gown;                  \
-    [[fallthrough]];
-        switch (kstart) {
-          MZ_GSTEP(15) MZ_GSTEP(14) MZ_GSTEP(13) MZ_GSTEP(12) MZ_GSTEP(11) MZ_GSTEP(10) MZ_GSTEP(9)
-          MZ_GSTEP(8) MZ_GSTEP(7) MZ_GSTEP(6) MZ_GSTEP(5) MZ_GSTEP(4) MZ_GSTEP(3) MZ_GSTEP(2) MZ_GSTEP(1)
-          MZ_GSTEP(0)
-          default: break;
-        }
+#define MZ_GSTEP(k)                          \
+  G = bcast<k>(re) + bcast<k>(ge) * G;       \
+  Gown = (j == k) ? G : Gown;
+        if (kstart >= 12) { MZ_GSTEP(15) MZ_GSTEP(14) MZ_GSTEP(13) MZ_GSTEP(12) }
+        if (kstart >= 8) { MZ_GSTEP(11) MZ_GSTEP(10) MZ_GSTEP(9) MZ_GSTEP(8) }
+        if (kstart >= 4) { MZ_GSTEP(7) MZ_GSTEP(6) MZ_GSTEP(5) MZ_GSTEP(4) }
+        MZ_GSTEP(3) MZ_GSTEP(2) MZ_GSTEP(1) MZ_GSTEP(0)
 #undef MZ_GSTEP
         const float newv = (pv * (float)cnt + Gown) / ((float)cnt + 1.0f);
         // children_values[parent, action] = node_values[child]: the child is the next entry
@@ -695,9 +691,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         // JUMP word: own end point, the off-path best child's cached word, or (when the best child
         // is the next entry of this very path) whatever that entry resolves to
         const bool inherit0 = valid && safe && child >= 0 && !isleaf && child == next_pn;
-        int jwd = jump_word(pn, best, e, !safe);
-        if (valid && safe && child >= 0 && !inherit0)
-          jwd = itree[__umul24((unsigned)child, (unsigned)NS) + C::JUMP];
+        // (unconditional read of a clamped address instead of a masked one: no exec juggling)
+        const int jchild = itree[__umul24((unsigned)(child < 0 ? 0 : child), (unsigned)NS) + C::JUMP];
+        const int jwd0 = jump_word(pn, best, e, !safe);
+        int jwd = (safe && child >= 0 && !inherit0) ? jchild : jwd0;
         int inh = inherit0 ? 1 : 0;
 #define MZ_JSCAN(d)                                                                              \
   {                                                                                              \
@@ -711,13 +708,12 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         jwd = inh ? carry_j : jwd;  // 15 hops covered; a lane still inheriting reaches past the row end
         carry_j = bcast_i<0>(jwd);
         if (valid) {
+          // one masked region; for the leaf entry the header / edge stores rewrite what was loaded
 #pragma unroll
           for (int a = 0; a < A; ++a) nd[C::SEL0 + 2 * a + 1] = sc[a];
           ndi[C::JUMP] = jwd;
-        }
-        if (edge) {
           ndi[C::HDR0] = nvis;
-          nd[C::HDR0 + 1] = newv;
+          nd[C::HDR0 + 1] = nval;
           float cvn = val[0];
           int cin = vis[0];
 #pragma unroll

@@ -274,6 +274,90 @@ struct Nets {
     pi_logit = pl[0];
     value = row_decode<C::F>(v_logits, j, support);
   }
+  // ---- the per-simulation pass: Dynamic (muax/nn.py:93-115) on (s, action), Prediction
+  // (muax/nn.py:73-90) on the child (or parent) embedding, both support decodes.  Same arithmetic
+  // as predict()/dynamics() below, organised for the machine: the two hidden layers that share an
+  // input run as ONE packed chain ((reward-net, state-net), (value-net, policy-net)), 2-slot logits
+  // are packed, and the reward and value decodes advance together as (reward, value) pairs. ----
+  MZ_DEV void forward(const float (&s)[C::ES], int action, int j, int support, bool pred_on_parent,
+                      float& reward, float& value, float& pi_logit, float& pi_prob,
+                      float (&ns)[C::ES]) const {
+    static_assert(C::FS == 2, "support logits are handled as two lane slots");
+    constexpr int E = C::E, A = C::A;
+    // Dynamic, first layer: [s, onehot(a)] -> 16 hidden units of the reward net and of the state net
+    f32x2 h = splat2(0.0f);
+    StaticFor<0, E>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      h = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), (f32x2){dr1.w[i], dn1.w[i]}, h);
+    });
+    {
+      f32x2 wsel = (f32x2){dr1.wa[0], dn1.wa[0]};
+#pragma unroll
+      for (int a = 1; a < A; ++a) wsel = (action == a) ? (f32x2){dr1.wa[a], dn1.wa[a]} : wsel;
+      h = (h + wsel) + (f32x2){dr1.b, dn1.b};
+    }
+    h = elu2(h);
+    // second layer: reward logits (two slots, packed) and next state
+    f32x2 rl = splat2(0.0f);
+#pragma unroll
+    for (int t = 0; t < C::ES; ++t) ns[t] = 0.0f;
+    StaticFor<0, kHidden>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      rl = fma2(splat2(bcast<i>(h.x)), (f32x2){dr2.w[i][0], dr2.w[i][1]}, rl);
+      const float hb = bcast<i>(h.y);
+#pragma unroll
+      for (int t = 0; t < C::ES; ++t) ns[t] = __builtin_fmaf(hb, dn2.w[i][t], ns[t]);
+    });
+    rl = rl + (f32x2){dr2.b[0], dr2.b[1]};
+#pragma unroll
+    for (int t = 0; t < C::ES; ++t) ns[t] = ns[t] + dn2.b[t];
+    row_min_max_normalize<E>(ns, j);
+    // Prediction, first layer, on the child embedding (muax/model.py:272) or the parent (coax quirk)
+    float x[C::ES];
+#pragma unroll
+    for (int t = 0; t < C::ES; ++t) x[t] = pred_on_parent ? s[t] : ns[t];
+    f32x2 g = splat2(0.0f);
+    StaticFor<0, E>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      g = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), (f32x2){pv1.w[i][0], pp1.w[i][0]}, g);
+    });
+    g = elu2(g + (f32x2){pv1.b[0], pp1.b[0]});
+    f32x2 vl = splat2(0.0f);
+    float pl = 0.0f;
+    StaticFor<0, kHidden>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      vl = fma2(splat2(bcast<i>(g.x)), (f32x2){pv2.w[i][0], pv2.w[i][1]}, vl);
+      pl = __builtin_fmaf(bcast<i>(g.y), pp2.w[i][0], pl);
+    });
+    vl = vl + (f32x2){pv2.b[0], pv2.b[1]};
+    pi_logit = pl + pp2.b[0];
+    {
+      // children_prior of the new node: softmax over the A policy logits (an independent chain the
+      // scheduler interleaves with the decodes below)
+      float px[1] = {pi_logit}, pp[1];
+      row_softmax<A>(px, j, pp);
+      pi_prob = pp[0];
+    }
+    // support_to_scalar(softmax(.)) of the reward logits and the value logits, as (reward, value) pairs
+    const bool ok1 = j + 16 < C::F;  // slot 0 is always inside the support (F > 16)
+    f32x2 m = (f32x2){ok1 ? fmaxf(rl.x, rl.y) : rl.x, ok1 ? fmaxf(vl.x, vl.y) : vl.x};
+    m = (f32x2){row_max<4>(m.x), row_max<4>(m.y)};
+    f32x2 e0 = exp_neg2((f32x2){rl.x, vl.x} - m);
+    f32x2 e1 = exp_neg2((f32x2){rl.y, vl.y} - m);
+    e1 = ok1 ? e1 : splat2(0.0f);
+    f32x2 part = ok1 ? e0 + e1 : e0;
+    f32x2 sum = (f32x2){row_sum(part.x), row_sum(part.y)};
+    f32x2 p0 = (f32x2){e0.x / sum.x, e0.y / sum.y};
+    f32x2 p1 = (f32x2){e1.x / sum.x, e1.y / sum.y};
+    f32x2 t0 = splat2((float)(j - support)) * p0;
+    f32x2 t1 = splat2((float)(j + 16 - support)) * p1;
+    f32x2 tp = ok1 ? t0 + t1 : t0;
+    f32x2 xs = (f32x2){row_sum(tp.x), row_sum(tp.y)};
+    f32x2 dec = inv_scaling2(xs);
+    reward = dec.x;
+    value = dec.y;
+  }
+
   // Dynamic (muax/nn.py:93-115) + reward decode
   MZ_DEV void dynamics(const float (&s)[C::ES], int action, int j, int support, float& reward,
                        float (&ns)[C::ES]) const {
@@ -552,24 +636,23 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
       sp[t] = (j + 16 * t < E) ? tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + j + 16 * t] : 0.0f;
-    float reward, value, pil;
+    // LDS reads the expansion needs are issued before the network pass so their latency hides behind it
+    float* nn = tree + __umul24((unsigned)newn, (unsigned)NS);
+    int* nni = reinterpret_cast<int*>(nn);
+    const unsigned po = __umul24((unsigned)parent, (unsigned)NS);
+    const int vis_old = nni[C::HDR0];
+    const int ppw = itree[po + C::PATH0 + (j < C::PATHW ? j : 0)];
+    float reward, value, pil, pprob;
     float ns[C::ES];
-    nets.dynamics(sp, action, j, support, reward, ns);
-    MZ_TICK(2);  // dynamics (+ parent embedding gather)
-    if (p.pred_on_parent) nets.predict(sp, j, support, value, pil);
-    else nets.predict(ns, j, support, value, pil);
-    MZ_TICK(3);  // prediction
-    float px[1] = {pil}, pp[1];
-    row_softmax<A>(px, j, pp);
+    nets.forward(sp, action, j, support, p.pred_on_parent != 0, reward, value, pil, pprob, ns);
+    MZ_TICK(2);  // dynamics + prediction (+ parent embedding gather)
+    MZ_TICK(3);
     {
-      float* nn = tree + __umul24((unsigned)newn, (unsigned)NS);
-      int* nni = reinterpret_cast<int*>(nn);
-      int vis = nni[C::HDR0] + 1;
-      if (j < A) nn[C::ST0 + C::STW * j + 0] = pp[0];
+      const int vis = vis_old + 1;
+      if (j < A) nn[C::ST0 + C::STW * j + 0] = pprob;
 #pragma unroll
       for (int t = 0; t < C::ES; ++t)
         if (j + 16 * t < E) nn[C::EMB0 + j + 16 * t] = ns[t];
-      const unsigned po = __umul24((unsigned)parent, (unsigned)NS);
       if (j == 0) {
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
@@ -580,7 +663,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       if (fresh && j < C::PATHW) {
         // the new node's root path = its parent's path + (parent, action); written once
         const int e = depth - 1;
-        int w = itree[po + C::PATH0 + j];
+        int w = ppw;
         const int sh = (e * C::ENTRY_BITS) & 31;
         const int ent = parent | (action << C::ENTRY_ACT_SHIFT);
         w = (j == ((e * C::ENTRY_BITS) >> 5))
@@ -645,6 +728,12 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           rew[a] = nd[C::ST0 + C::STW * a + 3];
           dis[a] = nd[C::ST0 + C::STW * a + 4];
         }
+        // cached JUMP words of all children (clamped addresses), fetched now so that the one the
+        // refreshed decision picks is already here
+        int jch[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+          jch[a] = itree[__umul24((unsigned)(cidx[a] < 0 ? 0 : cidx[a]), (unsigned)NS) + C::JUMP];
         float re = rew[0], ge = dis[0];
 #pragma unroll
         for (int a = 1; a < A; ++a) {
@@ -691,8 +780,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         // JUMP word: own end point, the off-path best child's cached word, or (when the best child
         // is the next entry of this very path) whatever that entry resolves to
         const bool inherit0 = valid && safe && child >= 0 && !isleaf && child == next_pn;
-        // (unconditional read of a clamped address instead of a masked one: no exec juggling)
-        const int jchild = itree[__umul24((unsigned)(child < 0 ? 0 : child), (unsigned)NS) + C::JUMP];
+        int jchild = jch[0];
+#pragma unroll
+        for (int a = 1; a < A; ++a) jchild = (best == a) ? jch[a] : jchild;
         const int jwd0 = jump_word(pn, best, e, !safe);
         int jwd = (safe && child >= 0 && !inherit0) ? jchild : jwd0;
         int inh = inherit0 ? 1 : 0;

@@ -199,6 +199,62 @@ MZ_DEV float inv_scaling(float x) {  // muax/utils.py:70-76, eps = 1e-3
   float sgn = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
   return sgn * g;
 }
+// ---- packed pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): component-wise the very same
+// operation sequences as the scalar routines above, two independent values per instruction ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+MZ_DEV f32x2 splat2(float x) { return (f32x2){x, x}; }
+MZ_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+MZ_DEV f32x2 exp_core2(f32x2 x, int& k0, int& k1) {
+  const float LOG2E = 1.44269504088896341f;
+  const float LN2_HI = 6.93145752e-1f;
+  const float LN2_LO = 1.42860677e-6f;
+  f32x2 t = x * splat2(LOG2E);
+  f32x2 kf = (f32x2){__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  f32x2 r = fma2(kf, splat2(-LN2_HI), x);
+  r = fma2(kf, splat2(-LN2_LO), r);
+  f32x2 p = splat2(1.0f / 5040.0f);
+  p = fma2(p, r, splat2(1.0f / 720.0f));
+  p = fma2(p, r, splat2(1.0f / 120.0f));
+  p = fma2(p, r, splat2(1.0f / 24.0f));
+  p = fma2(p, r, splat2(1.0f / 6.0f));
+  p = fma2(p, r, splat2(0.5f));
+  f32x2 rr = r * r;
+  k0 = (int)kf.x;
+  k1 = (int)kf.y;
+  return fma2(p, rr, r);
+}
+MZ_DEV f32x2 exp_neg2(f32x2 x) {
+  int k0, k1;
+  f32x2 xc = (f32x2){fmaxf(x.x, -87.0f), fmaxf(x.y, -87.0f)};
+  f32x2 q = exp_core2(xc, k0, k1);
+  f32x2 e = (splat2(1.0f) + q) * (f32x2){pow2i(k0), pow2i(k1)};
+  return (f32x2){x.x < -87.0f ? 0.0f : e.x, x.y < -87.0f ? 0.0f : e.y};
+}
+MZ_DEV f32x2 elu2(f32x2 x) {
+  f32x2 xn = (f32x2){fminf(x.x, 0.0f), fminf(x.y, 0.0f)};
+  int k0, k1;
+  f32x2 xc = (f32x2){fmaxf(xn.x, -87.0f), fmaxf(xn.y, -87.0f)};
+  f32x2 q = exp_core2(xc, k0, k1);
+  f32x2 big = (splat2(1.0f) + q) * (f32x2){pow2i(k0), pow2i(k1)} - splat2(1.0f);
+  float e0 = (k0 == 0) ? q.x : big.x, e1 = (k1 == 0) ? q.y : big.y;
+  e0 = xn.x < -87.0f ? -1.0f : e0;
+  e1 = xn.y < -87.0f ? -1.0f : e1;
+  return (f32x2){x.x > 0.0f ? x.x : e0, x.y > 0.0f ? x.y : e1};
+}
+MZ_DEV f32x2 inv_scaling2(f32x2 x) {
+  f32x2 ax = (f32x2){fabsf(x.x), fabsf(x.y)};
+  f32x2 a = (ax + splat2(1.0f)) + splat2(0.001f);
+  f32x2 b = splat2(0.004f) * a;
+  f32x2 c = splat2(1.0f) + b;
+  f32x2 d = (f32x2){sqrtf(c.x), sqrtf(c.y)};
+  f32x2 dm = d - splat2(1.0f);
+  f32x2 e = (f32x2){dm.x / 0.002f, dm.y / 0.002f};
+  f32x2 g = e * e - splat2(1.0f);
+  float s0 = x.x > 0.0f ? 1.0f : (x.x < 0.0f ? -1.0f : 0.0f);
+  float s1 = x.y > 0.0f ? 1.0f : (x.y < 0.0f ? -1.0f : 0.0f);
+  return (f32x2){s0, s1} * g;
+}
+
 // sqrt(n) * (pb_c_init + log((n + base + 1) / base)), mctx muzero_action_selection
 MZ_DEV float puct_scale(int n, float pb_c_init, float pb_c_base) {
   float num = ((float)n + pb_c_base) + 1.0f;

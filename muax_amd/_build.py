@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",
            "-fPIC", "-shared", "-Wno-unused-value",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -49,13 +49,16 @@ constexpr int kDppHalfMirror = 0x141; // row_half_mirror (== xor 4 once quads ar
 constexpr int kDppMirror = 0x140;     // row_mirror      (== xor 8 once halves are uniform)
 constexpr int kDppBcast0 = 0x150;     // row_newbcast:0 (gfx90a+)
 
+// Every control used through these two reads a valid lane in every lane (quad_perm, row mirrors,
+// row_newbcast), so the "old" operand is dead: bound_ctrl:1 tells the compiler so and saves the
+// zero-initialising v_mov in front of each DPP move.
 template <int CTRL>
 MZ_DEV int dpp_i(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 MZ_DEV float dpp_f(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 // value of lane I of this row, in every lane of the row
 template <int I>

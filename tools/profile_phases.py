@@ -17,7 +17,7 @@ PHASES = ["loop top", "select", "dynamics", "prediction", "prior softmax + expan
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",
                            "-fPIC", "-shared", "-Wno-unused-value", "-DMZ_PROFILE", "-o", LIB,
                            os.path.join(ROOT, "muax_amd", "csrc", "mz_api.hip")])
     print(LIB)

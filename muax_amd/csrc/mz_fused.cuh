@@ -427,6 +427,10 @@ template <class C>
 __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const FusedParams p) {
   constexpr int A = C::A, E = C::E, NS = C::NS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // One wavefront per SIMD owns the whole 512-entry unified register file.  LLVM infers "no AGPRs"
+  // for a kernel without MFMA and would spill to scratch beyond 256 VGPRs; naming an AGPR keeps the
+  // accumulator half allocatable so that spills (the E=32 weight columns) stay in registers.
+  asm volatile("; keep AGPRs allocatable" ::: "a0");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int j = lane & 15;

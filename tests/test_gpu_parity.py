@@ -276,3 +276,104 @@ def test_error_behaviour():
     w = {k: torch.zeros(1) for k in ["repr_w"]}
     with pytest.raises((ValueError, KeyError)):
         s7.set_mlp_weights(w, 4)
+
+
+# ---------------------------------------------------------------- edge cases of the domain
+
+def _stepwise_vs_oracle(oracle, case, S, tiebreak, max_depth=None, key=(4, 5)):
+    """Drive the step-wise kernels and the oracle with the same (torch) net outputs; compare everything."""
+    from muax_amd import MuZeroSearch, SearchConfig
+    B, A, E = case["B"], case["A"], case["E"]
+    root, rec = _torch_recurrent(case)
+    obs = torch.from_numpy(case["obs"]).cuda()
+    pl, v, emb = root(obs)
+    s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=tiebreak, max_depth=max_depth))
+    inv = None if case["invalid"] is None else torch.from_numpy(case["invalid"])
+    s.root(pl, v, emb, list(key), inv, torch.from_numpy(case["noise"]), 0.25)
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S, tiebreak=int(tiebreak), max_depth=max_depth or 0)
+    oracle.tree_init(tree, oracle.root_prior(pl.cpu().numpy(), case["noise"], 0.25, case["invalid"]),
+                     v.cpu().numpy(), emb.cpu().numpy(), case["invalid"])
+    k_sample, _, sims = oracle.sim_keys_from_act_key(list(key), S)
+    for sim in range(S):
+        action, pemb = s.select(sim)
+        p_ref, a_ref, _ = oracle.step_select(tree, cfg, sim, sims[sim])
+        assert np.array_equal(a_ref, action.cpu().numpy()), sim
+        outs = rec(action, pemb)
+        s.expand_backup(sim, *outs)
+        oracle.step_expand_backup(tree, sim, p_ref, a_ref, *[o.cpu().numpy() for o in outs])
+    out = s.finish(1.0, None, with_tree=True)
+    g = oracle.gumbel(k_sample, B * A).reshape(B, A)
+    a_ref, w_ref = oracle.summary_sample(tree, 1.0, g)
+    assert np.array_equal(a_ref, out.action.cpu().numpy())
+    assert np.array_equal(w_ref, out.action_weights.cpu().numpy())
+    assert_trees_equal(tree, out.search_tree, exact_floats=True)
+    return tree
+
+
+def test_single_action_and_single_simulation(oracle):
+    """A = 1 (every walk is a chain, visit probabilities are [1]) and S = 1."""
+    case = make_case(oracle, 41, 20, 4, 8, 1, 12)
+    tree = _stepwise_vs_oracle(oracle, case, 12, True)
+    assert (tree.children_visits[:, 0, 0] == 12).all()
+    depth = np.zeros((20, 13), int)
+    for k in range(1, 13):
+        depth[:, k] = depth[np.arange(20), tree.parents[:, k]] + 1
+    assert (depth[:, 12] == 12).all()  # a single chain of depth S
+    case1 = make_case(oracle, 42, 30, 4, 8, 2, 1)
+    s, out = _fused(case1, True, [7, 7])
+    _compare(_oracle(oracle, case1, True, [7, 7]), s, out)
+
+
+def test_deep_chains_beyond_two_backup_chunks(oracle):
+    """Trees deeper than 32 levels: three 16-entry chunks in the backup phase, jump words across chunks."""
+    case = make_case(oracle, 43, 24, 4, 8, 2, 50)
+    # make one action overwhelmingly likely so the search digs a single deep line
+    case["w"]["pp_b2"] = np.array([6.0, -6.0], np.float32)
+    key = [3, 1]
+    s, out = _fused(case, True, key)
+    ref = _oracle(oracle, case, True, key)
+    _compare(ref, s, out)
+    par = ref["tree"].parents
+    depth = np.zeros_like(par)
+    for k in range(1, 51):
+        depth[:, k] = depth[np.arange(24), par[:, k]] + 1
+    assert depth.max() > 32
+
+
+def test_stepwise_many_simulations_and_wide_actions(oracle):
+    """S above the fused path's 50-node trees, A = 64 (the step-wise maximum), ragged batch."""
+    case = make_case(oracle, 44, 19, 6, 8, 64, 80, invalid_frac=0.5)
+    _stepwise_vs_oracle(oracle, case, 80, True)
+    case2 = make_case(oracle, 45, 5, 6, 8, 3, 300)
+    _stepwise_vs_oracle(oracle, case2, 300, False, max_depth=7)
+
+
+def test_model_act_falls_back_to_stepwise_above_fused_limits():
+    """num_simulations = 64 has no fused instance for the default trio: act() must still work (step-wise
+    kernels + torch nets) and keep the reference's conventions."""
+    import muax_amd as mx
+    g = torch.Generator().manual_seed(0)
+    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
+                          mx.nn.Dynamic(8, 2, 21, generator=g))
+    m = mx.MuZero(net)
+    m.init(0, np.zeros((1, 4)))
+    obs = np.random.default_rng(0).uniform(-1, 1, (10, 4)).astype(F32)
+    a, pi = m.act(2, obs, with_pi=True, obs_from_batch=True, num_simulations=64)
+    assert a.shape == (10,) and np.allclose(pi.sum(1), 1, atol=1e-6) and (pi * 64 == np.round(pi * 64)).all()
+
+
+def test_bad_arguments_raise_value_error():
+    from muax_amd import MuZeroSearch, SearchConfig
+    with pytest.raises(ValueError):
+        MuZeroSearch(4, SearchConfig(65, 5, 8))      # more than 64 actions
+    with pytest.raises(ValueError):
+        MuZeroSearch(4, SearchConfig(2, 0, 8))       # no simulations
+    s = MuZeroSearch(4, SearchConfig(2, 5, 8, global_batch=8, root_offset=4))
+    with pytest.raises(ValueError):
+        MuZeroSearch(4, SearchConfig(2, 5, 8, global_batch=6, root_offset=4))  # shard past the batch
+    w = {k: torch.zeros(s) for k, s in {"repr_w": (4, 8)}.items()}
+    with pytest.raises(KeyError):
+        s.set_mlp_weights(w, 4)
+    with pytest.raises(ValueError):
+        s.act_mlp(torch.zeros(4, 4), 0)              # weights never set

@@ -48,13 +48,15 @@ typedef struct {
   int32_t num_simulations; /* S */
   int32_t embed_dim;       /* E: flattened embedding elements per node */
   int32_t max_depth;       /* <= 0: num_simulations (mctx default) */
-  int32_t qtransform;      /* 0: qtransform_by_parent_and_siblings */
-  int32_t tiebreak;        /* 0: none; 1: JAX threefry stream (1e-7 * uniform) */
-  int32_t reserved0;
+  int32_t qtransform;      /* 0: qtransform_by_parent_and_siblings; 1: qtransform_completed_by_mix_value (gumbel policy only) */
+  int32_t tiebreak;        /* 0: none; 1: JAX threefry stream (1e-7 * uniform); muzero policy only */
+  int32_t policy;          /* 0: mctx.muzero_policy (muax/policy.py:13-30); 1: mctx.gumbel_muzero_policy (muax/policy.py:33-47), step-wise path */
   float pb_c_init;         /* 1.25  */
   float pb_c_base;         /* 19652 */
   int64_t global_batch;    /* B of the un-sharded batch (PRNG stream layout); 0 -> batch */
   int64_t root_offset;     /* global index of local root 0 */
+  int32_t max_num_considered_actions; /* gumbel policy: 16 (muax/policy.py:45) */
+  float gumbel_scale;                 /* gumbel policy: 1.0 (muax/policy.py:46) */
 } mzs_config;
 
 /* Weights of the default MLP trio (muax/nn.py:59-115), haiku layout w[in][out],
@@ -129,6 +131,11 @@ int mzs_root(mzs_handle *h, const float *prior_logits, const float *value,
              const float *embedding, const uint8_t *invalid_actions,
              const float *dirichlet_noise, float dirichlet_fraction,
              const uint32_t key[2], void *stream);
+/* gumbel policy root: only mctx's invalid-action mask is applied to the logits; `gumbel` [B,A] is
+ * the root Gumbel noise or NULL to draw gumbel_scale * jax.random.gumbel(split(key)[1], [B,A]). */
+int mzs_root_gumbel(mzs_handle *h, const float *prior_logits, const float *value,
+                    const float *embedding, const uint8_t *invalid_actions,
+                    const float *gumbel, const uint32_t key[2], void *stream);
 int mzs_select(mzs_handle *h, int32_t sim, int32_t *action_out,
                float *parent_embedding_out, void *stream);
 int mzs_expand_backup(mzs_handle *h, int32_t sim, const float *reward,

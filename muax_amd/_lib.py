@@ -19,8 +19,9 @@ class MzsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32),
                 ("num_actions", C.c_int32), ("num_simulations", C.c_int32), ("embed_dim", C.c_int32),
                 ("max_depth", C.c_int32), ("qtransform", C.c_int32), ("tiebreak", C.c_int32),
-                ("reserved0", C.c_int32), ("pb_c_init", C.c_float), ("pb_c_base", C.c_float),
-                ("global_batch", C.c_int64), ("root_offset", C.c_int64)]
+                ("policy", C.c_int32), ("pb_c_init", C.c_float), ("pb_c_base", C.c_float),
+                ("global_batch", C.c_int64), ("root_offset", C.c_int64),
+                ("max_num_considered_actions", C.c_int32), ("gumbel_scale", C.c_float)]
 
 
 MLP_WEIGHT_NAMES = ["repr_w", "repr_b", "pv_w1", "pv_b1", "pv_w2", "pv_b2", "pp_w1", "pp_b1", "pp_w2",
@@ -52,7 +53,8 @@ class MzsActArgs(C.Structure):
 
 
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
-                    "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_select", "mzs_expand_backup",
+                    "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
+                    "mzs_expand_backup",
                     "mzs_finish", "mzs_tree_export"]
 
 _lib = None
@@ -77,6 +79,7 @@ def load(build_if_missing: bool = True):
     L.mzs_mlp_set_weights.argtypes = [_vp, C.POINTER(MzsMlpWeights)]
     L.mzs_act_mlp.argtypes = [_vp, C.POINTER(MzsActArgs), _vp]
     L.mzs_root.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.POINTER(C.c_uint32 * 2), _vp]
+    L.mzs_root_gumbel.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32 * 2), _vp]
     L.mzs_select.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
     L.mzs_expand_backup.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mzs_finish.argtypes = [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/mzsearch.h"
 #include "mz_fused.cuh"
@@ -73,6 +74,27 @@ int fail(mzs_handle* h, int code, const char* fmt, const char* a = "") {
     if (e_ != hipSuccess) return fail(h, MZS_E_RUNTIME, #call ": %s", hipGetErrorString(e_)); \
   } while (0)
 
+// mctx seq_halving.get_table_of_considered_visits (host integers, uploaded once per handle)
+void considered_visits(int m, int S, int32_t* seq) {
+  if (m <= 1) {
+    for (int i = 0; i < S; ++i) seq[i] = i;
+    return;
+  }
+  int log2max = 0;
+  while ((1 << log2max) < m) ++log2max;
+  std::vector<int32_t> visits(m, 0);
+  int n = 0, nc = m;
+  while (n < S) {
+    int extra = S / (log2max * nc);
+    if (extra < 1) extra = 1;
+    for (int e = 0; e < extra; ++e) {
+      for (int i = 0; i < nc && n < S; ++i) seq[n++] = visits[i];
+      for (int i = 0; i < nc; ++i) visits[i] += 1;
+    }
+    nc = nc / 2 > 2 ? nc / 2 : 2;
+  }
+}
+
 // mctx muzero_policy / search key walk: (k_sample, k_dirichlet, k_search) = split(key, 3);
 // per simulation (rng, simulate_key, expand_key) = split(rng, 3).
 void derive_keys(mzs_handle* h, const uint32_t key[2]) {
@@ -128,7 +150,11 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     return fail(nullptr, MZS_E_INVALID, "mzs_create: batch, num_actions, num_simulations, embed_dim must be positive");
   if (cfg->num_actions > 64) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: num_actions > 64");
   if (cfg->num_simulations >= 65535) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: num_simulations too large");
-  if (cfg->qtransform != 0) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: only qtransform_by_parent_and_siblings");
+  if (cfg->policy != 0 && cfg->policy != 1) return fail(nullptr, MZS_E_INVALID, "mzs_create: policy must be 0 (muzero) or 1 (gumbel)");
+  if (cfg->qtransform != 0 && !(cfg->qtransform == 1 && cfg->policy == 1))
+    return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_create: qtransform_completed_by_mix_value is built for the gumbel policy only");
+  if (cfg->policy == 1 && cfg->max_num_considered_actions < 0)
+    return fail(nullptr, MZS_E_INVALID, "mzs_create: max_num_considered_actions");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, MZS_E_NODEVICE, "mzs_create: no HIP device (this library has no CPU fallback)");
@@ -182,6 +208,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
     return fail(h, MZS_E_INVALID, "mzs_act_mlp: dirichlet_fraction != 0 needs dirichlet_noise");
   const mzs_config& c = h->cfg;
   if (c.num_simulations > mz::kMaxSims) return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: num_simulations > 256 (use the step-wise path)");
+  if (c.policy != 0) return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: no fused kernel instance for the gumbel policy; use the step-wise path");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
 
@@ -244,6 +271,21 @@ int mzs_debug_profile(mzs_handle* h, uint64_t* device_buffer) {
 // step-wise path
 // ---------------------------------------------------------------------------
 
+static int ensure_step_state(mzs_handle* h) {
+  const mzs_config& c = h->cfg;
+  if (h->step.allocated) return MZS_OK;
+  const int rows = c.policy == 1 ? c.max_num_considered_actions + 1 : 0;
+  const int table_words = rows * c.num_simulations;
+  hipError_t e = h->step.allocate(c.batch, c.num_simulations + 1, c.num_actions, c.embed_dim, table_words);
+  if (e != hipSuccess) return fail(h, MZS_E_RUNTIME, "tree allocation: %s", hipGetErrorString(e));
+  if (table_words) {
+    std::vector<int32_t> table((size_t)table_words);
+    for (int m = 0; m < rows; ++m) considered_visits(m, c.num_simulations, table.data() + (size_t)m * c.num_simulations);
+    MZS_HIP(h, hipMemcpy(h->step.visit_table, table.data(), sizeof(int32_t) * (size_t)table_words, hipMemcpyHostToDevice));
+  }
+  return MZS_OK;
+}
+
 int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const float* embedding,
              const uint8_t* invalid_actions, const float* dirichlet_noise, float dirichlet_fraction,
              const uint32_t key[2], void* stream_) {
@@ -254,10 +296,8 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
   const mzs_config& c = h->cfg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
-  if (!h->step.allocated) {
-    hipError_t e = h->step.allocate(c.batch, c.num_simulations + 1, c.num_actions, c.embed_dim);
-    if (e != hipSuccess) return fail(h, MZS_E_RUNTIME, "mzs_root: tree allocation: %s", hipGetErrorString(e));
-  }
+  if (c.policy != 0) return fail(h, MZS_E_INVALID, "mzs_root: this handle runs the gumbel policy; use mzs_root_gumbel");
+  if (int rc = ensure_step_state(h)) return rc;
   uint32_t zero[2] = {0, 0};
   derive_keys(h, key ? key : zero);
   if (c.tiebreak) {
@@ -266,7 +306,29 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
   }
   mz::StepArgs sa = h->step.args(c);
   hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
-                     value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction);
+                     value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction, 0,
+                     static_cast<const float*>(nullptr), 0u, 0u);
+  MZS_HIP(h, hipGetLastError());
+  h->step.rooted = true;
+  return MZS_OK;
+}
+
+int mzs_root_gumbel(mzs_handle* h, const float* prior_logits, const float* value, const float* embedding,
+                    const uint8_t* invalid_actions, const float* gumbel, const uint32_t key[2], void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!prior_logits || !value || !embedding) return fail(h, MZS_E_INVALID, "mzs_root_gumbel: null input");
+  const mzs_config& c = h->cfg;
+  if (c.policy != 1) return fail(h, MZS_E_INVALID, "mzs_root_gumbel: handle was created with policy 0 (muzero)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  if (int rc = ensure_step_state(h)) return rc;
+  // mctx gumbel_muzero_policy: rng_key, gumbel_rng = jax.random.split(rng_key)
+  uint32_t zero[2] = {0, 0}, gk[2];
+  h_split(key ? key : zero, 2, 1, gk);
+  mz::StepArgs sa = h->step.args(c);
+  hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
+                     value, embedding, invalid_actions, static_cast<const float*>(nullptr), 0.0f, 1, gumbel, gk[0],
+                     gk[1]);
   MZS_HIP(h, hipGetLastError());
   h->step.rooted = true;
   return MZS_OK;
@@ -281,8 +343,12 @@ int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_em
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
-  hipLaunchKernelGGL(mz::step_select_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
-                     action_out, parent_embedding_out);
+  if (c.policy == 1)
+    hipLaunchKernelGGL(mz::step_select_gumbel_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+                       action_out, parent_embedding_out);
+  else
+    hipLaunchKernelGGL(mz::step_select_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+                       action_out, parent_embedding_out);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;
 }
@@ -314,9 +380,13 @@ int mzs_finish(mzs_handle* h, float temperature, const float* gumbel, int32_t* a
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
-  hipLaunchKernelGGL(mz::step_finish_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, temperature,
-                     gumbel, h->k_sample[0], h->k_sample[1], action_out, action_weights_out, search_value_out,
-                     depth_sum_out);
+  if (c.policy == 1)
+    hipLaunchKernelGGL(mz::step_finish_gumbel_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa,
+                       action_out, action_weights_out, search_value_out, depth_sum_out);
+  else
+    hipLaunchKernelGGL(mz::step_finish_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, temperature,
+                       gumbel, h->k_sample[0], h->k_sample[1], action_out, action_weights_out, search_value_out,
+                       depth_sum_out);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;
 }

@@ -119,6 +119,13 @@ MZ_DEV int row_sum_i(int p) {
   p = p + dpp_i<kDppMirror>(p);
   return p;
 }
+MZ_DEV int row_max_i(int x) {
+  x = max(x, dpp_i<kDppXor1>(x));
+  x = max(x, dpp_i<kDppXor2>(x));
+  x = max(x, dpp_i<kDppHalfMirror>(x));
+  x = max(x, dpp_i<kDppMirror>(x));
+  return x;
+}
 // first-max argmax over (score, index) with a payload riding along
 template <int STEPS>
 MZ_DEV void row_argmax(float& score, int& idx, int& payload) {

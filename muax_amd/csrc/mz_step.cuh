@@ -26,6 +26,11 @@ struct StepArgs {
   uint8_t* root_invalid;
   int32_t *sel_parent, *sel_action, *sel_depth, *depth_sum, *path;
   const uint32_t* sim_keys;
+  // gumbel policy
+  int32_t qtransform, max_considered;
+  float gumbel_scale;
+  float* root_gumbel;           // [B, A]
+  const int32_t* visit_table;   // [(max_considered + 1), S] seq_halving.get_table_of_considered_visits
 };
 
 struct StepState {
@@ -40,12 +45,15 @@ struct StepState {
   int32_t *sel_parent = nullptr, *sel_action = nullptr, *sel_depth = nullptr, *depth_sum = nullptr,
           *path = nullptr;
   uint32_t* sim_keys = nullptr;
+  float* root_gumbel = nullptr;
+  int32_t* visit_table = nullptr;
   void* slab = nullptr;
 
   // one slab, carved: the only allocation the handle ever makes
-  hipError_t allocate(int B, int N, int A, int E) {
+  hipError_t allocate(int B, int N, int A, int E, int table_words) {
     size_t BN = (size_t)B * N;
-    size_t words = 5 * BN + 7 * BN * A + BN * E + 4 * (size_t)B + BN + 2 * (size_t)N;
+    size_t words = 5 * BN + 7 * BN * A + BN * E + 4 * (size_t)B + BN + 2 * (size_t)N + (size_t)B * A +
+                   (size_t)table_words;
     size_t bytes = words * 4 + (size_t)B * A + 256;
     hipError_t e = hipMalloc(&slab, bytes);
     if (e != hipSuccess) return e;
@@ -59,6 +67,7 @@ struct StepState {
     children_discounts = (float*)take(BN * A); embeddings = (float*)take(BN * E);
     sel_parent = (int32_t*)take(B); sel_action = (int32_t*)take(B); sel_depth = (int32_t*)take(B);
     depth_sum = (int32_t*)take(B); path = (int32_t*)take(BN); sim_keys = take(2 * (size_t)N);
+    root_gumbel = (float*)take((size_t)B * A); visit_table = (int32_t*)take(table_words);
     root_invalid = reinterpret_cast<uint8_t*>(w);
     allocated = true;
     return hipSuccess;
@@ -83,6 +92,8 @@ struct StepState {
     a.root_invalid = root_invalid;
     a.sel_parent = sel_parent; a.sel_action = sel_action; a.sel_depth = sel_depth;
     a.depth_sum = depth_sum; a.path = path; a.sim_keys = sim_keys;
+    a.qtransform = c.qtransform; a.max_considered = c.max_num_considered_actions;
+    a.gumbel_scale = c.gumbel_scale; a.root_gumbel = root_gumbel; a.visit_table = visit_table;
     return a;
   }
 };
@@ -118,7 +129,8 @@ MZ_DEV void row_softmax_rt(const float (&x)[kMaxAS], int A, int j, float (&p)[kM
 __global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float* prior_logits,
                                                          const float* value, const float* embedding,
                                                          const uint8_t* invalid, const float* noise,
-                                                         float fraction) {
+                                                         float fraction, int gumbel_policy,
+                                                         const float* gumbel_in, uint32_t gk0, uint32_t gk1) {
   MZ_ROW_SETUP
   for (int n = j; n < N; n += 16) {
     s.node_visits[rb + n] = 0;
@@ -147,18 +159,47 @@ __global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float*
     inv[t] = (invalid != nullptr && a < A) ? invalid[(size_t)r * A + a] != 0 : false;
     if (a < A) s.root_invalid[(size_t)r * A + a] = inv[t] ? 1 : 0;
   }
-  row_softmax_rt(x, A, j, pr);
-  float keep = 1.0f - fraction;
   float mx = -INFINITY;
+  bool any_invalid = false;
+  if (!gumbel_policy) {
+    // mctx muzero_policy prelude: Dirichlet mix, log
+    row_softmax_rt(x, A, j, pr);
+    float keep = 1.0f - fraction;
 #pragma unroll
-  for (int t = 0; t < kMaxAS; ++t) {
-    int a = j + 16 * t;
-    float nz = (noise != nullptr && a < A) ? noise[(size_t)r * A + a] : 0.0f;
-    float noisy = keep * pr[t] + fraction * nz;
-    lg[t] = log_pos(fmaxf(noisy, kFltTiny));
-    mx = a < A ? fmaxf(mx, lg[t]) : mx;
+    for (int t = 0; t < kMaxAS; ++t) {
+      int a = j + 16 * t;
+      float nz = (noise != nullptr && a < A) ? noise[(size_t)r * A + a] : 0.0f;
+      float noisy = keep * pr[t] + fraction * nz;
+      lg[t] = log_pos(fmaxf(noisy, kFltTiny));
+      mx = a < A ? fmaxf(mx, lg[t]) : mx;
+    }
+    any_invalid = invalid != nullptr;
+  } else {
+    // mctx gumbel_muzero_policy: the logits only pass through _mask_invalid_actions; root Gumbel noise
+    const uint64_t rg = s.root_offset + (uint64_t)r;
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      int a = j + 16 * t;
+      lg[t] = x[t];
+      mx = a < A ? fmaxf(mx, lg[t]) : mx;
+      any_invalid = any_invalid || inv[t];
+      if (a < A) {
+        float g;
+        if (gumbel_in != nullptr) {
+          g = gumbel_in[(size_t)r * A + a];
+        } else {
+          uint32_t x0, x1;
+          bool second;
+          bits_block(s.global_batch * (uint64_t)A, rg * (uint64_t)A + (uint64_t)a, x0, x1, second);
+          threefry2x32(gk0, gk1, x0, x1);
+          g = s.gumbel_scale * gumbel_from_bits(second ? x1 : x0);
+        }
+        s.root_gumbel[(size_t)r * A + a] = g;
+      }
+    }
+    any_invalid = ((__builtin_amdgcn_ballot_w64(any_invalid) >> (lane & 48)) & 0xffffull) != 0;  // any lane of the row
   }
-  if (invalid != nullptr) {
+  if (any_invalid) {
     mx = row_max<4>(mx);
 #pragma unroll
     for (int t = 0; t < kMaxAS; ++t) lg[t] = inv[t] ? kFltLowest : lg[t] - mx;
@@ -381,6 +422,210 @@ __global__ __launch_bounds__(256) void step_finish_kernel(StepArgs s, float temp
     if (take) { bscore = score; best = ok ? a : (1 << 20); }
   }
   row_argmax<4>(bscore, best, dummy);
+  if (j == 0) {
+    action_out[r] = best;
+    if (search_value_out) search_value_out[r] = s.node_values[rb];
+    if (depth_sum_out) depth_sum_out[r] = s.depth_sum[r];
+  }
+}
+
+// canonical 16-wide sum of a row-distributed vector with run-time length
+MZ_DEV float row_sum_rt(const float (&x)[kMaxAS], int A, int j) {
+  float part = 0.0f;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    bool ok = j + 16 * t < A;
+    part = (t == 0) ? (ok ? x[0] : 0.0f) : (ok ? part + x[t] : part);
+  }
+  return row_sum(part);
+}
+
+// mctx qtransforms for one node, row-distributed (kind 0: by_parent_and_siblings, 1: completed_by_mix_value)
+MZ_DEV void row_qtransform(const StepArgs& s, size_t rb, int node, int A, int j, float (&out)[kMaxAS],
+                           int (&vc)[kMaxAS], float (&logits)[kMaxAS], int& sum_visits) {
+  const size_t nb = (rb + node) * A;
+  float q[kMaxAS];
+  int part = 0, mxv = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    bool ok = a < A;
+    size_t o = nb + (ok ? a : 0);
+    vc[t] = ok ? s.children_visits[o] : 0;
+    logits[t] = ok ? s.children_prior_logits[o] : 0.0f;
+    q[t] = s.children_rewards[o] + s.children_discounts[o] * s.children_values[o];
+    part += vc[t];
+    mxv = max(mxv, vc[t]);
+  }
+  sum_visits = row_sum_i(part);
+  if (s.qtransform == 0) {
+    float nval = s.node_values[rb + node];
+    float lo = nval, hi = nval;
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      float safe = (j + 16 * t < A && vc[t] > 0) ? q[t] : nval;
+      lo = fminf(lo, safe);
+      hi = fmaxf(hi, safe);
+    }
+    lo = row_min<4>(lo);
+    hi = row_max<4>(hi);
+    float span = fmaxf(hi - lo, 1e-8f);
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) out[t] = ((vc[t] > 0 ? q[t] : lo) - lo) / span;
+    return;
+  }
+  float maxvisit = (float)row_max_i(mxv);
+  float prior[kMaxAS], tmp[kMaxAS];
+  row_softmax_rt(logits, A, j, prior);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    prior[t] = fmaxf(prior[t], kFltTiny);
+    tmp[t] = vc[t] > 0 ? prior[t] : 0.0f;
+  }
+  float sum_probs = row_sum_rt(tmp, A, j);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) tmp[t] = vc[t] > 0 ? (prior[t] * q[t]) / sum_probs : 0.0f;
+  float weighted_q = row_sum_rt(tmp, A, j);
+  float value = (s.raw_values[rb + node] + (float)sum_visits * weighted_q) / (float)(sum_visits + 1);
+  float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    out[t] = vc[t] > 0 ? q[t] : value;
+    bool ok = j + 16 * t < A;
+    lo = ok ? fminf(lo, out[t]) : lo;
+    hi = ok ? fmaxf(hi, out[t]) : hi;
+  }
+  lo = row_min<4>(lo);
+  hi = row_max<4>(hi);
+  float span = fmaxf(hi - lo, 1e-8f);
+  float scale = (50.0f + maxvisit) * 0.1f;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) out[t] = scale * ((out[t] - lo) / span);
+}
+
+// seq_halving.score_considered + masked_argmax over a row-distributed action set
+MZ_DEV int row_gumbel_argmax(const StepArgs& s, int r, int A, int j, int considered_visit,
+                             const float (&logits)[kMaxAS], const float (&qv)[kMaxAS], const int (&vc)[kMaxAS],
+                             int (&cidx)[kMaxAS], int& next) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) mx = (j + 16 * t < A) ? fmaxf(mx, logits[t]) : mx;
+  mx = row_max<4>(mx);
+  float bscore = -INFINITY;
+  int best = 1 << 20, bnext = -1;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    int a = j + 16 * t;
+    bool ok = a < A;
+    float g = ok ? s.root_gumbel[(size_t)r * A + a] : 0.0f;
+    float sc = (g + (logits[t] - mx)) + qv[t];
+    sc = fmaxf(sc, -1e9f);
+    sc = sc + (vc[t] == considered_visit ? 0.0f : -INFINITY);
+    if (ok && s.root_invalid[(size_t)r * A + a]) sc = -INFINITY;
+    if (!ok) sc = -INFINITY;
+    bool take = (t == 0) || (sc > bscore);
+    if (take) { bscore = sc; best = ok ? a : (1 << 20); bnext = cidx[t]; }
+  }
+  row_argmax<4>(bscore, best, bnext);
+  next = bnext;
+  return best;
+}
+
+// mctx search.simulate with gumbel_muzero_{root,interior}_action_selection
+__global__ __launch_bounds__(256) void step_select_gumbel_kernel(StepArgs s, int sim, int32_t* action_out,
+                                                                  float* parent_embedding_out) {
+  MZ_ROW_SETUP
+  int node = 0, depth = 0, parent = 0, action = 0;
+  for (;;) {
+    const size_t nb = (rb + node) * A;
+    float qv[kMaxAS], logits[kMaxAS];
+    int vc[kMaxAS], cidx[kMaxAS], sum_visits;
+    row_qtransform(s, rb, node, A, j, qv, vc, logits, sum_visits);
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) cidx[t] = s.children_index[nb + (j + 16 * t < A ? j + 16 * t : 0)];
+    int best, next;
+    if (depth == 0) {
+      int ninv = 0;
+#pragma unroll
+      for (int t = 0; t < kMaxAS; ++t)
+        ninv += (j + 16 * t < A && s.root_invalid[(size_t)r * A + j + 16 * t]) ? 1 : 0;
+      const int num_valid = A - row_sum_i(ninv);
+      const int num_considered = min(s.max_considered, num_valid);
+      const int si = min(sum_visits, s.S - 1);
+      const int considered_visit = s.visit_table[(size_t)num_considered * s.S + si];
+      best = row_gumbel_argmax(s, r, A, j, considered_visit, logits, qv, vc, cidx, next);
+    } else {
+      float x[kMaxAS], p[kMaxAS];
+#pragma unroll
+      for (int t = 0; t < kMaxAS; ++t) x[t] = logits[t] + qv[t];
+      row_softmax_rt(x, A, j, p);
+      float bscore = -INFINITY;
+      int b2 = 1 << 20, bnext = -1;
+#pragma unroll
+      for (int t = 0; t < kMaxAS; ++t) {
+        int a = j + 16 * t;
+        bool ok = a < A;
+        float sc = ok ? p[t] - (float)vc[t] / (float)(1 + sum_visits) : -INFINITY;
+        bool take = (t == 0) || (sc > bscore);
+        if (take) { bscore = sc; b2 = ok ? a : (1 << 20); bnext = cidx[t]; }
+      }
+      row_argmax<4>(bscore, b2, bnext);
+      best = b2;
+      next = bnext;
+    }
+    if (j == 0) s.path[rb + depth] = node | (best << 16);
+    parent = node;
+    action = best;
+    depth += 1;
+    if (next == -1 || depth >= s.max_depth) break;
+    node = next;
+  }
+  if (j == 0) {
+    s.sel_parent[r] = parent;
+    s.sel_action[r] = action;
+    s.sel_depth[r] = depth;
+    s.depth_sum[r] += depth;
+    action_out[r] = action;
+  }
+  const float* src = s.embeddings + (rb + parent) * E;
+  for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+}
+
+// tail of mctx gumbel_muzero_policy: best considered action + completed-Q policy target
+__global__ __launch_bounds__(256) void step_finish_gumbel_kernel(StepArgs s, int32_t* action_out,
+                                                                  float* action_weights_out,
+                                                                  float* search_value_out, int32_t* depth_sum_out) {
+  MZ_ROW_SETUP
+  float qv[kMaxAS], logits[kMaxAS];
+  int vc[kMaxAS], cidx[kMaxAS] = {0, 0, 0, 0}, sum_visits, next;
+  row_qtransform(s, rb, 0, A, j, qv, vc, logits, sum_visits);
+  int mxv = 0;
+  bool any_inv = false;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    mxv = max(mxv, vc[t]);
+    any_inv = any_inv || (j + 16 * t < A && s.root_invalid[(size_t)r * A + j + 16 * t]);
+  }
+  const int considered_visit = row_max_i(mxv);
+  const int best = row_gumbel_argmax(s, r, A, j, considered_visit, logits, qv, vc, cidx, next);
+  any_inv = ((__builtin_amdgcn_ballot_w64(any_inv) >> (lane & 48)) & 0xffffull) != 0;
+  float x[kMaxAS], w[kMaxAS];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    x[t] = logits[t] + qv[t];
+    mx = (j + 16 * t < A) ? fmaxf(mx, x[t]) : mx;
+  }
+  if (any_inv) {
+    mx = row_max<4>(mx);
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t)
+      x[t] = (j + 16 * t < A && s.root_invalid[(size_t)r * A + j + 16 * t]) ? kFltLowest : x[t] - mx;
+  }
+  row_softmax_rt(x, A, j, w);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t)
+    if (j + 16 * t < A) action_weights_out[(size_t)r * A + j + 16 * t] = w[t];
   if (j == 0) {
     action_out[r] = best;
     if (search_value_out) search_value_out[r] = s.node_values[rb];

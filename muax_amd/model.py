@@ -21,7 +21,7 @@ from . import nn as mz_nn
 from . import prng
 from . import utils as mx_utils
 from .nn import MZNetwork, MZNetworkParams
-from .policy import MuZeroPolicy, Policy
+from .policy import GumbelMuZeroPolicy, MuZeroPolicy, Policy
 from .search import MuZeroSearch, PolicyOutput, SearchConfig
 
 
@@ -56,9 +56,9 @@ class MuZero:
                 raise ValueError("give either an MZNetwork or representation_fn, prediction_fn and dynamic_fn")
             self.network = MZNetwork(rep, prediction_fn, dynamic_fn)
         if policy is not None:
-            if policy != "muzero":
-                raise NotImplementedError(f"policy={policy!r}: only 'muzero' is built (SURVEY.md 8(f))")
-            policy_class = MuZeroPolicy
+            if policy not in ("muzero", "gumbel"):
+                raise NotImplementedError(f"policy={policy!r}: 'muzero' and 'gumbel' are built (SURVEY.md 8(f))")
+            policy_class = MuZeroPolicy if policy == "muzero" else GumbelMuZeroPolicy
         if not (isinstance(policy_class, type) and issubclass(policy_class, Policy)):
             raise TypeError("policy_class must be a subclass of muax_amd.policy.Policy")
         self.repr_func, self.pred_func, self.dy_func = self.network
@@ -163,15 +163,27 @@ class MuZero:
     def _plan(self, params, rng_key, obs, num_simulations=5, temperature=1., invalid_actions=None,
               max_depth=None, loop_fn=None, qtransform=None, dirichlet_fraction=0.25, dirichlet_alpha=0.3,
               pb_c_init=1.25, pb_c_base=19652, dirichlet_noise=None, gumbel=None, tiebreak=True,
-              with_tree=False):
+              with_tree=False, max_num_considered_actions=16, gumbel_scale=1.0):
         """muax/model.py:222-243 -> (PolicyOutput, root value)."""
         if self._params is None:
             raise ValueError("call init() first")
-        if qtransform is not None and getattr(qtransform, "__name__", qtransform) != "qtransform_by_parent_and_siblings":
-            raise ValueError("only qtransform_by_parent_and_siblings is implemented")
+        gumbel_policy = isinstance(self._policy, GumbelMuZeroPolicy)
+        if qtransform is None:
+            qtransform = "qtransform_by_parent_and_siblings"  # muax/model.py:230-231, for EVERY policy
+        qtransform = getattr(qtransform, "__name__", qtransform)
+        if qtransform != "qtransform_by_parent_and_siblings" and not (
+                gumbel_policy and qtransform == "qtransform_completed_by_mix_value"):
+            raise ValueError(f"qtransform {qtransform!r} is not implemented for this policy")
         key = prng.as_key(rng_key)
         B = obs.shape[0]
         A = self.pred_func.num_actions if hasattr(self.pred_func, "num_actions") else None
+        if gumbel_policy:
+            root = self._root_inference(params, key, obs)
+            out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
+                               invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
+                               max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
+                               gumbel=gumbel, with_tree=with_tree)
+            return out, root[1]
         if dirichlet_noise is None and dirichlet_fraction:
             k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
             if A is None:
@@ -203,7 +215,8 @@ class MuZero:
             num_simulations: int = 5, temperature: float = 1., invalid_actions=None, max_depth: int = None,
             loop_fn=None, qtransform=None, dirichlet_fraction: float = 0.25, dirichlet_alpha: float = 0.3,
             pb_c_init: float = 1.25, pb_c_base: float = 19652, *, dirichlet_noise=None, gumbel=None,
-            tiebreak: bool = True, device_outputs: bool = False):
+            tiebreak: bool = True, device_outputs: bool = False, max_num_considered_actions: int = 16,
+            gumbel_scale: float = 1.0):
         r"""Acts given environment observations (muax/model.py:82-179, same arguments and defaults).
 
         Returns `action[, action_weights][, root_value]` in the reference's order.  Unbatched: action is a
@@ -212,7 +225,8 @@ class MuZero:
         default (one host sync, like the reference's np.asarray), or device tensors with
         `device_outputs=True` (no sync).  `root_value` is the NETWORK value of the root, as the reference.
         Keyword-only extras: exact `dirichlet_noise` / `gumbel` arrays, `tiebreak=False` to drop mctx's
-        1e-7 tie-break noise.
+        1e-7 tie-break noise; for the Gumbel policy `max_num_considered_actions` and `gumbel_scale`, which
+        the reference documents (muax/model.py:142-147) but never plumbs through.
         """
         obs = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs, dtype=torch.float32)
         if not obs_from_batch:
@@ -222,7 +236,8 @@ class MuZero:
             self.params, rng_key, obs, num_simulations=num_simulations, temperature=temperature,
             invalid_actions=invalid_actions, max_depth=max_depth, loop_fn=loop_fn, qtransform=qtransform,
             dirichlet_fraction=dirichlet_fraction, dirichlet_alpha=dirichlet_alpha, pb_c_init=pb_c_init,
-            pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak)
+            pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak,
+            max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale)
         if not obs_from_batch:
             action = int(plan_output.action.item())
             weights = plan_output.action_weights.cpu().numpy()

@@ -60,11 +60,44 @@ class MuZeroPolicy(Policy):
 
 
 class GumbelMuZeroPolicy(Policy):
-    """muax/policy.py:33-47 (mctx.gumbel_muzero_policy): next on the list."""
+    """muax/policy.py:33-47: mctx.gumbel_muzero_policy with the same keyword defaults
+    (max_num_considered_actions=16, gumbel_scale=1).  Runs on the step-wise HIP kernels.
+
+    qtransform: mctx's own default for this policy is qtransform_completed_by_mix_value, which is what
+    this adapter uses when called directly.  Note the reference quirk one level up: MuZero._plan always
+    substitutes qtransform_by_parent_and_siblings when none is given (muax/model.py:230-231), so going
+    through MuZero.act the Gumbel search runs with THAT transform unless one is passed explicitly --
+    muax_amd.MuZero reproduces this."""
+
+    def __init__(self):
+        self._handles = {}
 
     def __call__(self, params, rng_key, root, recurrent_fn=None, decision_recurrent_fn=None,
-                 chance_recurrent_fn=None, **kwargs):
-        raise NotImplementedError("Gumbel MuZero search is not built yet (SURVEY.md section 8(f), n2)")
+                 chance_recurrent_fn=None, **kwargs) -> PolicyOutput:
+        prior_logits, value, embedding = root
+        B, A = prior_logits.shape
+        emb = embedding.reshape(B, -1)
+        S = kwargs.get("num_simulations", 5)
+        qt = kwargs.get("qtransform") or "qtransform_completed_by_mix_value"
+        qt = getattr(qt, "__name__", qt)
+        key = (B, A, S, emb.shape[1], kwargs.get("max_depth"), qt, kwargs.get("max_num_considered_actions", 16),
+               kwargs.get("gumbel_scale", 1), str(prior_logits.device))
+        if key not in self._handles:
+            cfg = SearchConfig(A, S, emb.shape[1], max_depth=kwargs.get("max_depth"), tiebreak=False,
+                               policy="gumbel", qtransform=qt,
+                               max_num_considered_actions=kwargs.get("max_num_considered_actions", 16),
+                               gumbel_scale=float(kwargs.get("gumbel_scale", 1)))
+            self._handles[key] = MuZeroSearch(B, cfg, prior_logits.device)
+        h = self._handles[key]
+        shape = tuple(embedding.shape[1:])
+
+        def rec(action, flat_emb):
+            (reward, discount, logits, v), nxt = recurrent_fn(params, None, action, flat_emb.reshape((B,) + shape))
+            return reward, discount, logits, v, nxt.reshape(B, -1)
+
+        return h.search((prior_logits, value, emb), rec, key=rng_key,
+                        invalid_actions=kwargs.get("invalid_actions"), gumbel=kwargs.get("gumbel"),
+                        with_tree=kwargs.get("with_tree", False))
 
 
 class StochasticMuZeroPolicy(Policy):

@@ -54,6 +54,10 @@ class SearchConfig:
     pb_c_base: float = 19652.0
     global_batch: Optional[int] = None
     root_offset: int = 0
+    policy: str = "muzero"         # "muzero" (muax/policy.py:13-30) or "gumbel" (muax/policy.py:33-47)
+    qtransform: str = "qtransform_by_parent_and_siblings"   # or "qtransform_completed_by_mix_value" (gumbel)
+    max_num_considered_actions: int = 16
+    gumbel_scale: float = 1.0
 
 
 def key_words(key) -> tuple:
@@ -89,7 +93,14 @@ class MuZeroSearch:
         c.batch, c.num_actions = self.batch, cfg.num_actions
         c.num_simulations, c.embed_dim = cfg.num_simulations, cfg.embed_dim
         c.max_depth = cfg.max_depth or 0
-        c.qtransform, c.tiebreak = 0, int(bool(cfg.tiebreak))
+        try:
+            c.policy = {"muzero": 0, "gumbel": 1}[cfg.policy]
+            c.qtransform = {"qtransform_by_parent_and_siblings": 0, "qtransform_completed_by_mix_value": 1}[
+                getattr(cfg.qtransform, "__name__", cfg.qtransform)]
+        except KeyError as e:
+            raise ValueError(f"unknown policy / qtransform: {e}") from None
+        c.tiebreak = int(bool(cfg.tiebreak))
+        c.max_num_considered_actions, c.gumbel_scale = cfg.max_num_considered_actions, cfg.gumbel_scale
         c.pb_c_init, c.pb_c_base = cfg.pb_c_init, cfg.pb_c_base
         c.global_batch = cfg.global_batch or self.batch
         c.root_offset = cfg.root_offset
@@ -231,6 +242,22 @@ class MuZeroSearch:
         if self._parent_emb is None:
             self._parent_emb = torch.empty(B, E, dtype=torch.float32, device=self.device)
 
+    def root_gumbel(self, prior_logits, value, embedding, key=0, invalid_actions=None, gumbel=None):
+        """Gumbel MuZero root (mctx gumbel_muzero_policy prelude): invalid-action mask only, root Gumbel
+        noise drawn from the key (or injected)."""
+        B, A, E = self.batch, self.cfg.num_actions, self.cfg.embed_dim
+        pl = self._f32(prior_logits, (B, A), "prior_logits")
+        v = self._f32(value, (B,), "value")
+        emb = self._f32(torch.as_tensor(embedding, device=self.device).reshape(B, -1), (B, E), "embedding")
+        inv = self._u8(invalid_actions, (B, A), "invalid_actions")
+        g = self._f32(gumbel, (B, A), "gumbel")
+        kw = (C.c_uint32 * 2)(*key_words(key))
+        _lib.check(self._L.mzs_root_gumbel(self._h, _ptr(pl), _ptr(v), _ptr(emb), _ptr(inv), _ptr(g),
+                                           C.byref(kw), self._stream()), self._h)
+        self._keep = (pl, v, emb, inv, g)
+        if self._parent_emb is None:
+            self._parent_emb = torch.empty(B, E, dtype=torch.float32, device=self.device)
+
     def select(self, sim: int):
         """One mctx simulate(): returns (action [B] int32, parent embedding [B,E])."""
         if self._parent_emb is None:
@@ -272,8 +299,12 @@ class MuZeroSearch:
         """mctx.muzero_policy with a caller-supplied recurrent_fn(action, embedding) ->
         (reward, discount, prior_logits, value, next_embedding) of torch tensors."""
         prior_logits, value, embedding = root_fn_output
-        self.root(prior_logits, value, embedding, key, invalid_actions, dirichlet_noise,
-                  dirichlet_fraction)
+        if self.cfg.policy == "gumbel":
+            self.root_gumbel(prior_logits, value, embedding, key, invalid_actions, gumbel)
+            gumbel = None
+        else:
+            self.root(prior_logits, value, embedding, key, invalid_actions, dirichlet_noise,
+                      dirichlet_fraction)
         for sim in range(self.cfg.num_simulations):
             action, emb = self.select(sim)
             self.expand_backup(sim, *recurrent_fn(action, emb))

@@ -257,3 +257,141 @@ def act_mlp(w, obs, S, A, E, support_size=10, discount=0.99, dirichlet_noise=Non
     action, weights = summary_sample(tree, temperature, g)
     return {"action": action, "action_weights": weights, "root_value": v0, "tree": tree,
             "min_margin": margin, "depth_sum": dsum}
+
+
+# ---- Gumbel MuZero (mctx gumbel_muzero_policy), independent restatement ---------------------------
+
+def considered_visits(m, num_simulations):
+    """seq_halving.get_sequence_of_considered_visits"""
+    import math
+    if m <= 1:
+        return list(range(num_simulations))
+    log2max = int(math.ceil(math.log2(m)))
+    seq, visits, nc = [], [0] * m, m
+    while len(seq) < num_simulations:
+        extra = max(1, int(num_simulations / (log2max * nc)))
+        for _ in range(extra):
+            seq.extend(visits[:nc])
+            for i in range(nc):
+                visits[i] += 1
+        nc = max(2, nc // 2)
+    return seq[:num_simulations]
+
+
+def qtransform_completed_by_mix_value(tree, rows, node, value_scale=0.1, maxvisit_init=50.0, eps=1e-8):
+    vc = tree.children_visits[rows, node]
+    q = tree.children_rewards[rows, node] + tree.children_discounts[rows, node] * tree.children_values[rows, node]
+    raw = tree.raw_values[rows, node]
+    prior = np.maximum(TINY, softmax(tree.children_prior_logits[rows, node]))
+    sum_visits = vc.sum(-1)
+    sum_probs = np.where(vc > 0, prior, 0).sum(-1, keepdims=True)
+    weighted_q = np.where(vc > 0, prior * q / np.where(vc > 0, sum_probs, 1.0), 0.0).sum(-1)
+    value = (raw + sum_visits * weighted_q) / (sum_visits + 1)
+    cq = np.where(vc > 0, q, value[:, None])
+    lo, hi = cq.min(-1, keepdims=True), cq.max(-1, keepdims=True)
+    cq = (cq - lo) / np.maximum(hi - lo, F32(eps))
+    return ((F32(maxvisit_init) + vc.max(-1))[:, None] * F32(value_scale) * cq).astype(F32)
+
+
+def qtransform_by_parent_and_siblings(tree, rows, node, eps=1e-8):
+    vc = tree.children_visits[rows, node]
+    q = tree.children_rewards[rows, node] + tree.children_discounts[rows, node] * tree.children_values[rows, node]
+    nval = tree.node_values[rows, node][:, None]
+    safe = np.where(vc > 0, q, nval)
+    lo = np.minimum(nval, safe.min(-1, keepdims=True))
+    hi = np.maximum(nval, safe.max(-1, keepdims=True))
+    return ((np.where(vc > 0, q, lo) - lo) / np.maximum(hi - lo, F32(eps))).astype(F32)
+
+
+def _score_considered(considered_visit, gumbel, logits, qv, vc):
+    logits = logits - logits.max(-1, keepdims=True)
+    penalty = np.where(vc == considered_visit[:, None], 0, -np.inf)
+    return np.maximum(-1e9, gumbel + logits + qv) + penalty
+
+
+def gumbel_search(tree, recurrent_fn, S, root_gumbel, max_considered=16, qtransform="mix", max_depth=None):
+    """mctx search with gumbel_muzero_{root,interior}_action_selection. Returns depth_sum."""
+    B, A = tree.B, tree.A
+    qt = qtransform_completed_by_mix_value if qtransform == "mix" else qtransform_by_parent_and_siblings
+    max_depth = S if not max_depth or max_depth <= 0 else max_depth
+    br = np.arange(B)
+    table = [considered_visits(m, S) for m in range(max_considered + 1)]
+    num_valid = (1 - tree.root_invalid_actions.astype(np.int32)).sum(-1)
+    num_considered = np.minimum(max_considered, num_valid)
+    depth_sum = np.zeros(B, np.int64)
+    for sim in range(S):
+        node = np.zeros(B, np.int32)
+        parent = np.zeros(B, np.int32)
+        action = np.zeros(B, np.int32)
+        depth = np.zeros(B, np.int32)
+        cont = np.ones(B, bool)
+        level = 0
+        while cont.any():
+            rows = br[cont]
+            n = node[rows]
+            vc = tree.children_visits[rows, n]
+            qv = qt(tree, rows, n)
+            logits = tree.children_prior_logits[rows, n]
+            if level == 0:
+                cv = np.array([table[num_considered[b]][vc[i].sum()] for i, b in enumerate(rows)])
+                score = _score_considered(cv, root_gumbel[rows], logits, qv, vc)
+                score = np.where(tree.root_invalid_actions[rows].astype(bool), -np.inf, score)
+            else:
+                probs = softmax(logits + qv)
+                score = probs - vc / (1 + vc.sum(-1, keepdims=True))
+            a = score.argmax(-1).astype(np.int32)
+            parent[rows] = n
+            action[rows] = a
+            nxt = tree.children_index[rows, n, a]
+            depth[rows] += 1
+            go = (nxt != -1) & (depth[rows] < max_depth)
+            node[rows[go]] = nxt[go]
+            cont[rows[~go]] = False
+            level += 1
+        depth_sum += depth
+        nxt = tree.children_index[br, parent, action]
+        nxt = np.where(nxt == -1, sim + 1, nxt).astype(np.int32)
+        r, d, pl, v, ne = recurrent_fn(action, tree.embeddings[br, parent])
+        tree.children_prior_logits[br, nxt] = pl
+        tree.raw_values[br, nxt] = v
+        tree.node_values[br, nxt] = v
+        tree.node_visits[br, nxt] += 1
+        tree.embeddings[br, nxt] = ne
+        tree.children_index[br, parent, action] = nxt
+        tree.children_rewards[br, parent, action] = r
+        tree.children_discounts[br, parent, action] = d
+        tree.parents[br, nxt] = parent
+        tree.action_from_parent[br, nxt] = action
+        leaf_value = tree.node_values[br, nxt].copy()
+        idx = nxt.copy()
+        while (idx != 0).any():
+            rows = br[idx != 0]
+            i = idx[rows]
+            p = tree.parents[rows, i]
+            cnt = tree.node_visits[rows, p]
+            a = tree.action_from_parent[rows, i]
+            lv = tree.children_rewards[rows, p, a] + tree.children_discounts[rows, p, a] * leaf_value[rows]
+            leaf_value[rows] = lv
+            tree.node_values[rows, p] = (tree.node_values[rows, p] * cnt + lv) / (cnt + F32(1.0))
+            tree.node_visits[rows, p] = cnt + 1
+            tree.children_values[rows, p, a] = tree.node_values[rows, i]
+            tree.children_visits[rows, p, a] += 1
+            idx[rows] = p
+    return depth_sum
+
+
+def gumbel_finish(tree, root_gumbel, qtransform="mix"):
+    qt = qtransform_completed_by_mix_value if qtransform == "mix" else qtransform_by_parent_and_siblings
+    B = tree.B
+    br = np.arange(B)
+    root = np.zeros(B, np.int32)
+    vc = tree.children_visits[:, 0]
+    qv = qt(tree, br, root)
+    logits = tree.children_prior_logits[:, 0]
+    score = _score_considered(vc.max(-1), root_gumbel, logits, qv, vc)
+    inv = tree.root_invalid_actions.astype(bool)
+    action = np.where(inv, -np.inf, score).argmax(-1).astype(np.int32)
+    x = logits + qv
+    masked = np.where(inv, FMIN, x - x.max(-1, keepdims=True))
+    x = np.where(inv.any(-1, keepdims=True), masked, x)
+    return action, softmax(x)

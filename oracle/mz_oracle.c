@@ -474,6 +474,182 @@ void mzo_summary_sample(const mzo_tree *t, int b, float temperature, const float
   *action_out = best;
 }
 
+/* ===================================================================== */
+/* Gumbel MuZero (mctx gumbel_muzero_policy)                              */
+/* ===================================================================== */
+
+/* mctx qtransforms: per-child transformed Q of `node`. */
+void mzo_qtransform(const mzo_tree *t, int b, int node, int qtransform, float *out) {
+  int A = t->A;
+  int64_t n = (int64_t)b * t->N + node;
+  const int32_t *vc = t->children_visits + n * A;
+  float q[256];
+  for (int a = 0; a < A; ++a)
+    q[a] = t->children_rewards[n * A + a] + t->children_discounts[n * A + a] * t->children_values[n * A + a];
+  if (qtransform == 0) {
+    /* qtransform_by_parent_and_siblings */
+    float nval = t->node_values[n];
+    float lo = nval, hi = nval;
+    for (int a = 0; a < A; ++a) {
+      float safe = vc[a] > 0 ? q[a] : nval;
+      lo = safe < lo ? safe : lo;
+      hi = safe > hi ? safe : hi;
+    }
+    float span = hi - lo;
+    span = span > 1e-8f ? span : 1e-8f;
+    for (int a = 0; a < A; ++a) out[a] = ((vc[a] > 0 ? q[a] : lo) - lo) / span;
+    return;
+  }
+  /* qtransform_completed_by_mix_value(value_scale=0.1, maxvisit_init=50, rescale_values, use_mixed_value) */
+  float prior[256], tmp[256];
+  mzo_softmax(t->children_prior_logits + n * A, A, prior);
+  int32_t sum_visits = 0, maxvisit = 0;
+  for (int a = 0; a < A; ++a) {
+    sum_visits += vc[a];
+    maxvisit = vc[a] > maxvisit ? vc[a] : maxvisit;
+    prior[a] = prior[a] > FLT_TINY ? prior[a] : FLT_TINY;
+  }
+  for (int a = 0; a < A; ++a) tmp[a] = vc[a] > 0 ? prior[a] : 0.0f;
+  float sum_probs = mzo_sum16(tmp, A);
+  for (int a = 0; a < A; ++a)
+    tmp[a] = vc[a] > 0 ? (prior[a] * q[a]) / (vc[a] > 0 ? sum_probs : 1.0f) : 0.0f;
+  float weighted_q = mzo_sum16(tmp, A);
+  float value = (t->raw_values[n] + (float)sum_visits * weighted_q) / (float)(sum_visits + 1);
+  float lo = 0.0f, hi = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    out[a] = vc[a] > 0 ? q[a] : value;
+    if (a == 0 || out[a] < lo) lo = out[a];
+    if (a == 0 || out[a] > hi) hi = out[a];
+  }
+  float span = hi - lo;
+  span = span > 1e-8f ? span : 1e-8f;
+  float scale = (50.0f + (float)maxvisit) * 0.1f;
+  for (int a = 0; a < A; ++a) out[a] = scale * ((out[a] - lo) / span);
+}
+
+/* mctx seq_halving.get_sequence_of_considered_visits */
+void mzo_considered_visits(int m, int num_simulations, int32_t *seq) {
+  if (m <= 1) {
+    for (int i = 0; i < num_simulations; ++i) seq[i] = i;
+    return;
+  }
+  int log2max = 0;
+  while ((1 << log2max) < m) ++log2max;
+  int32_t visits[256];
+  for (int i = 0; i < m; ++i) visits[i] = 0;
+  int n = 0, num_considered = m;
+  while (n < num_simulations) {
+    int extra = num_simulations / (log2max * num_considered);
+    if (extra < 1) extra = 1;
+    for (int e = 0; e < extra; ++e) {
+      for (int i = 0; i < num_considered && n < num_simulations; ++i) seq[n++] = visits[i];
+      for (int i = 0; i < num_considered; ++i) visits[i] += 1;
+    }
+    num_considered = num_considered / 2 > 2 ? num_considered / 2 : 2;
+  }
+}
+
+/* seq_halving.score_considered + masked_argmax */
+static int gumbel_argmax(int A, int considered_visit, const float *gumbel, const float *logits,
+                         const float *qv, const int32_t *vc, const uint8_t *invalid) {
+  float mx = logits[0];
+  for (int a = 1; a < A; ++a) mx = logits[a] > mx ? logits[a] : mx;
+  int best = 0;
+  float bs = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    float s = (gumbel[a] + (logits[a] - mx)) + qv[a];
+    s = s > -1e9f ? s : -1e9f;
+    s = s + (vc[a] == considered_visit ? 0.0f : -INFINITY);
+    if (invalid && invalid[a]) s = -INFINITY;
+    if (a == 0 || s > bs) { best = a; bs = s; }
+  }
+  return best;
+}
+
+int mzo_gumbel_select_action(const mzo_tree *t, int b, int node, int depth, int qtransform,
+                             const float *root_gumbel, int num_simulations,
+                             int max_num_considered_actions) {
+  int A = t->A;
+  int64_t n = (int64_t)b * t->N + node;
+  const int32_t *vc = t->children_visits + n * A;
+  float qv[256];
+  mzo_qtransform(t, b, node, qtransform, qv);
+  if (depth == 0) {
+    /* gumbel_muzero_root_action_selection */
+    const uint8_t *inv = t->root_invalid_actions + (int64_t)b * A;
+    int num_valid = 0, sim_index = 0;
+    for (int a = 0; a < A; ++a) { num_valid += inv[a] ? 0 : 1; sim_index += vc[a]; }
+    int num_considered = max_num_considered_actions < num_valid ? max_num_considered_actions : num_valid;
+    int32_t *seq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(num_simulations > 0 ? num_simulations : 1));
+    mzo_considered_visits(num_considered, num_simulations, seq);
+    int considered_visit = seq[sim_index < num_simulations ? sim_index : num_simulations - 1];
+    free(seq);
+    return gumbel_argmax(A, considered_visit, root_gumbel + (int64_t)b * A,
+                         t->children_prior_logits + n * A, qv, vc, inv);
+  }
+  /* gumbel_muzero_interior_action_selection: argmax(softmax(logits + q) - visits / (1 + sum visits)) */
+  float x[256], p[256];
+  int32_t sum = 0;
+  for (int a = 0; a < A; ++a) { x[a] = t->children_prior_logits[n * A + a] + qv[a]; sum += vc[a]; }
+  mzo_softmax(x, A, p);
+  int best = 0;
+  float bs = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    float s = p[a] - (float)vc[a] / (float)(1 + sum);
+    if (a == 0 || s > bs) { best = a; bs = s; }
+  }
+  return best;
+}
+
+void mzo_gumbel_step_select(const mzo_tree *t, const mzo_search_cfg *cfg, int qtransform,
+                            const float *root_gumbel, int max_num_considered_actions,
+                            int32_t *parent_out, int32_t *action_out, int32_t *depth_out) {
+  int A = t->A;
+  int max_depth = cfg->max_depth > 0 ? cfg->max_depth : cfg->num_simulations;
+  for (int b = 0; b < t->B; ++b) {
+    int node = 0, depth = 0, action = 0, parent = 0;
+    for (;;) {
+      action = mzo_gumbel_select_action(t, b, node, depth, qtransform, root_gumbel,
+                                        cfg->num_simulations, max_num_considered_actions);
+      parent = node;
+      int next = t->children_index[((int64_t)b * t->N + node) * A + action];
+      depth += 1;
+      if (next == MZO_UNVISITED || depth >= max_depth) break;
+      node = next;
+    }
+    parent_out[b] = parent;
+    action_out[b] = action;
+    if (depth_out) depth_out[b] = depth;
+  }
+}
+
+/* tail of mctx gumbel_muzero_policy: best considered action, completed-Q policy target */
+void mzo_gumbel_finish(const mzo_tree *t, int b, int qtransform, const float *root_gumbel,
+                       const float *root_logits, int32_t *action_out, float *action_weights_out) {
+  int A = t->A;
+  const int32_t *vc = t->children_visits + (int64_t)b * t->N * A;
+  const uint8_t *inv = t->root_invalid_actions + (int64_t)b * A;
+  (void)root_logits;
+  const float *logits = t->children_prior_logits + (int64_t)b * t->N * A;
+  int considered_visit = 0, any_invalid = 0;
+  for (int a = 0; a < A; ++a) {
+    considered_visit = vc[a] > considered_visit ? vc[a] : considered_visit;
+    any_invalid |= inv[a];
+  }
+  float qv[256], x[256];
+  mzo_qtransform(t, b, 0, qtransform, qv);
+  *action_out = gumbel_argmax(A, considered_visit, root_gumbel + (int64_t)b * A, logits, qv, vc, inv);
+  /* completed_search_logits = _mask_invalid_actions(prior_logits + completed_qvalues, invalid_actions) */
+  float mx = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    x[a] = logits[a] + qv[a];
+    if (a == 0 || x[a] > mx) mx = x[a];
+  }
+  if (any_invalid)
+    for (int a = 0; a < A; ++a) x[a] = inv[a] ? FLT_LOWEST : x[a] - mx;
+  mzo_softmax(x, A, action_weights_out);
+}
+
 /* ---- stepwise driver ---- */
 
 void mzo_step_select(const mzo_tree *t, const mzo_search_cfg *cfg, int sim,

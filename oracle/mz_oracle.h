@@ -118,6 +118,22 @@ void mzo_backward(mzo_tree *t, int b, int leaf);
 void mzo_summary_sample(const mzo_tree *t, int b, float temperature, const float *gumbel,
                         int32_t *action_out, float *action_weights_out);
 
+/* ---- Gumbel MuZero (muax/policy.py:33-47 -> mctx.gumbel_muzero_policy, restated from mctx 0.0.5:
+ * policies.gumbel_muzero_policy, action_selection.gumbel_muzero_{root,interior}_action_selection,
+ * seq_halving.{score_considered,get_sequence_of_considered_visits}, qtransforms.
+ * qtransform_completed_by_mix_value).  qtransform: 0 = by_parent_and_siblings (what muax/model.py:230-231
+ * forces onto every policy), 1 = completed_by_mix_value (mctx's own default for this policy). ---- */
+void mzo_qtransform(const mzo_tree *t, int b, int node, int qtransform, float *out);
+void mzo_considered_visits(int max_num_considered_actions, int num_simulations, int32_t *seq);
+int mzo_gumbel_select_action(const mzo_tree *t, int b, int node, int depth, int qtransform,
+                             const float *root_gumbel, int num_simulations,
+                             int max_num_considered_actions);
+void mzo_gumbel_step_select(const mzo_tree *t, const mzo_search_cfg *cfg, int qtransform,
+                            const float *root_gumbel, int max_num_considered_actions,
+                            int32_t *parent_out, int32_t *action_out, int32_t *depth_out);
+void mzo_gumbel_finish(const mzo_tree *t, int b, int qtransform, const float *root_gumbel,
+                       const float *root_logits, int32_t *action_out, float *action_weights_out);
+
 /* ---- stepwise driver (any recurrent_fn supplied by the caller) ---- */
 void mzo_step_select(const mzo_tree *t, const mzo_search_cfg *cfg, int sim,
                      const uint32_t sim_key[2], int32_t *parent_out,

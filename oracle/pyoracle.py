@@ -104,7 +104,8 @@ def lib():
                      "mzo_root_inference", "mzo_recurrent_inference", "mzo_root_prior",
                      "mzo_tree_init", "mzo_simulate", "mzo_expand", "mzo_backward",
                      "mzo_summary_sample", "mzo_step_select", "mzo_step_expand_backup",
-                     "mzo_act_mlp"):
+                     "mzo_act_mlp", "mzo_qtransform", "mzo_considered_visits", "mzo_gumbel_step_select",
+                     "mzo_gumbel_finish"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -434,3 +435,59 @@ def act_mlp(mlp: Mlp, cfg: SearchCfg, obs, key, dirichlet_noise=None, dirichlet_
                       _p(depth_sum, _i64p), C.c_int(nthreads))
     return {"action": action, "action_weights": weights, "root_value": root_value,
             "depth_sum": depth_sum, "tree": tree}
+
+
+# --------------------------------------------------------------------------
+# Gumbel MuZero
+# --------------------------------------------------------------------------
+
+def considered_visits(m, num_simulations):
+    seq = np.zeros(max(num_simulations, 1), np.int32)
+    lib().mzo_considered_visits(C.c_int(m), C.c_int(num_simulations), _p(seq, _i32p))
+    return seq[:num_simulations]
+
+
+def qtransform(tree: Tree, node, kind):
+    """kind 0: by_parent_and_siblings, 1: completed_by_mix_value; node [B] -> [B,A]."""
+    out = np.zeros((tree.B, tree.A), np.float32)
+    t = tree.c()
+    for b in range(tree.B):
+        lib().mzo_qtransform(C.byref(t), C.c_int(b), C.c_int(int(node[b])), C.c_int(kind), _p(out[b], _f32p))
+    return out
+
+
+def mask_root_logits(prior_logits, invalid=None):
+    """mctx _mask_invalid_actions (the only root preprocessing of gumbel_muzero_policy)."""
+    pl = np.array(prior_logits, np.float32, copy=True)
+    if invalid is not None and np.asarray(invalid).any():
+        inv = np.asarray(invalid).astype(bool)
+        any_inv = inv.any(axis=1, keepdims=True)
+        shifted = np.where(inv, np.finfo(np.float32).min, pl - pl.max(axis=1, keepdims=True)).astype(np.float32)
+        pl = np.where(any_inv, shifted, pl)
+    return pl
+
+
+def gumbel_step_select(tree: Tree, cfg: SearchCfg, root_gumbel, qtransform_kind=1, max_considered=16):
+    B = tree.B
+    parent = np.zeros(B, np.int32)
+    action = np.zeros(B, np.int32)
+    depth = np.zeros(B, np.int32)
+    g = np.ascontiguousarray(root_gumbel, np.float32)
+    t, c = tree.c(), cfg.c(B)
+    lib().mzo_gumbel_step_select(C.byref(t), C.byref(c), C.c_int(qtransform_kind), _p(g, _f32p),
+                                 C.c_int(max_considered), _p(parent, _i32p), _p(action, _i32p), _p(depth, _i32p))
+    return parent, action, depth
+
+
+def gumbel_finish(tree: Tree, root_gumbel, qtransform_kind=1):
+    B, A = tree.B, tree.A
+    g = np.ascontiguousarray(root_gumbel, np.float32)
+    action = np.zeros(B, np.int32)
+    weights = np.zeros((B, A), np.float32)
+    t = tree.c()
+    for b in range(B):
+        ab = C.c_int32()
+        lib().mzo_gumbel_finish(C.byref(t), C.c_int(b), C.c_int(qtransform_kind), _p(g, _f32p), None,
+                                C.byref(ab), _p(weights[b], _f32p))
+        action[b] = ab.value
+    return action, weights

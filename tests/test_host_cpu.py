@@ -124,8 +124,9 @@ def test_model_constructor_shapes_and_errors():
     assert m1.network == m2.network
     with pytest.raises(ValueError):
         mx.MuZero(net.representation_fn, device="cpu")
+    assert isinstance(mx.MuZero(net, policy="gumbel", device="cpu")._policy, mx.GumbelMuZeroPolicy)
     with pytest.raises(NotImplementedError):
-        mx.MuZero(net, policy="gumbel", device="cpu")
+        mx.MuZero(net, policy="stochastic", device="cpu")
     with pytest.raises(TypeError):
         mx.MuZero(net, policy_class=dict, device="cpu")
     with pytest.raises(ValueError):

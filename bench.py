@@ -132,12 +132,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    # test-only overrides (dry run of the N>1 code path on a 1-GPU box): every rank on device 0, gloo
+    if os.environ.get("MUAX_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("MUAX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from muax_amd import MuZeroSearch, SearchConfig
     B, obs_dim, E, A, support, S = WORKLOADS[args.workload]
@@ -177,7 +181,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))

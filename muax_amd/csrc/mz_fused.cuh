@@ -276,7 +276,7 @@ struct Nets {
   }
   // ---- the per-simulation pass: Dynamic (muax/nn.py:93-115) on (s, action), Prediction
   // (muax/nn.py:73-90) on the child (or parent) embedding, both support decodes.  Same arithmetic
-  // as predict()/dynamics() below, organised for the machine: the two hidden layers that share an
+  // as predict() above (and a plain layer-by-layer Dynamic), organised for the machine: the two hidden layers that share an
   // input run as ONE packed chain ((reward-net, state-net), (value-net, policy-net)), 2-slot logits
   // are packed, and the reward and value decodes advance together as (reward, value) pairs. ----
   MZ_DEV void forward(const float (&s)[C::ES], int action, int j, int support, bool pred_on_parent,
@@ -356,19 +356,6 @@ struct Nets {
     f32x2 dec = inv_scaling2(xs);
     reward = dec.x;
     value = dec.y;
-  }
-
-  // Dynamic (muax/nn.py:93-115) + reward decode
-  MZ_DEV void dynamics(const float (&s)[C::ES], int action, int j, int support, float& reward,
-                       float (&ns)[C::ES]) const {
-    float h[1], r_logits[C::FS];
-    h[0] = elu(dr1.apply(s, action));
-    dr2.apply(h, r_logits);
-    float g[1];
-    g[0] = elu(dn1.apply(s, action));
-    dn2.apply(g, ns);
-    row_min_max_normalize<C::E>(ns, j);
-    reward = row_decode<C::F>(r_logits, j, support);
   }
 };
 
@@ -649,8 +636,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float reward, value, pil, pprob;
     float ns[C::ES];
     nets.forward(sp, action, j, support, p.pred_on_parent != 0, reward, value, pil, pprob, ns);
-    MZ_TICK(2);  // dynamics + prediction (+ parent embedding gather)
-    MZ_TICK(3);
+    MZ_TICK(2);  // network pass (+ parent embedding gather)
     {
       const int vis = vis_old + 1;
       if (j < A) nn[C::ST0 + C::STW * j + 0] = pprob;
@@ -686,7 +672,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       }
     }
 
-    MZ_TICK(4);  // prior softmax + expand stores
+    MZ_TICK(4);  // expand stores
     // -- backward (mctx search.backward) + decision refresh, lane e <-> path entry e --
     // entries 0..depth-1 are the (parent, action) edges of the path, entry `depth` is the leaf.
     {

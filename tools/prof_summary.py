@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 (rocpd sqlite) output of scripts_prof.sh into a small text report."""
+"""Summarise rocprofv3 (rocpd sqlite) output of tools/rocprof_passes.sh into a small text report."""
 import glob
 import os
 import sqlite3

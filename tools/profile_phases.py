@@ -11,8 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "bin", "libmzsearch_prof.so")
-PHASES = ["loop top", "select", "dynamics", "prediction", "prior softmax + expand", "backward + scores",
-          "noise commit", "-"]
+PHASES = ["loop top", "select (jump words)", "network pass", "-", "expand stores", "backward + refresh",
+          "-", "-"]
 
 
 def build():
@@ -51,7 +51,9 @@ def run():
     print(f"waves {waves}; cycles per wave: mean {tot.mean():.0f} max {tot.max():.0f} min {tot.min():.0f}")
     depth = s.depth_sum.cpu().numpy().reshape(waves, 4)
     print(f"mean selection depth {depth.mean() / S:.2f}; per-wave sum of max-of-4 is not tracked here")
-    for k, name in enumerate(PHASES[:7]):
+    for k, name in enumerate(PHASES[:6]):
+        if name == "-":
+            continue
         print(f"  {name:26s} {p[:, k].mean() / S:9.0f} cycles/sim  ({100 * p[:, k].sum() / tot.sum():5.1f}%)   "
               f"slowest wave {p[:, k].max() / S:9.0f}")
     slow = int(tot.argmax())

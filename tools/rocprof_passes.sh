@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_prof.sh <tag> [extra bench args]   (run on the GPU box through gpurun)
+# usage: tools/rocprof_passes.sh <tag> [extra bench args]   (run on the GPU box through gpurun)
 TAG=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

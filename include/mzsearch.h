@@ -50,7 +50,7 @@ typedef struct {
   int32_t max_depth;       /* <= 0: num_simulations (mctx default) */
   int32_t qtransform;      /* 0: qtransform_by_parent_and_siblings; 1: qtransform_completed_by_mix_value (gumbel policy only) */
   int32_t tiebreak;        /* 0: none; 1: JAX threefry stream (1e-7 * uniform); muzero policy only */
-  int32_t policy;          /* 0: mctx.muzero_policy (muax/policy.py:13-30); 1: mctx.gumbel_muzero_policy (muax/policy.py:33-47), step-wise path */
+  int32_t policy;          /* 0: mctx.muzero_policy (muax/policy.py:13-30); 1: mctx.gumbel_muzero_policy (muax/policy.py:33-47) */
   float pb_c_init;         /* 1.25  */
   float pb_c_base;         /* 19652 */
   int64_t global_batch;    /* B of the un-sharded batch (PRNG stream layout); 0 -> batch */
@@ -99,7 +99,8 @@ typedef struct {
   const float *obs;               /* [B,obs_dim] */
   const float *dirichlet_noise;   /* [B,A] or NULL (then dirichlet_fraction must be 0) */
   const uint8_t *invalid_actions; /* [B,A] 1 = invalid, or NULL */
-  const float *gumbel;            /* [B,A] or NULL: drawn from `key` as jax.random.categorical */
+  const float *gumbel;            /* [B,A] or NULL: drawn from `key` (muzero policy: the categorical's Gumbel;
+                                     gumbel policy: the ROOT Gumbel noise, gumbel_scale * gumbel(split(key)[1])) */
   uint32_t key[2];                /* the rng_key given to MuZero.act (HOST values) */
   float dirichlet_fraction;       /* 0.25 */
   float temperature;              /* 1.0  */

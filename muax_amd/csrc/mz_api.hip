@@ -58,6 +58,7 @@ struct mzs_handle {
   uint32_t k_sample[2] = {0, 0};
   uint32_t sim_keys[mz::kMaxSims][2];
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
+  int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
 };
 
 namespace {
@@ -129,9 +130,14 @@ int launch_fused(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
 }
 
 template <int A, int E, int F, int NMAX, int WAVES>
-int dispatch_tb(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
-  if (h->cfg.tiebreak) return launch_fused<mz::FusedCfg<A, E, F, NMAX, true, WAVES>>(h, p, stream);
-  return launch_fused<mz::FusedCfg<A, E, F, NMAX, false, WAVES>>(h, p, stream);
+int dispatch_mode(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
+  const mzs_config& c = h->cfg;
+  if (c.policy == 1) {
+    if (c.qtransform == 1) return launch_fused<mz::FusedCfg<A, E, F, NMAX, 3, WAVES>>(h, p, stream);
+    return launch_fused<mz::FusedCfg<A, E, F, NMAX, 2, WAVES>>(h, p, stream);
+  }
+  if (c.tiebreak) return launch_fused<mz::FusedCfg<A, E, F, NMAX, 1, WAVES>>(h, p, stream);
+  return launch_fused<mz::FusedCfg<A, E, F, NMAX, 0, WAVES>>(h, p, stream);
 }
 
 }  // namespace
@@ -180,6 +186,7 @@ int mzs_destroy(mzs_handle* h) {
   if (!h) return MZS_OK;
   hipSetDevice(h->cfg.device);
   h->step.release();
+  if (h->fused_table) hipFree(h->fused_table);
   delete h;
   return MZS_OK;
 }
@@ -204,11 +211,10 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   if (!h->have_weights) return fail(h, MZS_E_INVALID, "mzs_act_mlp: call mzs_mlp_set_weights first");
   if (!a->obs || !a->action || !a->action_weights || !a->root_value)
     return fail(h, MZS_E_INVALID, "mzs_act_mlp: obs/action/action_weights/root_value must be set");
-  if (!a->dirichlet_noise && a->dirichlet_fraction != 0.0f)
-    return fail(h, MZS_E_INVALID, "mzs_act_mlp: dirichlet_fraction != 0 needs dirichlet_noise");
   const mzs_config& c = h->cfg;
+  if (c.policy == 0 && !a->dirichlet_noise && a->dirichlet_fraction != 0.0f)
+    return fail(h, MZS_E_INVALID, "mzs_act_mlp: dirichlet_fraction != 0 needs dirichlet_noise");
   if (c.num_simulations > mz::kMaxSims) return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: num_simulations > 256 (use the step-wise path)");
-  if (c.policy != 0) return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: no fused kernel instance for the gumbel policy; use the step-wise path");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
 
@@ -242,13 +248,27 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.dirichlet_fraction = a->dirichlet_fraction; p.discount = w.discount; p.temperature = a->temperature;
   p.global_batch = (uint64_t)c.global_batch; p.root_offset = (uint64_t)c.root_offset;
   p.prof = h->prof;
+  if (c.policy == 1) {
+    // gumbel policy: seq_halving table on the device (once), root Gumbel key = split(key)[1]
+    const int rows = c.max_num_considered_actions + 1;
+    if (!h->fused_table) {
+      std::vector<int32_t> table((size_t)rows * c.num_simulations);
+      for (int m = 0; m < rows; ++m) considered_visits(m, c.num_simulations, table.data() + (size_t)m * c.num_simulations);
+      MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_table), table.size() * sizeof(int32_t)));
+      MZS_HIP(h, hipMemcpy(h->fused_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    p.visit_table = h->fused_table;
+    p.max_considered = c.max_num_considered_actions;
+    p.gumbel_scale = c.gumbel_scale;
+    h_split(a->key, 2, 1, p.k_gumbel);
+  }
   derive_keys(h, a->key);
   p.k_sample[0] = h->k_sample[0]; p.k_sample[1] = h->k_sample[1];
   memcpy(p.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)c.num_simulations);
 
   const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, N = c.num_simulations + 1;
 #define MZS_INST(A_, E_, F_, NMAX_, WAVES_) \
-  if (A == A_ && E == E_ && F == F_ && N <= NMAX_) return dispatch_tb<A_, E_, F_, NMAX_, WAVES_>(h, p, stream);
+  if (A == A_ && E == E_ && F == F_ && N <= NMAX_) return dispatch_mode<A_, E_, F_, NMAX_, WAVES_>(h, p, stream);
   MZS_INST(2, 8, 21, 51, 4)    // CartPole   (BASELINE cfg1/cfg2; README.md:102-132)
   MZS_INST(4, 32, 21, 51, 2)   // LunarLander (BASELINE cfg3)
   MZS_INST(3, 8, 21, 33, 4)    // odd action count (tests)

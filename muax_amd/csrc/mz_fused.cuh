@@ -82,21 +82,30 @@ struct FusedParams {
   float pb_c_init, pb_c_base, dirichlet_fraction, discount, temperature;
   uint64_t global_batch, root_offset;
   uint32_t k_sample[2];
+  // gumbel policy (MODE >= 2): root Gumbel noise comes from `gumbel` or from k_gumbel
+  const int32_t* visit_table;      // [(max_considered + 1), S] seq_halving table
+  int32_t max_considered;
+  float gumbel_scale;
+  uint32_t k_gumbel[2];
   uint32_t sim_keys[kMaxSims][2];  // simulate_key of every simulation (mctx search body_fun)
   uint64_t* prof;  // MZ_PROFILE builds only: [waves][8] cycle counters
 };
 
-template <int A_, int E_, int F_, int NMAX_, bool TB_, int WAVES_ = 4>
+// MODE: 0 muzero policy without tie-break noise, 1 muzero policy with mctx's tie-break noise,
+//       2 gumbel policy + qtransform_by_parent_and_siblings, 3 gumbel policy + completed_by_mix_value
+template <int A_, int E_, int F_, int NMAX_, int MODE_, int WAVES_ = 4>
 struct FusedCfg {
   static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_;
-  static constexpr int A = A_, E = E_, F = F_, NMAX = NMAX_;
-  static constexpr bool TB = TB_;
+  static constexpr int A = A_, E = E_, F = F_, NMAX = NMAX_, MODE = MODE_;
+  static constexpr bool TB = MODE_ == 1;
+  static constexpr bool GUMBEL = MODE_ >= 2;
+  static constexpr int QT = MODE_ == 3 ? 1 : 0;
   static constexpr int H = kHidden;
   static constexpr int ES = (E + 15) / 16, FS = (F + 15) / 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
   //   [SEL0  ..) A x {child index, cached pUCT score}
-  //   [HDR0  ..) visits, value, JUMP word, pad
-  //   [ST0   ..) A x {prob, value, visits, reward, discount, pad}
+  //   [HDR0  ..) visits, value, JUMP word, raw value
+  //   [ST0   ..) A x {prob, value, visits, reward, discount, prior logit}
   //   [EMB0  ..) embedding
   //   [PATH0 ..) this node's own root path, one packed (node, action) entry per level
   // JUMP word: end point of the greedy descent below this node:
@@ -114,6 +123,7 @@ struct FusedCfg {
   static constexpr int PATH_WORDS = 0;
   static constexpr int NOISE_WORDS = 0;
   static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
+  static_assert(A <= PATHW, "the root's (empty) path slot holds its Gumbel noise");
   static_assert(PATHW <= 16, "a node's path is copied by one lane per word");
   static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
@@ -410,6 +420,107 @@ MZ_DEV int jump_word(int node, int action, int depth, bool near_tie) {
   return node | (action << 12) | (depth << 16) | (near_tie ? (int)0x80000000 : 0);
 }
 
+// ---- Gumbel MuZero decisions (mctx gumbel_muzero_{root,interior}_action_selection), all A children of
+// one node inside a lane.  Sums follow the canonical 16-wide butterfly on the zero-padded vector. ----
+template <int A>
+MZ_DEV float sum16_inlane(const float (&x)[A]) {
+  static_assert(A <= 8, "");
+  float p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = i < A ? x[i] : 0.0f;
+  float q0 = p[0] + p[1], q1 = p[2] + p[3], q2 = p[4] + p[5], q3 = p[6] + p[7];
+  float r0 = q0 + q1, r1 = q2 + q3;
+  return (r0 + r1) + 0.0f;  // last butterfly step adds the (all-zero) upper half row
+}
+template <int A>
+MZ_DEV void softmax_inlane(const float (&x)[A], float (&p)[A]) {
+  float m = x[0];
+#pragma unroll
+  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
+  float e[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) e[a] = exp_neg(x[a] - m);
+  const float s = sum16_inlane<A>(e);
+#pragma unroll
+  for (int a = 0; a < A; ++a) p[a] = e[a] / s;
+}
+// mctx qtransforms (QT 0: by_parent_and_siblings, 1: completed_by_mix_value)
+template <int A, int QT>
+MZ_DEV void qtransform_inlane(float nval, float raw, const float (&logit)[A], const float (&val)[A],
+                              const int (&vis)[A], const float (&rew)[A], const float (&dis)[A],
+                              float (&out)[A], int& sum_visits) {
+  float q[A];
+  sum_visits = 0;
+  int maxvisit = 0;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    q[a] = rew[a] + dis[a] * val[a];
+    sum_visits += vis[a];
+    maxvisit = max(maxvisit, vis[a]);
+  }
+  if constexpr (QT == 0) {
+    float lo = nval, hi = nval;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      float safe = vis[a] > 0 ? q[a] : nval;
+      lo = fminf(lo, safe);
+      hi = fmaxf(hi, safe);
+    }
+    const float span = fmaxf(hi - lo, 1e-8f);
+#pragma unroll
+    for (int a = 0; a < A; ++a) out[a] = ((vis[a] > 0 ? q[a] : lo) - lo) / span;
+  } else {
+    float prior[A], tmp[A];
+    softmax_inlane<A>(logit, prior);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      prior[a] = fmaxf(prior[a], kFltTiny);
+      tmp[a] = vis[a] > 0 ? prior[a] : 0.0f;
+    }
+    const float sum_probs = sum16_inlane<A>(tmp);
+#pragma unroll
+    for (int a = 0; a < A; ++a) tmp[a] = vis[a] > 0 ? (prior[a] * q[a]) / sum_probs : 0.0f;
+    const float weighted_q = sum16_inlane<A>(tmp);
+    const float value = (raw + (float)sum_visits * weighted_q) / (float)(sum_visits + 1);
+    float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      out[a] = vis[a] > 0 ? q[a] : value;
+      lo = fminf(lo, out[a]);
+      hi = fmaxf(hi, out[a]);
+    }
+    const float span = fmaxf(hi - lo, 1e-8f);
+    const float scale = (50.0f + (float)maxvisit) * 0.1f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) out[a] = scale * ((out[a] - lo) / span);
+  }
+}
+// root: seq_halving.score_considered + invalid mask; interior: softmax(logits + q) - visits / (1 + sum)
+template <int A, int QT>
+MZ_DEV void gumbel_scores(bool is_root, float nval, float raw, const float (&logit)[A], const float (&val)[A],
+                          const int (&vis)[A], const float (&rew)[A], const float (&dis)[A],
+                          const float (&gum)[A], int considered_visit, uint32_t inv_bits, float (&sc)[A]) {
+  float qv[A];
+  int sum_visits;
+  qtransform_inlane<A, QT>(nval, raw, logit, val, vis, rew, dis, qv, sum_visits);
+  float x[A], pr[A];
+  float mxl = logit[0];
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    x[a] = logit[a] + qv[a];
+    mxl = fmaxf(mxl, logit[a]);
+  }
+  softmax_inlane<A>(x, pr);
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    float r = fmaxf((gum[a] + (logit[a] - mxl)) + qv[a], -1e9f);
+    r = r + (vis[a] == considered_visit ? 0.0f : -INFINITY);
+    r = ((inv_bits >> a) & 1u) ? -INFINITY : r;
+    const float in = pr[a] - (float)vis[a] / (float)(1 + sum_visits);
+    sc[a] = is_root ? r : in;
+  }
+}
+
 template <class C>
 __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const FusedParams p) {
   constexpr int A = C::A, E = C::E, NS = C::NS;
@@ -483,25 +594,53 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #pragma unroll
     for (int a = 0; a < A; ++a) inv_bits |= p.invalid[(size_t)r * A + a] ? (1u << a) : 0u;
   }
+  int ncons = 0;  // gumbel policy: number of root actions sequential halving considers
   {
-    // mctx muzero_policy prelude: dirichlet mix, log, invalid-action mask
-    float x[1] = {pl0}, pr[1];
-    row_softmax<A>(x, j, pr);
-    float nz = (p.dirichlet_noise != nullptr && j < A) ? p.dirichlet_noise[(size_t)r * A + j] : 0.0f;
-    float keep = 1.0f - p.dirichlet_fraction;
-    float noisy = keep * pr[0] + p.dirichlet_fraction * nz;
-    float lg = log_pos(fmaxf(noisy, kFltTiny));
-    if (p.invalid != nullptr) {
-      float mx = row_max<4>(j < A ? lg : -INFINITY);
-      lg = ((inv_bits >> j) & 1u) ? kFltLowest : lg - mx;
+    float lg, pq[1];
+    if constexpr (!C::GUMBEL) {
+      // mctx muzero_policy prelude: dirichlet mix, log, invalid-action mask
+      float x[1] = {pl0}, pr[1];
+      row_softmax<A>(x, j, pr);
+      float nz = (p.dirichlet_noise != nullptr && j < A) ? p.dirichlet_noise[(size_t)r * A + j] : 0.0f;
+      float keep = 1.0f - p.dirichlet_fraction;
+      float noisy = keep * pr[0] + p.dirichlet_fraction * nz;
+      lg = log_pos(fmaxf(noisy, kFltTiny));
+      if (p.invalid != nullptr) {
+        float mx = row_max<4>(j < A ? lg : -INFINITY);
+        lg = ((inv_bits >> j) & 1u) ? kFltLowest : lg - mx;
+      }
+      float lx[1] = {lg};
+      row_softmax<A>(lx, j, pq);
+    } else {
+      // mctx gumbel_muzero_policy prelude: invalid-action mask only; root Gumbel noise
+      lg = pl0;
+      if (inv_bits != 0) {
+        float mx = row_max<4>(j < A ? lg : -INFINITY);
+        lg = ((inv_bits >> j) & 1u) ? kFltLowest : lg - mx;
+      }
+      pq[0] = 0.0f;
+      float g;
+      if (p.gumbel != nullptr) {
+        g = j < A ? p.gumbel[(size_t)r * A + j] : 0.0f;
+      } else {
+        uint32_t x0, x1;
+        bool second;
+        bits_block(p.global_batch * (uint64_t)A, rg * (uint64_t)A + (uint64_t)(j < A ? j : 0), x0, x1, second);
+        threefry2x32(p.k_gumbel[0], p.k_gumbel[1], x0, x1);
+        g = p.gumbel_scale * gumbel_from_bits(second ? x1 : x0);
+      }
+      if (j < A) {
+        tree[C::PATH0 + j] = g;  // the root's own path is empty: its slot keeps root_gumbel
+        tree[C::ST0 + C::STW * j + 5] = lg;
+      }
+      ncons = min(p.max_considered, A - __builtin_popcount(inv_bits));
     }
-    float lx[1] = {lg}, pq[1];
-    row_softmax<A>(lx, j, pq);
     if (j < A) tree[C::ST0 + C::STW * j + 0] = pq[0];
     if (ex && j < A) p.t_children_prior_logits[(size_t)r * N * A + j] = lg;
     if (j == 0) {
       itree[C::HDR0] = 1;
       tree[C::HDR0 + 1] = v0;
+      tree[C::HDR0 + 3] = v0;
       p.root_value[r] = v0;
       if (ex) p.t_raw_values[(size_t)r * N] = v0;
     }
@@ -516,9 +655,20 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       prob[a] = tree[C::ST0 + C::STW * a + 0];
       val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = 0.0f;
     }
-    puct_scores<A>(v0, tbl[1], prob, val, vis, rew, dis, sc);
     int cidx[A], best, child;
     bool safe;
+    if constexpr (!C::GUMBEL) {
+      puct_scores<A>(v0, tbl[1], prob, val, vis, rew, dis, sc);
+    } else {
+      float logit[A], gum[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        logit[a] = tree[C::ST0 + C::STW * a + 5];
+        gum[a] = tree[C::PATH0 + a];
+      }
+      gumbel_scores<A, C::QT>(true, v0, v0, logit, val, vis, rew, dis, gum, p.visit_table[(size_t)ncons * S],
+                              inv_bits, sc);
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       cidx[a] = -1;
@@ -541,6 +691,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   // ---- simulations (mctx search.search body_fun) ----
   for (int sim = 0; sim < S; ++sim) {
     MZ_TICK(0);
+    int cv_next = 0;  // gumbel: visits the root's considered actions must have at the NEXT simulation
+    if constexpr (C::GUMBEL) cv_next = p.visit_table[(size_t)ncons * S + (sim + 1 < S ? sim + 1 : S - 1)];
     // -- simulate (mctx search.simulate) through the JUMP words: one iteration per near tie --
     int parent, action, dP;
     {
@@ -639,13 +791,17 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     MZ_TICK(2);  // network pass (+ parent embedding gather)
     {
       const int vis = vis_old + 1;
-      if (j < A) nn[C::ST0 + C::STW * j + 0] = pprob;
+      if (j < A) {
+        nn[C::ST0 + C::STW * j + 0] = pprob;
+        if constexpr (C::GUMBEL) nn[C::ST0 + C::STW * j + 5] = pil;
+      }
 #pragma unroll
       for (int t = 0; t < C::ES; ++t)
         if (j + 16 * t < E) nn[C::EMB0 + j + 16 * t] = ns[t];
       if (j == 0) {
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
+        nn[C::HDR0 + 3] = value;  // raw_values[new] (mctx update_tree_node)
         itree[po + C::SEL0 + 2 * action] = newn;
         tree[po + C::ST0 + C::STW * action + 3] = reward;
         tree[po + C::ST0 + C::STW * action + 4] = p.discount;
@@ -760,10 +916,21 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         const int nvis = edge ? cnt + 1 : cnt;
         const float nval = edge ? newv : pv;
         float sc[A];
-        puct_scores<A>(nval, tbl[valid ? nvis : 0], prob, val, vis, rew, dis, sc);
+        if constexpr (!C::GUMBEL) {
+          puct_scores<A>(nval, tbl[valid ? nvis : 0], prob, val, vis, rew, dis, sc);
 #pragma unroll
-        for (int a = 0; a < A; ++a)  // root_invalid_actions: the root is only ever selected at depth 0
-          sc[a] = (pn == 0 && ((inv_bits >> a) & 1u)) ? -INFINITY : sc[a];
+          for (int a = 0; a < A; ++a)  // root_invalid_actions: the root is only ever selected at depth 0
+            sc[a] = (pn == 0 && ((inv_bits >> a) & 1u)) ? -INFINITY : sc[a];
+        } else {
+          float logit[A], gum[A];
+#pragma unroll
+          for (int a = 0; a < A; ++a) {
+            logit[a] = nd[C::ST0 + C::STW * a + 5];
+            gum[a] = tree[C::PATH0 + a];
+          }
+          gumbel_scores<A, C::QT>(pn == 0, nval, nd[C::HDR0 + 3], logit, val, vis, rew, dis, gum, cv_next,
+                                  pn == 0 ? inv_bits : 0u, sc);
+        }
         int best, child;
         bool safe;
         decide<A, C::TB>(sc, cidx, best, child, safe);
@@ -815,6 +982,50 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   }
 #endif
 
+  if constexpr (C::GUMBEL) {
+    // ---- tail of mctx gumbel_muzero_policy: best action among the most visited, completed-Q target ----
+    float logit[A], val[A], rew[A], dis[A], gum[A], qv[A], sc[A], x[A], w[A];
+    int vis[A], sumv, cv = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      val[a] = tree[C::ST0 + C::STW * a + 1];
+      vis[a] = itree[C::ST0 + C::STW * a + 2];
+      rew[a] = tree[C::ST0 + C::STW * a + 3];
+      dis[a] = tree[C::ST0 + C::STW * a + 4];
+      logit[a] = tree[C::ST0 + C::STW * a + 5];
+      gum[a] = tree[C::PATH0 + a];
+      cv = max(cv, vis[a]);
+    }
+    const float nval = tree[C::HDR0 + 1], raw = tree[C::HDR0 + 3];
+    gumbel_scores<A, C::QT>(true, nval, raw, logit, val, vis, rew, dis, gum, cv, inv_bits, sc);
+    qtransform_inlane<A, C::QT>(nval, raw, logit, val, vis, rew, dis, qv, sumv);
+    int best = 0;
+    float bs = sc[0], mx = logit[0] + qv[0];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      x[a] = logit[a] + qv[a];
+      mx = fmaxf(mx, x[a]);
+      bool take = a > 0 && sc[a] > bs;  // first max wins
+      bs = take ? sc[a] : bs;
+      best = take ? a : best;
+    }
+    if (inv_bits != 0) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) x[a] = ((inv_bits >> a) & 1u) ? kFltLowest : x[a] - mx;
+    }
+    softmax_inlane<A>(x, w);
+    if (j < A) {
+      float mine = w[0];
+#pragma unroll
+      for (int a = 1; a < A; ++a) mine = (j == a) ? w[a] : mine;
+      p.action_weights[(size_t)r * A + j] = mine;
+    }
+    if (j == 0) {
+      p.action[r] = best;
+      if (p.search_value) p.search_value[r] = nval;
+      if (p.depth_sum) p.depth_sum[r] = depth_total;
+    }
+  } else {
   // ---- summary + sample (mctx Tree.summary, _apply_temperature, categorical) ----
   {
     const int ja = j < A ? j : A - 1;
@@ -847,6 +1058,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       if (p.search_value) p.search_value[r] = tree[C::HDR0 + 1];
       if (p.depth_sum) p.depth_sum[r] = depth_total;
     }
+  }
   }
 
   if (ex) {

@@ -148,12 +148,16 @@ class MuZero:
         return (r, discount, logits, v), next_embedding
 
     # ------------------------------------------------------------------ act
-    def _fused_handle(self, B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak):
-        key = (B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak)
+    def _fused_handle(self, B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak, policy="muzero",
+                      qtransform="qtransform_by_parent_and_siblings", max_considered=16, gumbel_scale=1.0):
+        key = (B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak, policy, qtransform, max_considered,
+               gumbel_scale)
         h = self._fused.get(key)
         if h is None or h[1] != self._weights_version:
             s = MuZeroSearch(B, SearchConfig(A, S, E, max_depth=max_depth, tiebreak=tiebreak,
-                                             pb_c_init=pb_c_init, pb_c_base=float(pb_c_base)), self.device)
+                                             pb_c_init=pb_c_init, pb_c_base=float(pb_c_base), policy=policy,
+                                             qtransform=qtransform, max_num_considered_actions=max_considered,
+                                             gumbel_scale=float(gumbel_scale)), self.device)
             w = {k: v.detach() for k, v in mz_nn.mlp_trio_weights(self.network).items()}
             s.set_mlp_weights(w, obs_dim, self._support_size, self._discount, self._recurrent_pred_on)
             h = (s, self._weights_version)
@@ -177,6 +181,17 @@ class MuZero:
         key = prng.as_key(rng_key)
         B = obs.shape[0]
         A = self.pred_func.num_actions if hasattr(self.pred_func, "num_actions") else None
+        fused_ok = mz_nn.is_default_mlp_trio(self.network) and obs.dim() == 2
+        if gumbel_policy and fused_ok and type(self._policy) is GumbelMuZeroPolicy:
+            try:
+                h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
+                                       1.25, 19652, False, "gumbel", qtransform, max_num_considered_actions,
+                                       gumbel_scale)
+                out = h.act_mlp(obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree)
+                return out, h.root_value
+            except ValueError as e:
+                if "no fused kernel instance" not in str(e):
+                    raise
         if gumbel_policy:
             root = self._root_inference(params, key, obs)
             out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
@@ -190,8 +205,7 @@ class MuZero:
                 with torch.no_grad():
                     A = self.pred_func(self.repr_func(obs[:1]))[1].shape[-1]
             dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (B, A), self.device)
-        fused = mz_nn.is_default_mlp_trio(self.network) and obs.dim() == 2 and isinstance(self._policy, MuZeroPolicy)
-        if fused:
+        if fused_ok and type(self._policy) is MuZeroPolicy:
             E = self.repr_func.embedding_dim
             try:
                 h = self._fused_handle(B, A, E, obs.shape[1], num_simulations, max_depth, pb_c_init, pb_c_base,

@@ -439,3 +439,52 @@ def test_gumbel_policy_through_model_act():
     m2.init(0, np.zeros((1, 6)))
     a3 = m2.act(11, obs, obs_from_batch=True, num_simulations=24)
     assert np.array_equal(a3, a)
+
+
+def _gumbel_oracle_act(oracle, case, key, kind, maxc, gumbel=None, max_depth=0):
+    """mctx.gumbel_muzero_policy around the oracle's MLP trio, composed from the oracle's pieces."""
+    B, A, E, S = case["B"], case["A"], case["E"], case["S"]
+    mlp = oracle.Mlp(case["w"], case["obs_dim"], E, A, case["F"])
+    pl, v, emb = oracle.root_inference(mlp, case["obs"])
+    g = gumbel if gumbel is not None else oracle.gumbel(oracle.split(key, 2)[1], B * A).reshape(B, A)
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S, max_depth=max_depth)
+    oracle.tree_init(tree, oracle.mask_root_logits(pl, case["invalid"]), v, emb, case["invalid"])
+    dsum = np.zeros(B, np.int64)
+    for sim in range(S):
+        p_, a_, d_ = oracle.gumbel_step_select(tree, cfg, g, kind, maxc)
+        dsum += d_
+        oracle.step_expand_backup(tree, sim, p_, a_, *oracle.recurrent_inference(mlp, a_, tree.embeddings[np.arange(B), p_]))
+    action, weights = oracle.gumbel_finish(tree, g, kind)
+    return {"action": action, "action_weights": weights, "root_value": v, "depth_sum": dsum, "tree": tree}
+
+
+@pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
+@pytest.mark.parametrize("A,E,S,B,maxc", [(2, 8, 50, 200, 16), (4, 8, 50, 90, 3), (4, 32, 40, 50, 16), (3, 8, 30, 40, 2)])
+def test_gumbel_fused_matches_oracle(oracle, A, E, S, B, maxc, qt):
+    """The whole Gumbel MuZero act() in the fused kernel (sequential halving at the root, cached
+    deterministic interior decisions through the JUMP words) against the oracle: bit-exact."""
+    from muax_amd import MuZeroSearch, SearchConfig
+    kind = 1 if qt.endswith("mix_value") else 0
+    case = make_case(oracle, 70 + A + E, B, 4 if E == 8 else 8, E, A, S, invalid_frac=0.3 if A > 2 else 0.0)
+    key = [21, 22]
+    s = MuZeroSearch(B, SearchConfig(A, S, E, policy="gumbel", qtransform=qt, max_num_considered_actions=maxc,
+                                     tiebreak=False))
+    s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"], 10, 0.99)
+    out = s.act_mlp(torch.from_numpy(case["obs"]), key,
+                    invalid_actions=None if case["invalid"] is None else torch.from_numpy(case["invalid"]),
+                    with_tree=True)
+    torch.cuda.synchronize()
+    _compare(_gumbel_oracle_act(oracle, case, key, kind, maxc), s, out)
+
+
+def test_gumbel_fused_injected_noise_and_max_depth(oracle):
+    from muax_amd import MuZeroSearch, SearchConfig
+    case = make_case(oracle, 91, 64, 4, 8, 2, 30)
+    g = np.random.default_rng(1).gumbel(size=(64, 2)).astype(F32)
+    s = MuZeroSearch(64, SearchConfig(2, 30, 8, policy="gumbel", qtransform="qtransform_completed_by_mix_value",
+                                      max_depth=4, tiebreak=False))
+    s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, 4, 10, 0.99)
+    out = s.act_mlp(torch.from_numpy(case["obs"]), 5, gumbel=torch.from_numpy(g), with_tree=True)
+    torch.cuda.synchronize()
+    _compare(_gumbel_oracle_act(oracle, case, [0, 5], 1, 16, gumbel=g, max_depth=4), s, out)

@@ -272,8 +272,27 @@ class MuZero:
 
     # ------------------------------------------------------------------ next tier
     def update(self, batch, *args, **kwargs):
-        """muax/model.py:181-201 (k-step unroll training step): next tier, SURVEY.md 8(f) n1."""
-        raise NotImplementedError("the training step is not built yet (SURVEY.md section 8(f), n1)")
+        """muax/model.py:181-201: one gradient step on a batch of k-step trajectories; returns
+        {'loss': float}.  INTERIM: torch autograd + torch.optim, with the
+        data-parallel gradient mean as ONE flat all-reduce when torch.distributed is initialised."""
+        from . import loss as mz_loss
+        from . import optimizers as mz_opt
+        from .sharding import allreduce_mean_flat
+        if self._params is None:
+            raise ValueError("call init() first")
+        params = [p for m in self.network if isinstance(m, torch.nn.Module) for p in m.parameters()]
+        if self._optimizer is None:
+            self._optimizer = mz_opt.create_optimizer()
+        if self._optimizer.opt is None:
+            self._opt_state = self._optimizer.init(params)
+        loss_fn = self.loss_fn or mz_loss.default_loss_fn
+        loss = loss_fn(self, batch, *args, **kwargs)
+        loss.backward()
+        allreduce_mean_flat([p.grad for p in params])
+        self._optimizer.step()
+        self._opt_state = self._optimizer.opt.state_dict()
+        self._weights_version += 1
+        return {"loss": float(loss.item())}
 
     def save_load(self, file, save=True):
         """muax/model.py:203-212, on torch state dicts (the reference pickles haiku params)."""

@@ -1,0 +1,64 @@
+"""Optimiser factories of the reference on torch.optim (muax/optimizers.py:5-87; README-era
+muax/frameworks/coax/model.py:23-71).  Host-side plumbing, not a kernel."""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional
+
+import torch
+
+
+class Optimizer:
+    """A deferred torch optimiser: bound to parameters at MuZero.init() (optax's init/update split)."""
+
+    def __init__(self, factory: Callable, lr_lambda: Optional[Callable] = None, clip_by_global_norm: float = 0.0):
+        self._factory, self._lr_lambda, self.clip = factory, lr_lambda, clip_by_global_norm
+        self.opt = self.sched = None
+
+    def init(self, params):
+        self.opt = self._factory(list(params))
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, self._lr_lambda) if self._lr_lambda else None
+        return self.opt.state_dict()
+
+    def step(self):
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_([p for g in self.opt.param_groups for p in g["params"]], self.clip)
+        self.opt.step()
+        if self.sched:
+            self.sched.step()
+        self.opt.zero_grad(set_to_none=True)
+
+
+def create_optimizer(optimizer_name: str = "adam", learning_rate: float = 1e-3, scheduler: Optional[str] = None,
+                     scheduler_params: Optional[Dict[str, Any]] = None,
+                     optimizer_params: Optional[Dict[str, Any]] = None) -> Optimizer:
+    """muax/optimizers.py:5-36 (adam / adamw / sgd / rmsprop / adagrad; exponential_decay schedule)."""
+    kw = dict(optimizer_params or {})
+    table = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "sgd": torch.optim.SGD,
+             "rmsprop": torch.optim.RMSprop, "adagrad": torch.optim.Adagrad}
+    if optimizer_name not in table:
+        raise ValueError(f"Unsupported optimizer: {optimizer_name}")
+    if optimizer_name == "adam":
+        kw.setdefault("eps", 1e-8)  # optax.adam default
+    lr_lambda = None
+    if scheduler == "exponential_decay":
+        sp = scheduler_params or {}
+        ts, dr = sp.get("transition_steps", 1), sp.get("decay_rate", 1.0)
+        lr_lambda = lambda step: dr ** (step / ts)  # noqa: E731
+    elif scheduler is not None:
+        raise ValueError(f"Unsupported scheduler: {scheduler}")
+    return Optimizer(lambda params: table[optimizer_name](params, lr=learning_rate, **kw), lr_lambda)
+
+
+def optimizer(init_value=0, peak_value=2e-2, end_value=1e-3, warmup_steps=1000, transition_steps=10000,
+              decay_rate=0.8, clip_by_global_norm=1.0) -> Optimizer:
+    """muax/frameworks/coax/model.py:23-71: clip by global norm -> adam -> warmup + exponential decay."""
+
+    def schedule(step):
+        if step < warmup_steps:
+            lr = init_value + (peak_value - init_value) * step / warmup_steps
+        else:
+            lr = peak_value * decay_rate ** ((step - warmup_steps) / transition_steps)
+            lr = max(lr, end_value) if decay_rate < 1 else min(lr, end_value)
+        return lr / peak_value
+
+    return Optimizer(lambda params: torch.optim.Adam(params, lr=peak_value, eps=1e-8), schedule, clip_by_global_norm)

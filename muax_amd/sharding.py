@@ -31,3 +31,22 @@ def gather_roots(local: torch.Tensor, global_batch: int, group=None) -> torch.Te
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def allreduce_mean_flat(tensors, group=None):
+    """Data-parallel gradient mean (the only collective of the whole project; reference precedent:
+    jax.lax.pmean in muax/frameworks/acme/jax/muzero/learning.py:151).  All tensors are packed into ONE
+    flat fp32 buffer -> one all-reduce (RCCL over xGMI on GPUs; a few KB to MB, latency-bound, so one
+    message instead of a ring of small ones) -> scaled by 1/world -> unpacked in place."""
+    import torch.distributed as dist
+    tensors = [t for t in tensors if t is not None]
+    if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].reshape(t.shape))
+        off += n

@@ -46,8 +46,15 @@ namespace mz {
     prof_acc[slot] += now_ - prof_t;                   \
     prof_t = now_;                                     \
   } while (0)
+// sub-phase tick: drains outstanding LDS/scalar traffic first so the time lands in the right slot
+#define MZ_TICKW(slot)                                 \
+  do {                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    MZ_TICK(slot);                                     \
+  } while (0)
 #else
 #define MZ_TICK(slot) do {} while (0)
+#define MZ_TICKW(slot) do {} while (0)
 #endif
 
 constexpr int kMaxSims = 256;
@@ -127,7 +134,7 @@ struct FusedCfg {
   static_assert(PATHW <= 16, "a node's path is copied by one lane per word");
   static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
-  static constexpr int TBL_WORDS = ((NMAX + 2 + 3) / 4) * 4;
+  static constexpr int TBL_WORDS = 2 * (((NMAX + 2 + 3) / 4) * 4);  // {sqrt(n) pb_c(n), 1/n} pairs
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
   static_assert(LDS_BYTES <= 160 * 1024, "tree does not fit the 160 KiB LDS of a CU: lower WAVES");
   static_assert(A <= 8, "selection keeps all A scores in registers");
@@ -372,10 +379,19 @@ struct Nets {
 // mctx muzero_action_selection (value_score + policy_score) for every child of
 // one node, with qtransform_by_parent_and_siblings; tie-break noise and the
 // root mask are applied at selection time.
+// x / d for a small positive integer d, given y = RN(1/d): q0 = RN(x y), r = x - q0 d (exact, fma),
+// q = RN(q0 + r y) is the correctly rounded quotient (Markstein); three dependent VALU ops instead of the
+// ~11 of the IEEE expansion.  tests/test_oracle_kat.py checks q == x / d for every mantissa and d <= 300.
+MZ_DEV float div_small(float x, float d, float y) {
+  const float q0 = x * y;
+  const float r = __builtin_fmaf(-q0, d, x);
+  return __builtin_fmaf(r, y, q0);
+}
+// rcp1[a] = RN(1 / (vis[a] + 1)) from the LDS table
 template <int A>
 MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const float (&val)[A],
                         const int (&vis)[A], const float (&rew)[A], const float (&dis)[A],
-                        float (&score)[A]) {
+                        const float (&rcp1)[A], float (&score)[A]) {
   float q[A];
   float lo = nval, hi = nval;
 #pragma unroll
@@ -389,7 +405,7 @@ MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const floa
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     float value_score = ((vis[a] > 0 ? q[a] : lo) - lo) / span;
-    float policy_score = (tn * prob[a]) / (float)(vis[a] + 1);
+    float policy_score = div_small(tn * prob[a], (float)(vis[a] + 1), rcp1[a]);
     score[a] = value_score + policy_score;
   }
 }
@@ -538,8 +554,15 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   const int r_raw = blockIdx.x * C::ROOTS_PER_WG + root_in_wg;
   const int r = r_raw < p.B ? r_raw : p.B - 1;
 
+#ifdef MZ_PROFILE
+  uint64_t prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
   float* tbl = lds;  // sqrt(n) * pb_c(n) by visit count
-  for (int i = tid; i < C::TBL_WORDS; i += C::THREADS) tbl[i] = puct_scale(i, p.pb_c_init, p.pb_c_base);
+  for (int i = tid; i < C::TBL_WORDS / 2; i += C::THREADS) {
+    tbl[2 * i] = puct_scale(i, p.pb_c_init, p.pb_c_base);
+    tbl[2 * i + 1] = i > 0 ? 1.0f / (float)i : 0.0f;  // correctly rounded reciprocal for div_small
+  }
   __syncthreads();  // the only barrier
 
   float* tree = lds + C::TBL_WORDS + root_in_wg * C::ROOT_WORDS;
@@ -555,10 +578,14 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   nets.load(p, j);
 
   // ---- tree init (mctx instantiate_tree_from_root) ----
-  for (int n = 0; n < N; ++n) {
-    for (int wq = j; wq < NS; wq += 16) {
-      bool is_index = wq < 2 * A && (wq & 1) == 0;
-      itree[n * NS + wq] = is_index ? -1 : 0;
+  // all-zero records written 16 bytes per lane, then children_index = -1 (same wave: LDS keeps the order)
+  {
+    int4* q4 = reinterpret_cast<int4*>(itree);
+    const int nq = N * (NS / 4);
+    for (int q = j; q < nq; q += 16) q4[q] = make_int4(0, 0, 0, 0);
+    for (int n = j; n < N; n += 16) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) itree[n * NS + C::SEL0 + 2 * a] = -1;
     }
   }
   if (ex) {
@@ -658,7 +685,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     int cidx[A], best, child;
     bool safe;
     if constexpr (!C::GUMBEL) {
-      puct_scores<A>(v0, tbl[1], prob, val, vis, rew, dis, sc);
+      float rcp1[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) rcp1[a] = 1.0f;  // no child visited yet
+      puct_scores<A>(v0, tbl[2], prob, val, vis, rew, dis, rcp1, sc);
     } else {
       float logit[A], gum[A];
 #pragma unroll
@@ -683,10 +713,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   }
 
   int depth_total = 0;
-#ifdef MZ_PROFILE
-  uint64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t prof_t = __builtin_amdgcn_s_memtime();
-#endif
+  MZ_TICKW(12);  // prologue: weights, tree init, root inference
 
   // ---- simulations (mctx search.search body_fun) ----
   for (int sim = 0; sim < S; ++sim) {
@@ -859,6 +886,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           pa = isleaf ? 0 : pa;
           pn = valid ? pn : 0;
         }
+        MZ_TICKW(6);  // path entry fetch + decode
         float* nd = tree + __umul24((unsigned)pn, (unsigned)NS);
         int* ndi = reinterpret_cast<int*>(nd);
         const int cnt = ndi[C::HDR0];
@@ -880,6 +908,17 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #pragma unroll
         for (int a = 0; a < A; ++a)
           jch[a] = itree[__umul24((unsigned)(cidx[a] < 0 ? 0 : cidx[a]), (unsigned)NS) + C::JUMP];
+        // visit counts after this backup and the table entries they select ({sqrt(n) pb_c(n), 1/n}
+        // pairs): fetched together with the JUMP words, behind the G chain
+        const int nvis = edge ? cnt + 1 : cnt;
+        const float2 tn_rc = *reinterpret_cast<const float2*>(tbl + 2 * (valid ? nvis : 0));
+        float rcp1[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          vis[a] = (edge && pa == a) ? vis[a] + 1 : vis[a];
+          rcp1[a] = tbl[2 * (vis[a] + 1) + 1];
+        }
+        MZ_TICKW(7);  // node + child JUMP loads
         float re = rew[0], ge = dis[0];
 #pragma unroll
         for (int a = 1; a < A; ++a) {
@@ -888,19 +927,26 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         }
         re = edge ? re : 0.0f;  // identity step for the leaf entry and for idle lanes
         ge = edge ? ge : 1.0f;
-        // leaf_value = reward + discount * leaf_value, deepest entry first; steps above the
-        // wave's deepest entry are identities for every row and are jumped over
-        float Gown = G;
+        // leaf_value = reward + discount * leaf_value, deepest entry first.  Every lane keeps its OWN
+        // entry's value: one step is G[e] = re[e] + ge[e] * G[e + 1] on all lanes at once (row_shl:1;
+        // lane 15 keeps the product with the value carried in from the chunk below), so entry e is final
+        // after (deepest entry - e + 1) steps and stays put afterwards; identity lanes hold the carry.
+        // Steps above the wave's deepest entry are identities for every row and are jumped over.
         const int kstart = min(15, wmax - 16 * c);
-#define MZ_GSTEP(k)                          \
-  G = bcast<k>(re) + bcast<k>(ge) * G;       \
-  Gown = (j == k) ? G : Gown;
-        if (kstart >= 12) { MZ_GSTEP(15) MZ_GSTEP(14) MZ_GSTEP(13) MZ_GSTEP(12) }
-        if (kstart >= 8) { MZ_GSTEP(11) MZ_GSTEP(10) MZ_GSTEP(9) MZ_GSTEP(8) }
-        if (kstart >= 4) { MZ_GSTEP(7) MZ_GSTEP(6) MZ_GSTEP(5) MZ_GSTEP(4) }
-        MZ_GSTEP(3) MZ_GSTEP(2) MZ_GSTEP(1) MZ_GSTEP(0)
+        float Gt = ge * G;
+#define MZ_GSTEP                                                                             \
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf"  \
+               : "+v"(Gt) : "v"(G), "v"(ge));                                                \
+  G = Gt + re;
+        if (kstart >= 12) { MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP }
+        if (kstart >= 8) { MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP }
+        if (kstart >= 4) { MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP }
+        MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP
 #undef MZ_GSTEP
-        const float newv = (pv * (float)cnt + Gown) / ((float)cnt + 1.0f);
+        const float Gown = G;
+        G = bcast<0>(G);  // carried into the chunk above
+        MZ_TICKW(8);  // G chain
+        const float newv = div_small(pv * (float)cnt + Gown, (float)cnt + 1.0f, tn_rc.y);
         // children_values[parent, action] = node_values[child]: the child is the next entry
         float childv = __int_as_float(__builtin_amdgcn_update_dpp(
             __float_as_int(carry_v), __float_as_int(newv), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
@@ -909,15 +955,12 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         const int next_pn = __builtin_amdgcn_update_dpp(carry_n, pn, 0x101, 0xf, 0xf, false);
         carry_n = bcast_i<0>(pn);
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-          val[a] = (edge && pa == a) ? childv : val[a];
-          vis[a] = (edge && pa == a) ? vis[a] + 1 : vis[a];
-        }
-        const int nvis = edge ? cnt + 1 : cnt;
+        for (int a = 0; a < A; ++a) val[a] = (edge && pa == a) ? childv : val[a];
         const float nval = edge ? newv : pv;
+        MZ_TICKW(9);  // value update
         float sc[A];
         if constexpr (!C::GUMBEL) {
-          puct_scores<A>(nval, tbl[valid ? nvis : 0], prob, val, vis, rew, dis, sc);
+          puct_scores<A>(nval, tn_rc.x, prob, val, vis, rew, dis, rcp1, sc);
 #pragma unroll
           for (int a = 0; a < A; ++a)  // root_invalid_actions: the root is only ever selected at depth 0
             sc[a] = (pn == 0 && ((inv_bits >> a) & 1u)) ? -INFINITY : sc[a];
@@ -931,6 +974,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           gumbel_scores<A, C::QT>(pn == 0, nval, nd[C::HDR0 + 3], logit, val, vis, rew, dis, gum, cv_next,
                                   pn == 0 ? inv_bits : 0u, sc);
         }
+        MZ_TICKW(10);  // scores
         int best, child;
         bool safe;
         decide<A, C::TB>(sc, cidx, best, child, safe);
@@ -954,6 +998,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #undef MZ_JSCAN
         jwd = inh ? carry_j : jwd;  // 15 hops covered; a lane still inheriting reaches past the row end
         carry_j = bcast_i<0>(jwd);
+        MZ_TICKW(11);  // decide + JUMP scan
         if (valid) {
           // one masked region; for the leaf entry the header / edge stores rewrite what was loaded
 #pragma unroll
@@ -975,12 +1020,6 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     }
     MZ_TICK(5);  // backward + score refresh
   }
-#ifdef MZ_PROFILE
-  if (p.prof != nullptr && lane == 0) {
-    uint64_t* dst = p.prof + ((size_t)blockIdx.x * C::WAVES + (tid >> 6)) * 8;
-    for (int q = 0; q < 8; ++q) dst[q] = prof_acc[q];
-  }
-#endif
 
   if constexpr (C::GUMBEL) {
     // ---- tail of mctx gumbel_muzero_policy: best action among the most visited, completed-Q target ----
@@ -1084,6 +1123,13 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       for (int i = j; i < E; i += 16) p.t_embeddings[o * E + i] = nd[C::EMB0 + i];
     }
   }
+  MZ_TICKW(13);  // epilogue: summary, sample, outputs
+#ifdef MZ_PROFILE
+  if (p.prof != nullptr && lane == 0) {
+    uint64_t* dst = p.prof + ((size_t)blockIdx.x * C::WAVES + (tid >> 6)) * 16;
+    for (int q = 0; q < 16; ++q) dst[q] = prof_acc[q];
+  }
+#endif
 }
 
 }  // namespace mz

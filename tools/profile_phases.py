@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "bin", "libmzsearch_prof.so")
 PHASES = ["loop top", "select (jump words)", "network pass", "-", "expand stores", "backward + refresh",
-          "-", "-"]
+          "bw: path entry", "bw: node loads", "bw: G chain", "bw: value update", "bw: scores",
+          "bw: decide + JUMP scan", "prologue (x S)", "epilogue (x S)", "-", "-"]
 
 
 def build():
@@ -39,7 +40,7 @@ def run():
     s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True))
     s.set_mlp_weights(w, obs_dim, support)
     waves = B // 4
-    prof = torch.zeros(waves, 8, dtype=torch.int64, device="cuda")
+    prof = torch.zeros(waves, 16, dtype=torch.int64, device="cuda")
     L = _lib.load()
     L.mzs_debug_profile.argtypes = [C.c_void_p, C.c_void_p]
     assert L.mzs_debug_profile(s._h, C.c_void_p(prof.data_ptr())) == 0
@@ -51,7 +52,7 @@ def run():
     print(f"waves {waves}; cycles per wave: mean {tot.mean():.0f} max {tot.max():.0f} min {tot.min():.0f}")
     depth = s.depth_sum.cpu().numpy().reshape(waves, 4)
     print(f"mean selection depth {depth.mean() / S:.2f}; per-wave sum of max-of-4 is not tracked here")
-    for k, name in enumerate(PHASES[:6]):
+    for k, name in enumerate(PHASES[:14]):
         if name == "-":
             continue
         print(f"  {name:26s} {p[:, k].mean() / S:9.0f} cycles/sim  ({100 * p[:, k].sum() / tot.sum():5.1f}%)   "

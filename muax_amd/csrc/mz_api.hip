@@ -59,6 +59,7 @@ struct mzs_handle {
   uint32_t sim_keys[mz::kMaxSims][2];
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
   int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
+  float* fused_emb = nullptr;      // fused path, embed_dim > 16: [B][S+1][E] embeddings in HBM
 };
 
 namespace {
@@ -187,6 +188,7 @@ int mzs_destroy(mzs_handle* h) {
   hipSetDevice(h->cfg.device);
   h->step.release();
   if (h->fused_table) hipFree(h->fused_table);
+  if (h->fused_emb) hipFree(h->fused_emb);
   delete h;
   return MZS_OK;
 }
@@ -248,6 +250,13 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.dirichlet_fraction = a->dirichlet_fraction; p.discount = w.discount; p.temperature = a->temperature;
   p.global_batch = (uint64_t)c.global_batch; p.root_offset = (uint64_t)c.root_offset;
   p.prof = h->prof;
+  p.emb_scratch = nullptr;
+  if (c.embed_dim > 16 && !p.export_tree) {
+    if (!h->fused_emb)
+      MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_emb),
+                           (size_t)c.batch * (c.num_simulations + 1) * c.embed_dim * sizeof(float)));
+    p.emb_scratch = h->fused_emb;
+  }
   if (c.policy == 1) {
     // gumbel policy: seq_halving table on the device (once), root Gumbel key = split(key)[1]
     const int rows = c.max_num_considered_actions + 1;
@@ -270,7 +279,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
 #define MZS_INST(A_, E_, F_, NMAX_, WAVES_) \
   if (A == A_ && E == E_ && F == F_ && N <= NMAX_) return dispatch_mode<A_, E_, F_, NMAX_, WAVES_>(h, p, stream);
   MZS_INST(2, 8, 21, 51, 4)    // CartPole   (BASELINE cfg1/cfg2; README.md:102-132)
-  MZS_INST(4, 32, 21, 51, 2)   // LunarLander (BASELINE cfg3)
+  MZS_INST(4, 32, 21, 51, 4)   // LunarLander (BASELINE cfg3)
   MZS_INST(3, 8, 21, 33, 4)    // odd action count (tests)
   MZS_INST(4, 8, 21, 51, 2)
 #undef MZS_INST

@@ -84,6 +84,7 @@ struct FusedParams {
   int32_t* t_children_index; float* t_children_prior_logits; float* t_children_values;
   int32_t* t_children_visits; float* t_children_rewards; float* t_children_discounts;
   float* t_embeddings;
+  float* emb_scratch;  // [B][S+1][E], instances with the embeddings out of LDS and no export
   // scalars
   int32_t B, obs_dim, S, max_depth, support, pred_on_parent, export_tree;
   float pb_c_init, pb_c_base, dirichlet_fraction, discount, temperature;
@@ -112,18 +113,22 @@ struct FusedCfg {
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
   //   [SEL0  ..) A x {child index, cached pUCT score}
   //   [HDR0  ..) visits, value, JUMP word, raw value
-  //   [ST0   ..) A x {prob, value, visits, reward, discount, prior logit}
+  //   [ST0   ..) A x {prob, value, visits, reward[, prior logit (Gumbel)]}; children_discounts is the
+  //              constant discount on expanded edges and multiplies a zero value on the others
   //   [EMB0  ..) embedding
   //   [PATH0 ..) this node's own root path, one packed (node, action) entry per level
   // JUMP word: end point of the greedy descent below this node:
   //   parent[0:12) | action[12:16) | depth of parent[16:24) | bit 31: the end point is a near tie
   static constexpr int SEL0 = 0, SELW = ((2 * A + 3) / 4) * 4;
   static constexpr int HDR0 = SELW, JUMP = HDR0 + 2;
-  static constexpr int ST0 = HDR0 + 4, STW = 6;
+  static constexpr int ST0 = HDR0 + 4, STW = MODE_ >= 2 ? 5 : 4, ST_LOGIT = 4;
+  // embeddings: in the LDS record while 16 roots per workgroup still fit the CU's LDS with them, else in
+  // HBM ([root][node][E], one coalesced E*4-byte row per access, L2-resident while the root is active)
+  static constexpr bool EMB_LDS = E_ <= 16;
   static constexpr int EMB0 = ST0 + STW * A;
   static constexpr int ENTRY_BITS = (NMAX <= 64 && A <= 4) ? 8 : 16;
   static constexpr int ENTRY_ACT_SHIFT = ENTRY_BITS == 8 ? 6 : 12;
-  static constexpr int PATH0 = EMB0 + E;
+  static constexpr int PATH0 = EMB0 + (EMB_LDS ? E : 0);
   static constexpr int PATHW = (NMAX * ENTRY_BITS + 31) / 32;
   static constexpr int NS = ((PATH0 + PATHW + 3) / 4) * 4;
   static constexpr int TREE_WORDS = NS * NMAX;
@@ -574,6 +579,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   const int support = p.support;
   const bool ex = p.export_tree != 0;
 
+  // embeddings of this root in HBM (instances that keep them out of LDS): the caller's export buffer when
+  // a tree export is requested, else the handle's scratch
+  float* gemb = C::EMB_LDS ? nullptr : (ex ? p.t_embeddings : p.emb_scratch) + (size_t)r * N * E;
+
   Nets<C> nets;
   nets.load(p, j);
 
@@ -596,6 +605,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       p.t_action_from_parent[o] = -1;
     }
     for (int i = j; i < N * A; i += 16) p.t_children_prior_logits[(size_t)r * N * A + i] = 0.0f;
+    if constexpr (!C::EMB_LDS)
+      for (int i = j; i < N * E; i += 16) gemb[i] = 0.0f;
   }
 
   // ---- root inference (muax/model.py:251-263) ----
@@ -658,7 +669,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       }
       if (j < A) {
         tree[C::PATH0 + j] = g;  // the root's own path is empty: its slot keeps root_gumbel
-        tree[C::ST0 + C::STW * j + 5] = lg;
+        tree[C::ST0 + C::STW * j + C::ST_LOGIT] = lg;
       }
       ncons = min(p.max_considered, A - __builtin_popcount(inv_bits));
     }
@@ -673,14 +684,17 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     }
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
-      if (j + 16 * t < E) tree[C::EMB0 + j + 16 * t] = s[t];
+      if (j + 16 * t < E) {
+        if constexpr (C::EMB_LDS) tree[C::EMB0 + j + 16 * t] = s[t];
+        else gemb[j + 16 * t] = s[t];
+      }
     // cached scores of the root's children (all unvisited)
     float prob[A], val[A], rew[A], dis[A], sc[A];
     int vis[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       prob[a] = tree[C::ST0 + C::STW * a + 0];
-      val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = 0.0f;
+      val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = p.discount;
     }
     int cidx[A], best, child;
     bool safe;
@@ -693,7 +707,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       float logit[A], gum[A];
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        logit[a] = tree[C::ST0 + C::STW * a + 5];
+        logit[a] = tree[C::ST0 + C::STW * a + C::ST_LOGIT];
         gum[a] = tree[C::PATH0 + a];
       }
       gumbel_scores<A, C::QT>(true, v0, v0, logit, val, vis, rew, dis, gum, p.visit_table[(size_t)ncons * S],
@@ -805,7 +819,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float sp[C::ES];
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
-      sp[t] = (j + 16 * t < E) ? tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + j + 16 * t] : 0.0f;
+      if constexpr (C::EMB_LDS)
+        sp[t] = (j + 16 * t < E) ? tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + j + 16 * t] : 0.0f;
+      else
+        sp[t] = (j + 16 * t < E) ? gemb[(size_t)parent * E + j + 16 * t] : 0.0f;
     // LDS reads the expansion needs are issued before the network pass so their latency hides behind it
     float* nn = tree + __umul24((unsigned)newn, (unsigned)NS);
     int* nni = reinterpret_cast<int*>(nn);
@@ -820,18 +837,20 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       const int vis = vis_old + 1;
       if (j < A) {
         nn[C::ST0 + C::STW * j + 0] = pprob;
-        if constexpr (C::GUMBEL) nn[C::ST0 + C::STW * j + 5] = pil;
+        if constexpr (C::GUMBEL) nn[C::ST0 + C::STW * j + C::ST_LOGIT] = pil;
       }
 #pragma unroll
       for (int t = 0; t < C::ES; ++t)
-        if (j + 16 * t < E) nn[C::EMB0 + j + 16 * t] = ns[t];
+        if (j + 16 * t < E) {
+          if constexpr (C::EMB_LDS) nn[C::EMB0 + j + 16 * t] = ns[t];
+          else gemb[(size_t)newn * E + j + 16 * t] = ns[t];
+        }
       if (j == 0) {
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
         nn[C::HDR0 + 3] = value;  // raw_values[new] (mctx update_tree_node)
         itree[po + C::SEL0 + 2 * action] = newn;
         tree[po + C::ST0 + C::STW * action + 3] = reward;
-        tree[po + C::ST0 + C::STW * action + 4] = p.discount;
       }
       if (fresh && j < C::PATHW) {
         // the new node's root path = its parent's path + (parent, action); written once
@@ -900,7 +919,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           val[a] = nd[C::ST0 + C::STW * a + 1];
           vis[a] = ndi[C::ST0 + C::STW * a + 2];
           rew[a] = nd[C::ST0 + C::STW * a + 3];
-          dis[a] = nd[C::ST0 + C::STW * a + 4];
+          dis[a] = p.discount;
         }
         // cached JUMP words of all children (clamped addresses), fetched now so that the one the
         // refreshed decision picks is already here
@@ -919,14 +938,11 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           rcp1[a] = tbl[2 * (vis[a] + 1) + 1];
         }
         MZ_TICKW(7);  // node + child JUMP loads
-        float re = rew[0], ge = dis[0];
+        float re = rew[0];
 #pragma unroll
-        for (int a = 1; a < A; ++a) {
-          re = (pa == a) ? rew[a] : re;
-          ge = (pa == a) ? dis[a] : ge;
-        }
+        for (int a = 1; a < A; ++a) re = (pa == a) ? rew[a] : re;
         re = edge ? re : 0.0f;  // identity step for the leaf entry and for idle lanes
-        ge = edge ? ge : 1.0f;
+        const float ge = edge ? p.discount : 1.0f;
         // leaf_value = reward + discount * leaf_value, deepest entry first.  Every lane keeps its OWN
         // entry's value: one step is G[e] = re[e] + ge[e] * G[e + 1] on all lanes at once (row_shl:1;
         // lane 15 keeps the product with the value carried in from the chunk below), so entry e is final
@@ -968,7 +984,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           float logit[A], gum[A];
 #pragma unroll
           for (int a = 0; a < A; ++a) {
-            logit[a] = nd[C::ST0 + C::STW * a + 5];
+            logit[a] = nd[C::ST0 + C::STW * a + C::ST_LOGIT];
             gum[a] = tree[C::PATH0 + a];
           }
           gumbel_scores<A, C::QT>(pn == 0, nval, nd[C::HDR0 + 3], logit, val, vis, rew, dis, gum, cv_next,
@@ -1030,8 +1046,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       val[a] = tree[C::ST0 + C::STW * a + 1];
       vis[a] = itree[C::ST0 + C::STW * a + 2];
       rew[a] = tree[C::ST0 + C::STW * a + 3];
-      dis[a] = tree[C::ST0 + C::STW * a + 4];
-      logit[a] = tree[C::ST0 + C::STW * a + 5];
+      dis[a] = p.discount;
+      logit[a] = tree[C::ST0 + C::STW * a + C::ST_LOGIT];
       gum[a] = tree[C::PATH0 + a];
       cv = max(cv, vis[a]);
     }
@@ -1118,9 +1134,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         p.t_children_values[o * A + j] = nd[so + 1];
         p.t_children_visits[o * A + j] = ndi[so + 2];
         p.t_children_rewards[o * A + j] = nd[so + 3];
-        p.t_children_discounts[o * A + j] = nd[so + 4];
+        p.t_children_discounts[o * A + j] = ndi[C::SEL0 + 2 * j] >= 0 ? p.discount : 0.0f;
       }
-      for (int i = j; i < E; i += 16) p.t_embeddings[o * E + i] = nd[C::EMB0 + i];
+      if constexpr (C::EMB_LDS)  // (else: the search ran on t_embeddings itself)
+        for (int i = j; i < E; i += 16) p.t_embeddings[o * E + i] = nd[C::EMB0 + i];
     }
   }
   MZ_TICKW(13);  // epilogue: summary, sample, outputs

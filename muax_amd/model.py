@@ -47,7 +47,7 @@ class MuZero:
     def __init__(self, network=None, prediction_fn=None, dynamic_fn=None, policy_class=MuZeroPolicy,
                  policy: Optional[str] = None, optimizer=None, loss_fn=None, discount: float = 0.99,
                  support_size: int = 10, recurrent_pred_on: str = "child", device=None,
-                 representation_fn=None):
+                 representation_fn=None, capture_graph: bool = False):
         if isinstance(network, MZNetwork):
             self.network = network
         else:
@@ -72,6 +72,8 @@ class MuZero:
         self._recurrent_pred_on = recurrent_pred_on
         self.device = torch.device(device) if device is not None else (
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        # plugin (non-default) nets: run the S x (select, recurrent_fn, expand_backup) loop as one hipGraph
+        self.capture_graph = bool(capture_graph)
         self._params = None
         self._opt_state = None
         self._fused = {}
@@ -197,7 +199,7 @@ class MuZero:
             out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
                                invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
                                max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
-                               gumbel=gumbel, with_tree=with_tree)
+                               gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph)
             return out, root[1]
         if dirichlet_noise is None and dirichlet_fraction:
             k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
@@ -222,7 +224,7 @@ class MuZero:
                            temperature=temperature, invalid_actions=invalid_actions, max_depth=max_depth,
                            dirichlet_fraction=dirichlet_fraction, dirichlet_noise=dirichlet_noise,
                            pb_c_init=pb_c_init, pb_c_base=pb_c_base, gumbel=gumbel, tiebreak=tiebreak,
-                           with_tree=with_tree)
+                           with_tree=with_tree, graph=self.capture_graph)
         return out, root[1]
 
     def act(self, rng_key, obs, with_pi: bool = False, with_value: bool = False, obs_from_batch: bool = False,

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from abc import ABC, abstractmethod
 
-from .search import MuZeroSearch, PolicyOutput, SearchConfig
+from .search import MuZeroSearch, PolicyOutput, SearchConfig, fn_identity
 
 
 class Policy(ABC):
@@ -56,7 +56,8 @@ class MuZeroPolicy(Policy):
                         dirichlet_noise=kwargs.get("dirichlet_noise"),
                         dirichlet_fraction=kwargs.get("dirichlet_fraction", 0.25),
                         temperature=kwargs.get("temperature", 1.0), gumbel=kwargs.get("gumbel"),
-                        with_tree=kwargs.get("with_tree", False))
+                        with_tree=kwargs.get("with_tree", False), graph=kwargs.get("graph", False),
+                        graph_key=(fn_identity(recurrent_fn), id(params), shape))
 
 
 class GumbelMuZeroPolicy(Policy):
@@ -97,7 +98,8 @@ class GumbelMuZeroPolicy(Policy):
 
         return h.search((prior_logits, value, emb), rec, key=rng_key,
                         invalid_actions=kwargs.get("invalid_actions"), gumbel=kwargs.get("gumbel"),
-                        with_tree=kwargs.get("with_tree", False))
+                        with_tree=kwargs.get("with_tree", False), graph=kwargs.get("graph", False),
+                        graph_key=(fn_identity(recurrent_fn), id(params), shape))
 
 
 class StochasticMuZeroPolicy(Policy):

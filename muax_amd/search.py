@@ -73,6 +73,11 @@ def key_words(key) -> tuple:
     return (int(a[0]) & 0xFFFFFFFF, int(a[1]) & 0xFFFFFFFF)
 
 
+def fn_identity(fn):
+    """Hashable identity of a callable that survives bound-method re-creation."""
+    return (getattr(fn, "__func__", fn), id(getattr(fn, "__self__", None)))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -117,6 +122,7 @@ class MuZeroSearch:
             self.depth_sum = torch.empty(B, dtype=torch.int32, device=self.device)
         self._tree = None
         self._parent_emb = None
+        self._graphs = {}  # (recurrent_fn) -> captured simulation loop
 
     def close(self):
         if getattr(self, "_h", None):
@@ -295,17 +301,49 @@ class MuZeroSearch:
 
     def search(self, root_fn_output, recurrent_fn, key=0, invalid_actions=None,
                dirichlet_noise=None, dirichlet_fraction=0.25, temperature=1.0, gumbel=None,
-               with_tree=False) -> PolicyOutput:
+               with_tree=False, graph=False, graph_key=None) -> PolicyOutput:
         """mctx.muzero_policy with a caller-supplied recurrent_fn(action, embedding) ->
-        (reward, discount, prior_logits, value, next_embedding) of torch tensors."""
+        (reward, discount, prior_logits, value, next_embedding) of torch tensors.
+
+        graph=True captures the S x (select -> recurrent_fn -> expand_backup) loop into ONE hipGraph
+        (torch.cuda.CUDAGraph; our kernels are launched on torch's current stream, so the capture sees
+        them) and replays it on later calls: the loop is launch-bound -- two tree kernels plus the
+        plugin's own small kernels per simulation -- and a graph launch removes the per-kernel host cost.
+        recurrent_fn must then be capture-safe (no host synchronisation, static shapes); the per-call
+        PRNG keys live in device memory (root) or in the un-captured root/finish calls."""
         prior_logits, value, embedding = root_fn_output
-        if self.cfg.policy == "gumbel":
-            self.root_gumbel(prior_logits, value, embedding, key, invalid_actions, gumbel)
-            gumbel = None
+
+        def do_root():
+            if self.cfg.policy == "gumbel":
+                self.root_gumbel(prior_logits, value, embedding, key, invalid_actions, gumbel)
+            else:
+                self.root(prior_logits, value, embedding, key, invalid_actions, dirichlet_noise,
+                          dirichlet_fraction)
+
+        def loop():
+            for sim in range(self.cfg.num_simulations):
+                action, emb = self.select(sim)
+                self.expand_backup(sim, *recurrent_fn(action, emb))
+
+        do_root()
+        if not graph:
+            loop()
         else:
-            self.root(prior_logits, value, embedding, key, invalid_actions, dirichlet_noise,
-                      dirichlet_fraction)
-        for sim in range(self.cfg.num_simulations):
-            action, emb = self.select(sim)
-            self.expand_backup(sim, *recurrent_fn(action, emb))
-        return self.finish(temperature, gumbel, with_tree)
+            gkey = graph_key if graph_key is not None else fn_identity(recurrent_fn)
+            entry = self._graphs.get(gkey)
+            if entry is None:
+                # warm-up run (lazy library initialisation must not happen under capture), then the tree
+                # is rebuilt from the same root and the loop is captured (capture records, it does not run)
+                with torch.no_grad():
+                    side = torch.cuda.Stream(device=self.device)
+                    side.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(side):
+                        loop()
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                    do_root()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        loop()
+                entry = self._graphs[gkey] = (g, recurrent_fn, self._keep)
+            entry[0].replay()
+        return self.finish(temperature, None if self.cfg.policy == "gumbel" else gumbel, with_tree)

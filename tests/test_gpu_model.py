@@ -195,3 +195,40 @@ def test_stepwise_search_reuses_handle_and_errors():
                        lambda a, e: (torch.zeros(8), torch.ones(8), torch.zeros(8, 3), torch.zeros(8), e),
                        key=rep, with_tree=True)
         assert int(out.search_tree.node_visits[:, 0].min()) == 7
+
+
+@pytest.mark.gpu
+def test_graph_captured_simulation_loop_equals_eager_loop():
+    """capture_graph=True replays the S x (select, recurrent_fn, expand_backup) loop as ONE hipGraph; the
+    search must be identical to the eager loop, call after call, with fresh keys/observations each call
+    (keys live in device memory / the un-captured root and finish), for both policies."""
+    for policy in ("muzero", "gumbel"):
+        g = torch.Generator().manual_seed(11)
+        mk = lambda: mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),  # noqa: E731
+                                     mx.nn.Dynamic(8, 2, 21, generator=g))
+        net = mk()
+
+        class Wrap(torch.nn.Module):  # hides the default trio from the fused kernel -> step-wise path
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, *a):
+                return self.inner(*a)
+
+        mods = [Wrap(x) for x in net]
+        eager = mx.MuZero(*mods, policy=policy)
+        graph = mx.MuZero(*mods, policy=policy, capture_graph=True)
+        eager.init(0, np.zeros((1, 4)))
+        graph.init(0, np.zeros((1, 4)))
+        rng = np.random.default_rng(12)
+        for call in range(4):
+            obs = rng.uniform(-1, 1, (96, 4)).astype(F32)
+            kw = dict(with_pi=True, with_value=True, obs_from_batch=True, num_simulations=20)
+            if policy == "muzero":
+                kw["dirichlet_noise"] = rng.dirichlet([0.3, 0.3], 96).astype(F32)
+            a1, pi1, v1 = eager.act(100 + call, obs, **kw)
+            a2, pi2, v2 = graph.act(100 + call, obs, **kw)
+            assert (a1 == a2).all() and (pi1 == pi2).all() and (v1 == v2).all(), (policy, call)
+        handles = list(graph._policy._handles.values())
+        assert len(handles) == 1 and len(handles[0]._graphs) == 1  # captured once, replayed afterwards

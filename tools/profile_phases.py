@@ -32,7 +32,7 @@ def run():
     _lib._lib = None
     import bench
     from muax_amd import MuZeroSearch, SearchConfig
-    B, obs_dim, E, A, support, S = bench.WORKLOADS["cartpole"]
+    B, obs_dim, E, A, support, S = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else "cartpole"]
     w = bench.haiku_style_weights(0, obs_dim, E, A, 2 * support + 1)
     g = torch.Generator().manual_seed(1000)
     obs = (torch.rand(B, obs_dim, generator=g) * 2 - 1).cuda()

@@ -155,3 +155,215 @@ def mlp_trio_weights(network: MZNetwork) -> dict:
             "pp_w1": p.pi_func[0].w, "pp_b1": p.pi_func[0].b, "pp_w2": p.pi_func[1].w, "pp_b2": p.pi_func[1].b,
             "dr_w1": d.r_func[0].w, "dr_b1": d.r_func[0].b, "dr_w2": d.r_func[1].w, "dr_b2": d.r_func[1].b,
             "dn_w1": d.ns_func[0].w, "dn_b1": d.ns_func[0].b, "dn_w2": d.ns_func[1].w, "dn_b2": d.ns_func[1].b}
+
+
+# ---------------------------------------------------------------------------------------------------
+# Convolutional plugin nets (muax/nn.py:47-56,118-395).  INTERIM: plain torch modules
+# (MIOpen / hipBLASLt kernels underneath) that the step-wise search drives -- optionally as one hipGraph
+# (MuZero(capture_graph=True)).  They are NOT hand-written MFMA kernels; the tree kernels either side of
+# them are.  Tensors keep the reference's NHWC layout at every module boundary (embedding [B, H, W, C]);
+# inside a convolution the same memory is viewed as channels_last NCHW, so no transposes are made.
+# ---------------------------------------------------------------------------------------------------
+def min_max_normalize2d(s: torch.Tensor) -> torch.Tensor:
+    """muax/nn.py:47-56: per (sample, channel) min/max over the H*W plane of an NHWC tensor."""
+    s_min = s.amin(dim=(1, 2), keepdim=True)
+    s_max = s.amax(dim=(1, 2), keepdim=True)
+    s_scale = s_max - s_min
+    s_scale = torch.where(s_scale < 1e-5, s_scale + 1e-5, s_scale)
+    return (s - s_min) / s_scale
+
+
+def _same_pad(size: int, k: int, stride: int):
+    """TensorFlow/haiku 'SAME': out = ceil(size / stride), the odd pixel of padding goes after."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return total // 2, total - total // 2
+
+
+class HkConv2D(nn.Module):
+    """hk.Conv2D(channels, kernel_shape, stride, padding='SAME', with_bias=False) on NHWC tensors;
+    weight stored HWIO like haiku (w[kh][kw][in][out]), TruncatedNormal(1/sqrt(fan_in)) init."""
+
+    def __init__(self, out_channels: int, kernel_shape: int = 3, stride: int = 1, in_channels: Optional[int] = None,
+                 generator=None):
+        super().__init__()
+        self.out_channels, self.k, self.stride, self._gen = out_channels, kernel_shape, stride, generator
+        self.w = None
+        if in_channels:
+            self.materialize(in_channels)
+
+    def materialize(self, cin: int):
+        if self.w is None:
+            w = torch.empty(self.k, self.k, cin, self.out_channels)
+            nn.init.trunc_normal_(w, 0.0, 1.0, -2.0, 2.0, generator=self._gen)
+            self.w = nn.Parameter(w / math.sqrt(self.k * self.k * cin))
+
+    def forward(self, x):
+        self.materialize(x.shape[-1])
+        xc = x.permute(0, 3, 1, 2)
+        (ht, hb), (wl, wr) = _same_pad(x.shape[1], self.k, self.stride), _same_pad(x.shape[2], self.k, self.stride)
+        if ht or hb or wl or wr:
+            xc = torch.nn.functional.pad(xc, (wl, wr, ht, hb))
+        y = torch.nn.functional.conv2d(xc, self.w.permute(3, 2, 0, 1), stride=self.stride)
+        return y.permute(0, 2, 3, 1)
+
+
+class HkLayerNorm(nn.Module):
+    """hk.LayerNorm(axis, create_scale=True, create_offset=True): statistics over `axis`, scale/offset
+    over the last axis, eps 1e-5, biased variance."""
+
+    def __init__(self, axis=(-3, -2, -1)):
+        super().__init__()
+        self.axis = tuple(axis) if isinstance(axis, (tuple, list)) else (axis,)
+        self.scale = self.offset = None
+
+    def forward(self, x):
+        if self.scale is None:
+            self.scale = nn.Parameter(torch.ones(x.shape[-1], device=x.device))
+            self.offset = nn.Parameter(torch.zeros(x.shape[-1], device=x.device))
+        mean = x.mean(dim=self.axis, keepdim=True)
+        var = x.var(dim=self.axis, keepdim=True, unbiased=False)
+        return (x - mean) * torch.rsqrt(var + 1e-5) * self.scale + self.offset
+
+
+class LazyHkLinear(nn.Module):
+    """hk.Linear(out, with_bias) whose input width is known at the first call."""
+
+    def __init__(self, out_features: int, with_bias: bool = True, generator=None):
+        super().__init__()
+        self.out_features, self.with_bias, self._gen = out_features, with_bias, generator
+        self.w = self.b = None
+
+    def forward(self, x):
+        if self.w is None:
+            w = torch.empty(x.shape[-1], self.out_features)
+            nn.init.trunc_normal_(w, 0.0, 1.0, -2.0, 2.0, generator=self._gen)
+            self.w = nn.Parameter((w / math.sqrt(x.shape[-1])).to(x.device))
+            if self.with_bias:
+                self.b = nn.Parameter(torch.zeros(self.out_features, device=x.device))
+        y = x @ self.w
+        return y + self.b if self.with_bias else y
+
+
+def avg_pool_same(x: torch.Tensor, window: int = 3, stride: int = 2) -> torch.Tensor:
+    """hk.AvgPool(window_shape=(3,3,1), strides=(2,2,1), padding='SAME') on NHWC: the mean of the VALID
+    elements under each window."""
+    xc = x.permute(0, 3, 1, 2)
+    (ht, hb), (wl, wr) = _same_pad(x.shape[1], window, stride), _same_pad(x.shape[2], window, stride)
+    s = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(xc, (wl, wr, ht, hb)), window, stride, divisor_override=1)
+    ones = torch.ones(1, 1, x.shape[1], x.shape[2], dtype=x.dtype, device=x.device)
+    cnt = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(ones, (wl, wr, ht, hb)), window, stride, divisor_override=1)
+    return (s / cnt).permute(0, 2, 3, 1)
+
+
+class ResidualConvBlockV1(nn.Module):
+    """muax/nn.py:118-148: conv-LN-relu-conv-LN, (projected) shortcut, relu."""
+
+    def __init__(self, channels: int, stride: int, use_projection: bool, generator=None):
+        super().__init__()
+        self.use_projection = use_projection
+        if use_projection:
+            self.proj_conv, self.proj_ln = HkConv2D(channels, 3, stride, generator=generator), HkLayerNorm()
+        self.conv_0, self.ln_0 = HkConv2D(channels, 3, stride, generator=generator), HkLayerNorm()
+        self.conv_1, self.ln_1 = HkConv2D(channels, 3, 1, generator=generator), HkLayerNorm()
+
+    def forward(self, x):
+        shortcut = self.proj_ln(self.proj_conv(x)) if self.use_projection else x
+        out = self.ln_1(self.conv_1(torch.relu(self.ln_0(self.conv_0(x)))))
+        return torch.relu(shortcut + out)
+
+
+class ResidualConvBlockV2(nn.Module):
+    """muax/nn.py:151-178: pre-activation block (LN-relu first; the projection reads the activated input)."""
+
+    def __init__(self, channels: int, stride: int, use_projection: bool, generator=None):
+        super().__init__()
+        self.use_projection = use_projection
+        if use_projection:
+            self.proj_conv = HkConv2D(channels, 3, stride, generator=generator)
+        self.conv_0, self.ln_0 = HkConv2D(channels, 3, stride, generator=generator), HkLayerNorm()
+        self.conv_1, self.ln_1 = HkConv2D(channels, 3, 1, generator=generator), HkLayerNorm()
+
+    def forward(self, x):
+        out = torch.relu(self.ln_0(x))
+        shortcut = self.proj_conv(out) if self.use_projection else x
+        out = self.conv_1(torch.relu(self.ln_1(self.conv_0(out))))
+        return shortcut + out
+
+
+class _Seq(nn.Sequential):
+    pass
+
+
+def _head(conv_channels, n_convs, hidden, out, gen):
+    """1x1 conv (x n_convs) - relu - flatten - Linear(hidden) - relu - Linear(out) (muax/nn.py:317-337)."""
+    layers = []
+    for _ in range(n_convs):
+        layers += [HkConv2D(conv_channels, 1, 1, generator=gen), nn.ReLU()]
+    return _Seq(*layers, nn.Flatten(1), LazyHkLinear(hidden, generator=gen), nn.ReLU(), LazyHkLinear(out, generator=gen))
+
+
+class ResNetRepresentation(nn.Module):
+    """muax/nn.py:291-310: uint8-range NHWC frames -> [B, H/16, W/16, 2*input_channels], min-max
+    normalised per channel (84x84x4 -> 6x6x64 at the default width)."""
+
+    def __init__(self, input_channels: int = 32, generator=None, name="representation"):
+        super().__init__()
+        c, g = input_channels, generator
+        self.embedding_dim = None
+        self.stem0 = HkConv2D(c, 3, 2, generator=g)
+        self.blocks0 = nn.ModuleList([ResidualConvBlockV1(c, 1, True, g) for _ in range(2)])
+        self.stem1 = HkConv2D(2 * c, 3, 2, generator=g)
+        self.blocks1 = nn.ModuleList([ResidualConvBlockV1(2 * c, 1, True, g) for _ in range(3)])
+        self.blocks2 = nn.ModuleList([ResidualConvBlockV1(2 * c, 1, True, g) for _ in range(3)])
+
+    def forward(self, obs):
+        x = torch.relu(self.stem0(obs.to(torch.float32) / 255.))
+        for b in self.blocks0:
+            x = b(x)
+        x = torch.relu(self.stem1(x))
+        for b in self.blocks1:
+            x = b(x)
+        x = avg_pool_same(x)
+        for b in self.blocks2:
+            x = b(x)
+        return min_max_normalize2d(avg_pool_same(x))
+
+
+class ResNetPrediction(nn.Module):
+    """muax/nn.py:313-341."""
+
+    def __init__(self, num_actions: int, full_support_size: int, output_channels: int = 16, generator=None,
+                 name="prediction"):
+        super().__init__()
+        self.num_actions, self.full_support_size = num_actions, full_support_size
+        # creation order follows the reference: pi_func, then v_func
+        self.pi_func = _head(output_channels, 1, output_channels, num_actions, generator)
+        self.v_func = _head(output_channels, 2, output_channels, full_support_size, generator)
+
+    def forward(self, s):
+        return self.v_func(s), self.pi_func(s)
+
+
+class ResNetDynamic(nn.Module):
+    """muax/nn.py:344-378: the action enters as one extra plane a / num_actions."""
+
+    def __init__(self, embedding_dim, num_actions: int = None, full_support_size: int = None, output_channels: int = 64,
+                 generator=None, name="dynamic"):
+        super().__init__()
+        if full_support_size is None:  # the reference's own signature: (num_actions, full_support_size)
+            embedding_dim, num_actions, full_support_size = None, embedding_dim, num_actions
+        self.num_actions, self.full_support_size = num_actions, full_support_size
+        g = generator
+        self.r_func = _head(output_channels, 2, output_channels, full_support_size, g)
+        self.ns_stem = HkConv2D(output_channels, 1, 1, generator=g)
+        self.ns_blocks = nn.ModuleList([ResidualConvBlockV1(output_channels, 1, True, g) for _ in range(8)])
+
+    def forward(self, s, a):
+        n, h, w, _ = s.shape
+        plane = (a.to(s.dtype) / self.num_actions).reshape(n, 1, 1, 1).expand(n, h, w, 1)
+        sa = torch.cat([s, plane], dim=-1)
+        ns = torch.relu(self.ns_stem(sa))
+        for b in self.ns_blocks:
+            ns = b(ns)
+        return self.r_func(sa), min_max_normalize2d(ns)

@@ -232,3 +232,23 @@ def test_graph_captured_simulation_loop_equals_eager_loop():
             assert (a1 == a2).all() and (pi1 == pi2).all() and (v1 == v2).all(), (policy, call)
         handles = list(graph._policy._handles.values())
         assert len(handles) == 1 and len(handles[0]._graphs) == 1  # captured once, replayed afterwards
+
+
+@pytest.mark.gpu
+def test_resnet_plugin_nets_drive_the_stepwise_search():
+    """Conv plugin nets (NHWC embedding [B,h,w,c], A=18): the embedding is opaque to the tree kernels; the
+    hipGraph-captured loop reproduces the eager one."""
+    g = torch.Generator().manual_seed(0)
+    mods = (mx.nn.ResNetRepresentation(4, generator=g), mx.nn.ResNetPrediction(18, 21, 8, generator=g),
+            mx.nn.ResNetDynamic(18, 21, output_channels=8, generator=g))
+    obs = np.random.default_rng(0).integers(0, 256, (6, 32, 32, 2)).astype(F32)
+    out = []
+    for cap in (False, True):
+        m = mx.MuZero(*mods, capture_graph=cap)
+        m.init(0, obs[:1])
+        for call in range(2):
+            out.append(m.act(5 + call, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=12))
+    for (a, pi, v), (a2, pi2, v2) in zip(out[:2], out[2:]):
+        assert a.shape == (6,) and pi.shape == (6, 18) and v.shape == (6,)
+        assert (pi * 12 == np.round(pi * 12)).all() and np.allclose(pi.sum(1), 1, atol=1e-6)
+        assert np.allclose(v, v2, rtol=1e-4, atol=1e-5) and (pi == pi2).mean() > 0.9

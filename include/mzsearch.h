@@ -147,6 +147,38 @@ int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
                float *search_value_out, int32_t *depth_sum_out, void *stream);
 int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
 
+/* ---- training step of the default MLP trio ----
+ * mzs_mlp_loss_grad replaces jax.value_and_grad(loss_fn) at muax/model.py:245-249 with the default
+ * loss (muax/loss.py:10-88): for a batch of k-step trajectories it returns the scalar loss and the
+ * gradient of every one of the 18 weight arrays, concatenated in the member order of mzs_mlp_weights
+ * (repr_w, repr_b, pv_w1, ... dn_b2), each in its own haiku layout.  One fused forward+backward kernel
+ * and a fixed-order reduction: bit-reproducible run to run.  The optimiser (muax/optimizers.py) and the
+ * optional data-parallel gradient mean (one flat all-reduce over `grads`) stay with the caller. */
+typedef struct mzs_train_args {
+  int32_t struct_size;      /* = sizeof(mzs_train_args) */
+  int32_t device;
+  int32_t batch;            /* B trajectories */
+  int32_t unroll_steps;     /* L = k_steps (muax/replay_buffer.py:192-240 batch layout [B, L, ...]) */
+  int32_t num_actions;
+  int32_t embed_dim;
+  const float *obs;         /* [B, obs_dim]  batch.obs[:, 0] */
+  const int32_t *actions;   /* [B, L] */
+  const float *rewards;     /* [B, L]   batch.r  */
+  const float *returns;     /* [B, L]   batch.Rn */
+  const float *policy;      /* [B, L, A] batch.pi */
+  float loss_scale;         /* 1/B (muax/loss.py) or 1/(B L) (frameworks/coax/loss.py:70-71) */
+  float l2_coeff;           /* 1e-4 (muax/loss.py:84-87) */
+  float *loss;              /* [1] out */
+  float *grads;             /* [mzs_mlp_num_params] out */
+  void *workspace;          /* >= mzs_mlp_train_workspace_bytes(...) */
+  int64_t workspace_bytes;
+} mzs_train_args;
+int64_t mzs_mlp_num_params(int32_t obs_dim, int32_t embed_dim, int32_t num_actions, int32_t support_size);
+int64_t mzs_mlp_train_workspace_bytes(int32_t batch, int32_t obs_dim, int32_t embed_dim,
+                                      int32_t num_actions, int32_t support_size);
+/* errors: mzs_last_error(NULL) */
+int mzs_mlp_loss_grad(const mzs_mlp_weights *w, const mzs_train_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

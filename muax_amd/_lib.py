@@ -52,10 +52,19 @@ class MzsActArgs(C.Structure):
                 ("depth_sum", _vp), ("tree", C.POINTER(MzsTreeView))]
 
 
+class MzsTrainArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32),
+                ("unroll_steps", C.c_int32), ("num_actions", C.c_int32), ("embed_dim", C.c_int32),
+                ("obs", _vp), ("actions", _vp), ("rewards", _vp), ("returns", _vp), ("policy", _vp),
+                ("loss_scale", C.c_float), ("l2_coeff", C.c_float), ("loss", _vp), ("grads", _vp),
+                ("workspace", _vp), ("workspace_bytes", C.c_int64)]
+
+
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup",
-                    "mzs_finish", "mzs_tree_export"]
+                    "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
+                    "mzs_mlp_train_workspace_bytes"]
 
 _lib = None
 
@@ -84,8 +93,13 @@ def load(build_if_missing: bool = True):
     L.mzs_expand_backup.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mzs_finish.argtypes = [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mzs_tree_export.argtypes = [_vp, C.POINTER(MzsTreeView), _vp]
+    L.mzs_mlp_loss_grad.argtypes = [C.POINTER(MzsMlpWeights), C.POINTER(MzsTrainArgs), _vp]
+    L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4
+    L.mzs_mlp_train_workspace_bytes.argtypes = [C.c_int32] * 5
     for n in EXPORTED_SYMBOLS[2:]:
         getattr(L, n).restype = C.c_int
+    L.mzs_mlp_num_params.restype = C.c_int64
+    L.mzs_mlp_train_workspace_bytes.restype = C.c_int64
     if L.mzs_abi_version() != 1:
         raise RuntimeError("libmzsearch.so ABI version mismatch")
     _lib = L

@@ -11,6 +11,7 @@
 #include "../../include/mzsearch.h"
 #include "mz_fused.cuh"
 #include "mz_step.cuh"
+#include "mz_train.cuh"
 
 namespace {
 
@@ -142,6 +143,26 @@ int dispatch_mode(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+static void mlp_offsets(int obs_dim, int E, int A, int F, int off[19]) {
+  const int H = mz::kHidden, X = E + A;
+  const int sizes[18] = {obs_dim * E, E, E * H, H, H * F, F, E * H, H, H * A, A, X * H, H, H * F, F, X * H, H, H * E, E};
+  off[0] = 0;
+  for (int i = 0; i < 18; ++i) off[i + 1] = off[i] + sizes[i];
+}
+
+template <class C>
+static int launch_train(const mz::TrainParams& p, hipStream_t stream) {
+  const size_t lds = sizeof(float) * ((size_t)C::WEIGHT_WORDS + (size_t)p.L * C::CK_WORDS_PER_STEP);
+  if (lds > 160 * 1024) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: unroll_steps too large for the LDS");
+  auto kern = mz::mz_train_kernel<C>;
+  MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(p.waves / 4), dim3(256), lds, stream, p);
+  MZS_HIP(nullptr, hipGetLastError());
+  hipLaunchKernelGGL(mz::mz_train_reduce_kernel, dim3((p.off[18] + 31) / 32), dim3(256), 0, stream, p);
+  MZS_HIP(nullptr, hipGetLastError());
+  return MZS_OK;
+}
 
 extern "C" {
 
@@ -445,6 +466,57 @@ int mzs_tree_export(mzs_handle* h, const mzs_tree_view* out, void* stream_) {
   CP(out->embeddings, s.embeddings, BN * c.embed_dim);
 #undef CP
   return MZS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// training step of the default MLP trio
+// ---------------------------------------------------------------------------
+int64_t mzs_mlp_num_params(int32_t obs_dim, int32_t embed_dim, int32_t num_actions, int32_t support_size) {
+  int off[19];
+  mlp_offsets(obs_dim, embed_dim, num_actions, 2 * support_size + 1, off);
+  return off[18];
+}
+
+int64_t mzs_mlp_train_workspace_bytes(int32_t batch, int32_t obs_dim, int32_t embed_dim, int32_t num_actions,
+                                      int32_t support_size) {
+  const int64_t waves = 4 * (int64_t)((batch + 15) / 16);
+  return waves * (mzs_mlp_num_params(obs_dim, embed_dim, num_actions, support_size) + 1) * (int64_t)sizeof(float);
+}
+
+int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* stream_) {
+  if (!w || w->struct_size != (int32_t)sizeof(mzs_mlp_weights))
+    return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: null weights or size mismatch (ABI)");
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_train_args))
+    return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: null arguments or size mismatch (ABI)");
+  const float* const* ptrs = &w->repr_w;
+  for (int i = 0; i < 18; ++i)
+    if (!ptrs[i]) return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: null weight pointer");
+  if (a->batch <= 0 || a->unroll_steps <= 0) return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: batch and unroll_steps must be positive");
+  if (!a->obs || !a->actions || !a->rewards || !a->returns || !a->policy || !a->loss || !a->grads || !a->workspace)
+    return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: null batch / output / workspace pointer");
+  if (w->obs_dim <= 0 || w->obs_dim > 16) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: obs_dim must be 1..16");
+  const int A = a->num_actions, E = a->embed_dim, F = 2 * w->support_size + 1;
+  if (a->workspace_bytes < mzs_mlp_train_workspace_bytes(a->batch, w->obs_dim, E, A, w->support_size))
+    return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: workspace too small");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MZS_E_NODEVICE, "mzs_mlp_loss_grad: no HIP device (this library has no CPU fallback)");
+  if (a->device < 0 || a->device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_mlp_loss_grad: bad device ordinal");
+  MZS_HIP(nullptr, hipSetDevice(a->device));
+  mz::TrainParams p;
+  memset(&p, 0, sizeof p);
+  p.obs = a->obs; p.act = a->actions; p.rew = a->rewards; p.ret = a->returns; p.pi = a->policy;
+  for (int i = 0; i < 18; ++i) p.w[i] = ptrs[i];
+  mlp_offsets(w->obs_dim, E, A, F, p.off);
+  p.B = a->batch; p.L = a->unroll_steps; p.obs_dim = w->obs_dim; p.support = w->support_size;
+  p.loss_scale = a->loss_scale; p.l2 = a->l2_coeff;
+  p.ws = static_cast<float*>(a->workspace); p.grads = a->grads; p.loss = a->loss;
+  p.waves = 4 * ((a->batch + 15) / 16);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (A == 2 && E == 8 && F == 21) return launch_train<mz::TrainCfg<2, 8, 21>>(p, stream);
+  if (A == 4 && E == 32 && F == 21) return launch_train<mz::TrainCfg<4, 32, 21>>(p, stream);
+  if (A == 3 && E == 8 && F == 21) return launch_train<mz::TrainCfg<3, 8, 21>>(p, stream);
+  return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: no kernel instance for this (A, E, F)");
 }
 
 }  // extern "C"

@@ -72,3 +72,77 @@ def default_loss_fn(muzero_instance, batch: Transition, divide_by_length: bool =
     l2 = 0.5 * sum((p ** 2).sum() for m in muzero_instance.network if isinstance(m, torch.nn.Module)
                    for p in m.parameters())
     return loss + 1e-4 * l2
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP path: loss and gradients of the default MLP trio in one fused forward+backward kernel
+# (muax_amd/csrc/mz_train.cuh through the C-ABI entry mzs_mlp_loss_grad).
+# ---------------------------------------------------------------------------------------------------
+class FusedLossGrad:
+    """value_and_grad of the default loss (muax/loss.py:10-88 via muax/model.py:245-249) for the default
+    MLP trio.  The gradient comes back as ONE flat fp32 vector in the C-ABI's array order (that is also the
+    buffer a data-parallel all-reduce works on); `views` maps it onto the 18 parameters."""
+
+    def __init__(self, muzero_instance):
+        import ctypes as C
+
+        from . import _lib
+        from . import nn as mz_nn
+        if not mz_nn.is_default_mlp_trio(muzero_instance.network):
+            raise ValueError("the fused training step is built for the default MLP trio")
+        self.m, self._C, self._lib = muzero_instance, C, _lib
+        self._L = _lib.load()
+        params = mz_nn.mlp_trio_weights(muzero_instance.network)
+        self.params = [params[n] for n in _lib.MLP_WEIGHT_NAMES]
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("muax_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+        r, p, _ = muzero_instance.network
+        self.obs_dim, self.E, self.A = r.obs_dim, r.embedding_dim, p.num_actions
+        self.S = muzero_instance._support_size
+        n = int(self._L.mzs_mlp_num_params(self.obs_dim, self.E, self.A, self.S))
+        assert n == sum(x.numel() for x in self.params)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for x in self.params:
+            self.views.append(self.grads[off:off + x.numel()].view_as(x))
+            off += x.numel()
+        self._ws = None
+
+    def __call__(self, batch: Transition, divide_by_length: bool = False):
+        C, _lib, dev = self._C, self._lib, self.grads.device
+        t = lambda x, dt: torch.as_tensor(x, device=dev).to(dt).contiguous()  # noqa: E731
+        a = t(batch.a, torch.int32)
+        B, L = a.shape[:2]
+        a = a.reshape(B, L)
+        obs = t(batch.obs, torch.float32)[:, 0].reshape(B, -1).contiguous()
+        r, Rn = t(batch.r, torch.float32).reshape(B, L), t(batch.Rn, torch.float32).reshape(B, L)
+        pi = t(batch.pi, torch.float32).reshape(B, L, self.A)
+        if obs.shape[1] != self.obs_dim:
+            raise ValueError(f"batch.obs has {obs.shape[1]} features, the network takes {self.obs_dim}")
+        need = int(self._L.mzs_mlp_train_workspace_bytes(B, self.obs_dim, self.E, self.A, self.S))
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        w = _lib.MzsMlpWeights()
+        w.struct_size = C.sizeof(_lib.MzsMlpWeights)
+        w.obs_dim, w.support_size = self.obs_dim, self.S
+        w.discount = self.m._discount
+        keep = [x.detach().contiguous() for x in self.params]
+        for n, x in zip(_lib.MLP_WEIGHT_NAMES, keep):
+            setattr(w, n, x.data_ptr())
+        args = _lib.MzsTrainArgs()
+        args.struct_size = C.sizeof(_lib.MzsTrainArgs)
+        args.device = dev.index or 0
+        args.batch, args.unroll_steps, args.num_actions, args.embed_dim = B, L, self.A, self.E
+        args.obs, args.actions, args.rewards = obs.data_ptr(), a.data_ptr(), r.data_ptr()
+        args.returns, args.policy = Rn.data_ptr(), pi.data_ptr()
+        args.loss_scale = 1.0 / (B * L) if divide_by_length else 1.0 / B
+        args.l2_coeff = 1e-4
+        args.loss, args.grads = self.loss.data_ptr(), self.grads.data_ptr()
+        args.workspace, args.workspace_bytes = self._ws.data_ptr(), self._ws.numel() * 4
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(self._L.mzs_mlp_loss_grad(C.byref(w), C.byref(args), stream))
+        self._keep = (obs, a, r, Rn, pi, keep)
+        return self.loss, self.grads

@@ -76,6 +76,7 @@ class MuZero:
         self.capture_graph = bool(capture_graph)
         self._params = None
         self._opt_state = None
+        self._fused_train = None
         self._fused = {}
         self._weights_version = 0
 
@@ -273,10 +274,13 @@ class MuZero:
         return action
 
     # ------------------------------------------------------------------ next tier
-    def update(self, batch, *args, **kwargs):
+    def update(self, batch, *args, backend: str = "auto", **kwargs):
         """muax/model.py:181-201: one gradient step on a batch of k-step trajectories; returns
-        {'loss': float}.  INTERIM: torch autograd + torch.optim, with the
-        data-parallel gradient mean as ONE flat all-reduce when torch.distributed is initialised."""
+        {'loss': float}.  With the default MLP trio and the default loss the loss and all gradients come from
+        ONE fused forward+backward HIP kernel (mzs_mlp_loss_grad, muax_amd/csrc/mz_train.cuh) into a flat
+        vector; the data-parallel gradient mean is then one all-reduce of that vector (RCCL on GPUs) and the
+        optimiser (muax/optimizers.py mirror on torch.optim) consumes views of it.  Plugin nets or a custom
+        loss_fn take the torch autograd route (backend="torch" forces it; "hip" refuses to fall back)."""
         from . import loss as mz_loss
         from . import optimizers as mz_opt
         from .sharding import allreduce_mean_flat
@@ -287,10 +291,28 @@ class MuZero:
             self._optimizer = mz_opt.create_optimizer()
         if self._optimizer.opt is None:
             self._opt_state = self._optimizer.init(params)
-        loss_fn = self.loss_fn or mz_loss.default_loss_fn
-        loss = loss_fn(self, batch, *args, **kwargs)
-        loss.backward()
-        allreduce_mean_flat([p.grad for p in params])
+        fused = backend != "torch" and self.loss_fn is None and self.device.type == "cuda" \
+            and mz_nn.is_default_mlp_trio(self.network) and (self.repr_func.obs_dim or 99) <= 16 \
+            and not kwargs.get("pi_all_pairs", False)
+        if backend == "hip" and not fused:
+            raise ValueError("backend='hip' needs the default MLP trio on a GPU and the default loss")
+        if fused:
+            try:
+                if self._fused_train is None:
+                    self._fused_train = mz_loss.FusedLossGrad(self)
+                loss, flat = self._fused_train(batch, divide_by_length=kwargs.get("divide_by_length", False))
+                allreduce_mean_flat([flat])
+                for p, g in zip(self._fused_train.params, self._fused_train.views):
+                    p.grad = g
+            except ValueError as e:
+                if backend == "hip" or "no kernel instance" not in str(e):
+                    raise
+                fused = False
+        if not fused:
+            loss_fn = self.loss_fn or mz_loss.default_loss_fn
+            loss = loss_fn(self, batch, *args, **kwargs)
+            loss.backward()
+            allreduce_mean_flat([p.grad for p in params])
         self._optimizer.step()
         self._opt_state = self._optimizer.opt.state_dict()
         self._weights_version += 1

@@ -111,7 +111,7 @@ struct FusedCfg {
   static constexpr int H = kHidden;
   static constexpr int ES = (E + 15) / 16, FS = (F + 15) / 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
-  //   [SEL0  ..) A x {child index, cached pUCT score}
+  //   [SEL0  ..) A x {child index, cached pUCT score}   (4-byte aligned only: the stride is odd)
   //   [HDR0  ..) visits, value, JUMP word, raw value
   //   [ST0   ..) A x {prob, value, visits, reward[, prior logit (Gumbel)]}; children_discounts is the
   //              constant discount on expanded edges and multiplies a zero value on the others
@@ -130,8 +130,10 @@ struct FusedCfg {
   static constexpr int ENTRY_ACT_SHIFT = ENTRY_BITS == 8 ? 6 : 12;
   static constexpr int PATH0 = EMB0 + (EMB_LDS ? E : 0);
   static constexpr int PATHW = (NMAX * ENTRY_BITS + 31) / 32;
-  static constexpr int NS = ((PATH0 + PATHW + 3) / 4) * 4;
-  static constexpr int TREE_WORDS = NS * NMAX;
+  // odd record stride: lane e of the backup reads node(e)'s record, and with an odd stride the 16 records
+  // of a row start in 16 different LDS banks (a stride of 40 words put them in 4)
+  static constexpr int NS = (PATH0 + PATHW) | 1;
+  static constexpr int TREE_WORDS = ((NS * NMAX + 3) / 4) * 4;
   static constexpr int PATH_WORDS = 0;
   static constexpr int NOISE_WORDS = 0;
   static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   // all-zero records written 16 bytes per lane, then children_index = -1 (same wave: LDS keeps the order)
   {
     int4* q4 = reinterpret_cast<int4*>(itree);
-    const int nq = N * (NS / 4);
+    const int nq = (N * NS + 3) / 4;
     for (int q = j; q < nq; q += 16) q4[q] = make_int4(0, 0, 0, 0);
     for (int n = j; n < N; n += 16) {
 #pragma unroll

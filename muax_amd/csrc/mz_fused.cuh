@@ -139,7 +139,10 @@ struct FusedCfg {
   static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
   static_assert(A <= PATHW, "the root's (empty) path slot holds its Gumbel noise");
   static_assert(PATHW <= 16, "a node's path is copied by one lane per word");
-  static constexpr int ROOT_WORDS = TREE_WORDS + PATH_WORDS + NOISE_WORDS;
+  // the four roots of a wave start 8 banks apart: row-uniform reads of the same field of four trees
+  // (selection, expansion) then hit four different banks
+  static constexpr int pad_root(int w) { return w + ((8 - w % 32 + 32) % 32); }
+  static constexpr int ROOT_WORDS = pad_root(TREE_WORDS + PATH_WORDS + NOISE_WORDS);
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
   static constexpr int TBL_WORDS = 2 * (((NMAX + 2 + 3) / 4) * 4);  // {sqrt(n) pb_c(n), 1/n} pairs
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);

@@ -17,25 +17,12 @@ muax/loss.py:60-61).  Reference quirks handled explicitly:
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import Any
 
 import torch
 
 from . import utils as mx_utils
-
-
-@dataclass
-class Transition:
-    """muax/episode_tracer.py:41-56, batched: every field is [B, L, ...]."""
-    obs: Any = 0.
-    a: Any = 0
-    r: Any = 0.
-    done: Any = False
-    Rn: Any = 0.
-    v: Any = 0.
-    pi: Any = 0.
-    w: Any = 1.
+from .episode_tracer import Transition  # noqa: F401  (muax.episode_tracer.Transition)
 
 
 def softmax_cross_entropy(logits, labels):

@@ -331,3 +331,10 @@ class MuZero:
                 m.load_state_dict(saved["params"][n])
             self._opt_state = saved.get("optimizer_state")
             self._weights_version += 1
+
+    def save(self, file):
+        """muax/model.py `save`: parameters + optimiser state to `file`."""
+        self.save_load(file, save=True)
+
+    def load(self, file):
+        self.save_load(file, save=False)

@@ -4,14 +4,19 @@
 What the reference's loops pin and this module reproduces: one `split` of the key per environment
 step, the act() call contract, the temperature schedule, greedy evaluation at temperature 0.  The
 batched variants (`rollout_batched`) are what the metric measures: B environments stepped in lock step,
-one batched act() per step.  The learning half of fit() (tracer, replay buffer, loss, optimiser) is the
-next tier.
+one batched act() per step.  `fit` is the reference's whole loop (muax/train.py:26-241): acting through the HIP
+search, the n-step tracer and trajectory buffer on the host, `model.update` on the fused HIP training kernel.
 """
 from __future__ import annotations
+
+import os
+import time
 
 import numpy as np
 
 from . import prng
+from .episode_tracer import PNStep
+from .replay_buffer import Trajectory, TrajectoryReplayBuffer
 
 
 def _temperature_fn(max_training_steps, training_steps):
@@ -71,3 +76,116 @@ def rollout_batched(model, envs, key, steps: int, num_simulations: int = 50, tem
         obs, r, done = envs.step(a)
         returns += r
     return steps * obs.shape[0], returns
+
+
+def _episode(model, env, tracer, key, num_simulations, temperature, reset_kwargs=None, on_transition=None):
+    """Acting half of one fit() episode (muax/train.py:150-173,181-204): one key split and one act() per
+    environment step, tracer -> trajectory."""
+    obs, info = env.reset(**(reset_kwargs or {}))
+    tracer.reset()
+    trajectory = Trajectory()
+    for t in range(env.spec.max_episode_steps):
+        key, subkey = prng.split(key)
+        a, pi, v = model.act(subkey, obs, with_pi=True, with_value=True, obs_from_batch=False,
+                             num_simulations=num_simulations, temperature=temperature)
+        obs_next, r, done, truncated, info = env.step(a)
+        tracer.add(obs, a, r, done or truncated, v=v, pi=pi)
+        while tracer:
+            trans = tracer.pop()
+            trajectory.add(trans)
+            if on_transition is not None:
+                on_transition(trans)
+        if done or truncated:
+            break
+        obs = obs_next
+    trajectory.finalize()
+    return trajectory, key
+
+
+def fit(model, env_id=None, env=None, test_env=None, tracer=None, buffer=None, max_episodes: int = 1000,
+        test_interval: int = 10, num_test_episodes: int = 10, max_training_steps: int = 10000,
+        save_every_n_epochs: int = 1, num_simulations: int = 50, k_steps: int = 10, buffer_warm_up: int = 128,
+        num_trajectory: int = 32, sample_per_trajectory: int = 10, name: str = None, tensorboard_dir=None,
+        model_save_path=None, save_name=None, random_seed: int = 42, temperature_fn=_temperature_fn,
+        log_all_metrics=False, num_update_per_episode: int = 50, metrics=None):
+    """muax/train.py:26-241 with the same arguments, defaults and return value (the path of the best
+    checkpoint).  The TrainMonitor / tensorboard side of the reference is not rebuilt (`name`,
+    `tensorboard_dir`, `log_all_metrics` are accepted and ignored); pass a list as `metrics` to receive one
+    dict per episode (`loss`, `G`, `training_step`, `test_G`)."""
+    if env_id is None and env is None:
+        raise ValueError("You must provide either `env_id` or `env`.")
+    if env_id is not None and env is not None:
+        raise ValueError("You can only provide either `env_id` or `env`, not both.")
+    if env is None:
+        try:
+            import gymnasium as gym
+        except ImportError:
+            try:
+                import gym
+            except ImportError:
+                raise ValueError("`env_id` needs gymnasium (or gym), which is not installed: pass `env` and `test_env`") from None
+        env = gym.make(env_id, render_mode="rgb_array")
+        if test_env is None:
+            test_env = gym.make(env_id, render_mode="rgb_array")
+    if test_env is None:
+        raise ValueError("You must provide `test_env` when using a custom `env`.")
+    tracer = tracer if tracer is not None else PNStep(50, 0.997, 0.5)
+    buffer = buffer if buffer is not None else TrajectoryReplayBuffer(500)
+    save_name = save_name or "model_params"
+    model_dir = model_save_path or os.path.join("models", time.strftime("%Y-%m-%d_%H-%M-%S"))
+
+    sample_input = np.expand_dims(np.asarray(env.observation_space.sample()), 0).astype(float)
+    key = prng.PRNGKey(random_seed)
+    key, test_key, subkey = prng.split(key, 3)
+    model.init(subkey, sample_input)
+
+    training_step, best_test_G, model_path = 0, -float("inf"), None
+    while len(buffer) < buffer_warm_up:  # buffer warm up (muax/train.py:148-173)
+        temperature = temperature_fn(max_training_steps=max_training_steps, training_steps=training_step)
+        trajectory, key = _episode(model, env, tracer, key, num_simulations, temperature)
+        if len(trajectory) >= k_steps:
+            buffer.add(trajectory, trajectory.batched_transitions.w.mean())
+
+    for ep in range(max_episodes):
+        temperature = temperature_fn(max_training_steps=max_training_steps, training_steps=training_step)
+        G = [0.0]
+
+        def on_transition(trans):
+            G[0] += float(trans.r)
+
+        trajectory, key = _episode(model, env, tracer, key, num_simulations, temperature,
+                                   {"seed": random_seed}, on_transition)
+        if len(trajectory) >= k_steps:
+            buffer.add(trajectory, trajectory.batched_transitions.w.mean())
+        train_loss = 0.0
+        for _ in range(num_update_per_episode):
+            batch = buffer.sample(num_trajectory=num_trajectory, sample_per_trajectory=sample_per_trajectory,
+                                  k_steps=k_steps)
+            train_loss += model.update(batch)["loss"]
+            training_step += 1
+        train_loss /= num_update_per_episode
+        row = {"episode": ep, "loss": train_loss, "G": G[0], "training_step": training_step}
+        if ep % save_every_n_epochs == 0:
+            folder = os.path.join(model_dir, f"epoch_{ep:04d}_loss_{train_loss:.8f}")
+            os.makedirs(folder, exist_ok=True)
+            cur_path = os.path.join(folder, save_name)
+            model.save(cur_path)
+            if not model_path:
+                model_path = cur_path
+        if training_step >= max_training_steps:
+            if metrics is not None:
+                metrics.append(row)
+            return model_path
+        if ep % test_interval == 0:
+            test_G = test(model, test_env, test_key, num_simulations=num_simulations,
+                          num_test_episodes=num_test_episodes)
+            row["test_G"] = test_G
+            if test_G >= best_test_G:
+                best_test_G = test_G
+                folder = os.path.join(model_dir, f"epoch_{ep:04d}_test_G_{test_G:.8f}")
+                os.makedirs(folder, exist_ok=True)
+                model_path = os.path.join(folder, save_name)
+                model.save(model_path)
+        if metrics is not None:
+            metrics.append(row)
+    return model_path

@@ -252,3 +252,31 @@ def test_resnet_plugin_nets_drive_the_stepwise_search():
         assert a.shape == (6,) and pi.shape == (6, 18) and v.shape == (6,)
         assert (pi * 12 == np.round(pi * 12)).all() and np.allclose(pi.sum(1), 1, atol=1e-6)
         assert np.allclose(v, v2, rtol=1e-4, atol=1e-5) and (pi == pi2).mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_fit_runs_end_to_end_on_the_hip_paths(tmp_path):
+    """muax.fit's whole loop: HIP search for acting, tracer/buffer on the host, fused HIP training step."""
+
+    class Env(_ToyEnv):
+        class observation_space:
+            @staticmethod
+            def sample():
+                return np.zeros(4, F32)
+
+        def reset(self, seed=None):
+            return super().reset()
+
+    g = torch.Generator().manual_seed(0)
+    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
+                          mx.nn.Dynamic(8, 2, 21, generator=g))
+    model = mx.MuZero(net, optimizer=mx.optimizers.create_optimizer("adam", 5e-3))
+    rows = []
+    path = mx.fit(model, env=Env(), test_env=Env(), tracer=mx.PNStep(5, 0.99, 0.5), buffer=mx.TrajectoryReplayBuffer(50),
+                  max_episodes=3, test_interval=1, num_test_episodes=2, max_training_steps=1000, num_simulations=8,
+                  k_steps=4, buffer_warm_up=4, num_trajectory=8, sample_per_trajectory=2, num_update_per_episode=10,
+                  model_save_path=str(tmp_path), metrics=rows)
+    assert path is not None and os.path.exists(path) and len(rows) == 3
+    assert all(np.isfinite(r["loss"]) and "test_G" in r for r in rows) and rows[-1]["training_step"] == 30
+    assert rows[-1]["loss"] < rows[0]["loss"] and model._fused_train is not None  # the HIP training kernel ran
+    model.load(path)

@@ -211,6 +211,42 @@ struct RowLinearOneHot {
   }
 };
 
+// the two first layers of Dynamic (reward net, next-state net) share their input: their weights are
+// kept as (reward, state) pairs from the start, the operand form of v_pk_fma_f32
+template <int E, int A>
+struct RowLinearOneHot2 {
+  f32x2 w[E];
+  f32x2 wa[A];
+  f32x2 b;
+  MZ_DEV void load(const float* __restrict__ W0, const float* __restrict__ B0, const float* __restrict__ W1,
+                   const float* __restrict__ B1, int j) {
+    b = (f32x2){B0[j], B1[j]};
+    StaticFor<0, E>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      w[i] = (f32x2){W0[i * kHidden + j], W1[i * kHidden + j]};
+    });
+    StaticFor<0, A>::run([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      wa[a] = (f32x2){W0[(E + a) * kHidden + j], W1[(E + a) * kHidden + j]};
+    });
+  }
+};
+
+// first layers of Prediction (value net, policy net): (value, policy) weight pairs
+template <int E>
+struct RowLinearPair {
+  f32x2 w[E];
+  f32x2 b;
+  MZ_DEV void load(const float* __restrict__ W0, const float* __restrict__ B0, const float* __restrict__ W1,
+                   const float* __restrict__ B1, int j) {
+    b = (f32x2){B0[j], B1[j]};
+    StaticFor<0, E>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      w[i] = (f32x2){W0[i * kHidden + j], W1[i * kHidden + j]};
+    });
+  }
+};
+
 // jax.nn.softmax over a row-distributed vector of N elements (N <= 32).  For
 // N < 16 the result is only valid in lanes < 2^ceil(log2 N) (all that is used).
 template <int N>
@@ -274,31 +310,41 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
 
 template <class C>
 struct Nets {
-  RowLinear<C::E, kHidden> pv1, pp1;
+  RowLinearPair<C::E> p1;  // (pv1, pp1)
   RowLinear<kHidden, C::F> pv2;
   RowLinear<kHidden, C::A> pp2;
-  RowLinearOneHot<C::E, C::A> dr1, dn1;
+  RowLinearOneHot2<C::E, C::A> d1;  // (dr1, dn1)
   RowLinear<kHidden, C::F> dr2;
   RowLinear<kHidden, C::E> dn2;
 
   MZ_DEV void load(const FusedParams& p, int j) {
-    pv1.load(p.pv_w1, p.pv_b1, j); pv2.load(p.pv_w2, p.pv_b2, j);
-    pp1.load(p.pp_w1, p.pp_b1, j); pp2.load(p.pp_w2, p.pp_b2, j);
-    dr1.load(p.dr_w1, p.dr_b1, j); dr2.load(p.dr_w2, p.dr_b2, j);
-    dn1.load(p.dn_w1, p.dn_b1, j); dn2.load(p.dn_w2, p.dn_b2, j);
+    p1.load(p.pv_w1, p.pv_b1, p.pp_w1, p.pp_b1, j);
+    pv2.load(p.pv_w2, p.pv_b2, j); pp2.load(p.pp_w2, p.pp_b2, j);
+    d1.load(p.dr_w1, p.dr_b1, p.dn_w1, p.dn_b1, j);
+    dr2.load(p.dr_w2, p.dr_b2, j); dn2.load(p.dn_w2, p.dn_b2, j);
   }
   // Prediction (muax/nn.py:73-90) + value decode
   MZ_DEV void predict(const float (&s)[C::ES], int j, int support, float& value,
                       float& pi_logit) const {
-    float h[1], v_logits[C::FS], pl[1];
-    pv1.apply(s, h);
-    h[0] = elu(h[0]);
-    pv2.apply(h, v_logits);
-    float g[1];
-    pp1.apply(s, g);
-    g[0] = elu(g[0]);
-    pp2.apply(g, pl);
-    pi_logit = pl[0];
+    // same packed chains as forward() below: every weight register then has ONE pairing in the whole
+    // kernel (a second, scalar use made the compiler re-pair them through scratch memory)
+    static_assert(C::FS == 2, "support logits are handled as two lane slots");
+    f32x2 g = splat2(0.0f);
+    StaticFor<0, C::E>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      g = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), p1.w[i], g);
+    });
+    g = elu2(g + p1.b);
+    f32x2 vl = splat2(0.0f);
+    float pl = 0.0f;
+    StaticFor<0, kHidden>::run([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      vl = fma2(splat2(bcast<i>(g.x)), (f32x2){pv2.w[i][0], pv2.w[i][1]}, vl);
+      pl = __builtin_fmaf(bcast<i>(g.y), pp2.w[i][0], pl);
+    });
+    vl = vl + (f32x2){pv2.b[0], pv2.b[1]};
+    pi_logit = pl + pp2.b[0];
+    float v_logits[C::FS] = {vl.x, vl.y};
     value = row_decode<C::F>(v_logits, j, support);
   }
   // ---- the per-simulation pass: Dynamic (muax/nn.py:93-115) on (s, action), Prediction
@@ -315,13 +361,15 @@ struct Nets {
     f32x2 h = splat2(0.0f);
     StaticFor<0, E>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      h = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), (f32x2){dr1.w[i], dn1.w[i]}, h);
+      h = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), d1.w[i], h);
     });
     {
-      f32x2 wsel = (f32x2){dr1.wa[0], dn1.wa[0]};
-#pragma unroll
-      for (int a = 1; a < A; ++a) wsel = (action == a) ? (f32x2){dr1.wa[a], dn1.wa[a]} : wsel;
-      h = (h + wsel) + (f32x2){dr1.b, dn1.b};
+      f32x2 wsel = d1.wa[0];
+      StaticFor<1, A>::run([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        wsel = (action == a) ? d1.wa[a] : wsel;
+      });
+      h = (h + wsel) + d1.b;
     }
     h = elu2(h);
     // second layer: reward logits (two slots, packed) and next state
@@ -346,9 +394,9 @@ struct Nets {
     f32x2 g = splat2(0.0f);
     StaticFor<0, E>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      g = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), (f32x2){pv1.w[i][0], pp1.w[i][0]}, g);
+      g = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), p1.w[i], g);
     });
-    g = elu2(g + (f32x2){pv1.b[0], pp1.b[0]});
+    g = elu2(g + p1.b);
     f32x2 vl = splat2(0.0f);
     float pl = 0.0f;
     StaticFor<0, kHidden>::run([&](auto ic) {

@@ -761,3 +761,27 @@ void mzo_act_mlp(const mzo_mlp *m, const mzo_search_cfg *cfg, mzo_tree *t,
   }
   free(sim_keys);
 }
+
+/* see mz_oracle.h: exhaustive check of the small-integer Markstein division used by the HIP kernel */
+int64_t mzo_markstein_mismatches(int dmax, int exponent) {
+  int64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic)
+  for (int d = 1; d <= dmax; ++d) {
+    const float fd = (float)d;
+    volatile float yv = 1.0f / fd;
+    const float y = yv;
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+      uint32_t bits = ((uint32_t)(127 + exponent) << 23) | m;
+      for (int sgn = 0; sgn < 2; ++sgn) {
+        uint32_t b2 = bits | ((uint32_t)sgn << 31);
+        float x;
+        memcpy(&x, &b2, 4);
+        const float q0 = x * y;
+        const float r = fmaf(-q0, fd, x);
+        const float q = fmaf(r, y, q0);
+        bad += (q != x / fd);
+      }
+    }
+  }
+  return bad;
+}

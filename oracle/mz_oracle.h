@@ -156,6 +156,14 @@ void mzo_act_mlp(const mzo_mlp *m, const mzo_search_cfg *cfg, mzo_tree *t,
                  const float *gumbel, int32_t *action_out, float *action_weights_out,
                  float *root_value_out, int64_t *depth_sum_out, int nthreads);
 
+/* ---- checker for a kernel-side identity (test infrastructure, not part of the restatement) ----
+ * muax_amd/csrc/mz_fused.cuh divides by small integers d (visit counts) as
+ *   q0 = x * y;  r = fma(-q0, d, x);  q = fma(r, y, q0)     with y = RN(1 / d)   (Markstein)
+ * where this oracle writes x / d.  Returns how many of the 2^24 binary32 values of the given exponent
+ * (every mantissa, both signs) give q != x / d, summed over d = 1 .. dmax.  0 means the two agree for
+ * every normal x (scaling by a power of two changes neither side). */
+int64_t mzo_markstein_mismatches(int dmax, int exponent);
+
 #ifdef __cplusplus
 }
 #endif

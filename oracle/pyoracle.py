@@ -25,8 +25,9 @@ _i64p = C.POINTER(C.c_int64)
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc if the shared object is missing."""
-    if force or not os.path.exists(_SO):
+    """Compile the oracle with gcc (make decides from the time stamps whether anything is to do)."""
+    if force or not os.path.exists(_SO) or os.path.exists(os.path.join(_HERE, "mz_oracle.c")) and \
+            os.path.getmtime(os.path.join(_HERE, "mz_oracle.c")) > os.path.getmtime(_SO):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
@@ -100,6 +101,8 @@ def lib():
         L.mzo_random_bits.restype = C.c_uint32
         L.mzo_random_bits.argtypes = [_u32p, C.c_int64, C.c_int64]
         L.mzo_select_action.restype = C.c_int
+        L.mzo_markstein_mismatches.restype = C.c_int64
+        L.mzo_markstein_mismatches.argtypes = [C.c_int, C.c_int]
         for name in ("mzo_softmax", "mzo_min_max_normalize", "mzo_threefry2x32", "mzo_split",
                      "mzo_root_inference", "mzo_recurrent_inference", "mzo_root_prior",
                      "mzo_tree_init", "mzo_simulate", "mzo_expand", "mzo_backward",
@@ -157,6 +160,11 @@ def min_max_normalize(s):
     s = np.array(s, np.float32, copy=True)
     lib().mzo_min_max_normalize(_p(s, _f32p), C.c_int(s.size))
     return s
+
+
+def markstein_mismatches(dmax=300, exponent=0):
+    """Exhaustive check of the kernel's small-integer division identity (see mz_oracle.h)."""
+    return int(lib().mzo_markstein_mismatches(dmax, exponent))
 
 
 def threefry2x32(key, x0, x1):

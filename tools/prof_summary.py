@@ -14,7 +14,7 @@ for db in sorted(glob.glob(os.path.join(out, "*", "*_results.db"))):
         lines.append("== kernel trace (rocprofv3 --kernel-trace --stats) ==")
         lines.append(f"{'calls':>6} {'avg_us':>10} {'total_us':>12} {'pct':>6}  kernel")
         for n, calls, tot, avg, pct in cur.execute(
-                "select name,total_calls,total_duration,average,percentage from top_kernels"):
+                "select name,total_calls,total_duration,average,percentage from top_kernels limit 12"):
             lines.append(f"{calls:6d} {avg / 1e3 if avg > 1e4 else avg:10.2f} {tot / 1e3 if avg > 1e4 else tot:12.2f} {pct:6.2f}  {n[:110]}")
         for r in cur.execute("select name, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, grid_x, workgroup_x, "
                              "avg(duration), count(*) from kernels where name like 'void mz::%' group by name"):

@@ -179,6 +179,31 @@ int64_t mzs_mlp_train_workspace_bytes(int32_t batch, int32_t obs_dim, int32_t em
 /* errors: mzs_last_error(NULL) */
 int mzs_mlp_loss_grad(const mzs_mlp_weights *w, const mzs_train_args *a, void *stream);
 
+/* ---- next-state tower of the ResNet dynamics net ----
+ * mzs_resnet_tower evaluates, for a batch of 6x6x64 hidden states (NHWC, the reference's embedding
+ * layout), what muax/nn.py:344-378 calls ns_func followed by min_max_normalize2d: conv1x1 on
+ * [s, a / num_actions] + relu, `blocks` x ResidualConvBlockV1(64, stride 1, projection)
+ * (muax/nn.py:118-148: 3 x conv3x3 + LayerNorm over (H, W, C)), per-channel min-max normalisation -- one
+ * kernel, one workgroup per root, fp32 MFMA.  Weights stay in haiku's layouts:
+ *   stem_w  [65][64]                 (hk.Conv2D 1x1, HWIO)  or NULL to skip the stem
+ *   conv_w  [blocks][3][3][3][64][64]  order inside a block: projection conv, conv_0, conv_1 (HWIO each)
+ *   ln      [blocks][3][2][64]        (scale, offset) of the projection's, ln_0's, ln_1's LayerNorm */
+typedef struct mzs_tower_args {
+  int32_t struct_size;     /* = sizeof(mzs_tower_args) */
+  int32_t device;
+  int32_t batch;
+  int32_t blocks;
+  int32_t normalize;       /* != 0: apply min_max_normalize2d at the end */
+  int32_t num_actions;     /* the action plane is a / num_actions */
+  const float *x;          /* [B, 6, 6, 64] */
+  const int32_t *action;   /* [B] (needed with stem_w) */
+  const float *stem_w;
+  const float *conv_w;
+  const float *ln;
+  float *y;                /* [B, 6, 6, 64] out */
+} mzs_tower_args;
+int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

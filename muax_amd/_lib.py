@@ -60,11 +60,17 @@ class MzsTrainArgs(C.Structure):
                 ("workspace", _vp), ("workspace_bytes", C.c_int64)]
 
 
+class MzsTowerArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("blocks", C.c_int32),
+                ("normalize", C.c_int32), ("num_actions", C.c_int32), ("x", _vp), ("action", _vp),
+                ("stem_w", _vp), ("conv_w", _vp), ("ln", _vp), ("y", _vp)]
+
+
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
-                    "mzs_mlp_train_workspace_bytes"]
+                    "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower"]
 
 _lib = None
 
@@ -94,6 +100,7 @@ def load(build_if_missing: bool = True):
     L.mzs_finish.argtypes = [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mzs_tree_export.argtypes = [_vp, C.POINTER(MzsTreeView), _vp]
     L.mzs_mlp_loss_grad.argtypes = [C.POINTER(MzsMlpWeights), C.POINTER(MzsTrainArgs), _vp]
+    L.mzs_resnet_tower.argtypes = [C.POINTER(MzsTowerArgs), _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4
     L.mzs_mlp_train_workspace_bytes.argtypes = [C.c_int32] * 5
     for n in EXPORTED_SYMBOLS[2:]:

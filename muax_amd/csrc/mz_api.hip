@@ -12,6 +12,7 @@
 #include "mz_fused.cuh"
 #include "mz_step.cuh"
 #include "mz_train.cuh"
+#include "mz_conv.cuh"
 
 namespace {
 
@@ -517,6 +518,32 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
   if (A == 4 && E == 32 && F == 21) return launch_train<mz::TrainCfg<4, 32, 21>>(p, stream);
   if (A == 3 && E == 8 && F == 21) return launch_train<mz::TrainCfg<3, 8, 21>>(p, stream);
   return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: no kernel instance for this (A, E, F)");
+}
+
+// ---------------------------------------------------------------------------
+// ResNet dynamics: next-state tower
+// ---------------------------------------------------------------------------
+int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_tower_args))
+    return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: null arguments or size mismatch (ABI)");
+  if (a->batch <= 0 || a->blocks < 0) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: batch / blocks");
+  if (!a->x || !a->y || (a->blocks > 0 && (!a->conv_w || !a->ln)))
+    return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: null tensor pointer");
+  if (a->stem_w && (!a->action || a->num_actions <= 0))
+    return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: the stem needs actions and num_actions");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MZS_E_NODEVICE, "mzs_resnet_tower: no HIP device (this library has no CPU fallback)");
+  if (a->device < 0 || a->device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: bad device ordinal");
+  MZS_HIP(nullptr, hipSetDevice(a->device));
+  mz::TowerParams p;
+  p.x = a->x; p.action = a->action; p.stem_w = a->stem_w; p.conv_w = a->conv_w; p.ln = a->ln; p.y = a->y;
+  p.inv_num_actions = a->stem_w ? 1.0f / (float)a->num_actions : 0.0f;
+  p.B = a->batch; p.blocks = a->blocks; p.normalize = a->normalize;
+  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + 4);
+  hipLaunchKernelGGL(mz::mz_resnet_tower_kernel, dim3(a->batch), dim3(256), lds, static_cast<hipStream_t>(stream_), p);
+  MZS_HIP(nullptr, hipGetLastError());
+  return MZS_OK;
 }
 
 }  // extern "C"

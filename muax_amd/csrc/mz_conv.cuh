@@ -1,0 +1,225 @@
+// mz_conv.cuh -- the next-state tower of the ResNet dynamics net (muax/nn.py:344-378 with the residual
+// block of muax/nn.py:118-148) as ONE kernel: conv1x1 stem, `blocks` x ResidualConvBlockV1(64, projection)
+// = 3 x (conv3x3 + LayerNorm) each, min_max_normalize2d.  SURVEY.md 8(f) n3: this tower is 98 % of the
+// flops of BASELINE config 4's recurrent_fn (24 of its 3x3 convolutions, 6x6x64 maps).
+//
+// One workgroup owns one root's 6x6x64 map, which never leaves the CU: two zero-haloed 8x8-pixel buffers in
+// LDS (pixel stride 65 words, so the 16 pixels of an MFMA tile sit in 16 different banks).  A 3x3
+// convolution is an implicit GEMM  out[36 px (padded to 48)][64 co] = sum_{tap, ci} in[px + tap][ci] W[tap][ci][co]
+// on v_mfma_f32_16x16x4_f32: wave w owns output channels 16 w .. 16 w + 15 for all three pixel tiles
+// (12 accumulator registers); per k-step of 4 input channels it fetches ONE weight register from L2
+// (haiku's HWIO layout is already [k][co]) and three activation registers from LDS.  LayerNorm over the
+// whole map (two-pass mean / variance, as jnp.var) needs two workgroup reductions per convolution; the
+// projection shortcut stays in registers until the block's final add.  fp32 throughout (the search's
+// parity bar is 1e-5 on values): 65 MFLOP per root and simulation at the fp32-MFMA rate.
+//
+// Floating-point kernel: checked against the torch modules of muax_amd/nn.py (tests), tolerance there.
+#pragma once
+#include "mz_train.cuh"  // f32x4
+
+#pragma clang fp contract(off)
+
+namespace mz {
+
+struct TowerParams {
+  const float* x;          // [B][36][64]  NHWC hidden state s
+  const int32_t* action;   // [B] (stem only)
+  const float* stem_w;     // [65][64] 1x1 conv on [s, a / num_actions] (HWIO), or nullptr: no stem
+  const float* conv_w;     // [blocks][3][9][64][64]  (projection, conv_0, conv_1), HWIO per conv
+  const float* ln;         // [blocks][3][2][64]      (scale, offset) of proj_ln, ln_0, ln_1
+  float* y;                // [B][36][64]
+  float inv_num_actions;
+  int B, blocks, normalize;
+};
+
+constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 65;
+// one haloed map + an always-zero tail of 19 pixels: the rows that pad a 36-pixel map to three 16-row MFMA
+// tiles read their 3x3 windows from the tail
+constexpr int kTailPix = 2 * kHalo + 2 + 1;
+constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
+
+MZ_DEV float wg_sum(float v, float* red, int wave, int lane) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m);
+  __syncthreads();  // previous use of red[] is over
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// acc[mt] (+)= conv3x3 of the haloed map `in` with W[9][64][64], this wave's 16 output channels
+MZ_DEV void conv3x3_tile(const float* in, const float* __restrict__ W, const int (&abase)[3], int wcol,
+                         f32x4 (&acc)[3]) {
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int tap = 0; tap < 9; ++tap) {
+    const int toff = ((tap / 3) * kHalo + (tap % 3)) * kPixStride;
+    const float* wt = W + (size_t)tap * kTowerC * kTowerC + wcol;
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+      const float b = wt[c4 * 4 * kTowerC];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[abase[mt] + toff + 4 * c4], b, acc[mt], 0, 0, 0);
+    }
+  }
+}
+
+// hk.LayerNorm(axis=(-3,-2,-1)) over the root's 36 x 64 map, scale / offset per channel; optional relu
+MZ_DEV void layer_norm_tile(f32x4 (&acc)[3], const float* __restrict__ so, int ch, int lane, int wave,
+                            float* red, bool relu) {
+  const int g = lane >> 4;
+  float s = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s = s + ((16 * mt + 4 * g + v < kTowerPix) ? acc[mt][v] : 0.0f);
+  const float mean = wg_sum(s, red, wave, lane) * (1.0f / (kTowerPix * kTowerC));
+  float q = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float d = acc[mt][v] - mean;
+      q = q + ((16 * mt + 4 * g + v < kTowerPix) ? d * d : 0.0f);
+    }
+  const float var = wg_sum(q, red, wave, lane) * (1.0f / (kTowerPix * kTowerC));
+  const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
+  const float sc = so[ch], of = so[kTowerC + ch];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float o = (acc[mt][v] - mean) * rstd * sc + of;
+      acc[mt][v] = relu ? fmaxf(o, 0.0f) : o;
+    }
+}
+
+MZ_DEV void store_map(const f32x4 (&acc)[3], float* buf, int ch, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int p = 16 * mt + 4 * g + v;
+      if (p < kTowerPix) buf[((p / kTowerHW + 1) * kHalo + p % kTowerHW + 1) * kPixStride + ch] = acc[mt][v];
+    }
+}
+
+__global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
+  extern __shared__ float lds[];
+  float* bufA = lds;
+  float* bufB = lds + kBufWords;
+  float* red = lds + 2 * kBufWords;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x;
+  for (int i = tid; i < 2 * kBufWords; i += 256) lds[i] = 0.0f;
+  __syncthreads();
+  const float* xin = p.x + (size_t)r * kTowerPix * kTowerC;
+  for (int i = tid; i < kTowerPix * kTowerC; i += 256) {
+    const int px = i >> 6, c = i & 63;
+    bufA[((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride + c] = xin[i];
+  }
+  __syncthreads();
+
+  // A operand: lane (m = lane & 15, kk = lane >> 4) reads pixel 16 mt + m, input channel 4 c4 + kk
+  int abase[3];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+    const int px = 16 * mt + (lane & 15);
+    abase[mt] = (px < kTowerPix ? ((px / kTowerHW) * kHalo + px % kTowerHW) * kPixStride
+                                : kHalo * kHalo * kPixStride) + (lane >> 4);
+  }
+  const int ch = 16 * wave + (lane & 15);            // this lane's output channel
+  const int wcol = (lane >> 4) * kTowerC + ch;       // B operand: W[k = 4 c4 + kk][co = ch]
+  f32x4 acc[3], sc[3];
+
+  float* cur = bufA;
+  float* oth = bufB;
+  if (p.stem_w != nullptr) {
+    // conv1x1 on [s, a / num_actions] + relu: the action plane is constant over the map
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int ctr = (kHalo + 1) * kPixStride;  // centre tap
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+      const float b = p.stem_w[c4 * 4 * kTowerC + wcol];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[abase[mt] + ctr + 4 * c4], b, acc[mt], 0, 0, 0);
+    }
+    const float plane = (float)p.action[r] * p.inv_num_actions * p.stem_w[kTowerC * kTowerC + ch];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v] + plane, 0.0f);
+    store_map(acc, oth, ch, lane);
+    __syncthreads();
+    float* t = cur; cur = oth; oth = t;
+  }
+
+  for (int blk = 0; blk < p.blocks; ++blk) {
+    const float* W = p.conv_w + (size_t)blk * 3 * 9 * kTowerC * kTowerC;
+    const float* LN = p.ln + (size_t)blk * 3 * 2 * kTowerC;
+    conv3x3_tile(cur, W, abase, wcol, sc);
+    layer_norm_tile(sc, LN, ch, lane, wave, red, false);
+    conv3x3_tile(cur, W + 9 * kTowerC * kTowerC, abase, wcol, acc);
+    layer_norm_tile(acc, LN + 2 * kTowerC, ch, lane, wave, red, true);
+    store_map(acc, oth, ch, lane);
+    __syncthreads();
+    conv3x3_tile(oth, W + 2 * 9 * kTowerC * kTowerC, abase, wcol, acc);
+    layer_norm_tile(acc, LN + 4 * kTowerC, ch, lane, wave, red, false);
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(sc[mt][v] + acc[mt][v], 0.0f);
+    store_map(acc, cur, ch, lane);  // every wave is past its reads of `cur` (the LayerNorm barriers)
+    __syncthreads();
+  }
+  if (p.blocks == 0) {
+    // (stem only) bring the map back into registers
+    const int g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int px = 16 * mt + 4 * g + v;
+        acc[mt][v] = px < kTowerPix ? cur[((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride + ch] : 0.0f;
+      }
+  }
+
+  if (p.normalize) {
+    // min_max_normalize2d (muax/nn.py:47-56): per channel over the 36 pixels
+    const int g = lane >> 4;
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const bool ok = 16 * mt + 4 * g + v < kTowerPix;
+        mn = ok ? fminf(mn, acc[mt][v]) : mn;
+        mx = ok ? fmaxf(mx, acc[mt][v]) : mx;
+      }
+    mn = fminf(mn, __shfl_xor(mn, 16)); mn = fminf(mn, __shfl_xor(mn, 32));
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float scale = mx - mn;
+    scale = scale < 1e-5f ? scale + 1e-5f : scale;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[mt][v] = (acc[mt][v] - mn) / scale;
+  }
+  float* yout = p.y + (size_t)r * kTowerPix * kTowerC;
+  {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int px = 16 * mt + 4 * g + v;
+        if (px < kTowerPix) yout[px * kTowerC + ch] = acc[mt][v];
+      }
+  }
+}
+
+}  // namespace mz

@@ -363,7 +363,49 @@ class ResNetDynamic(nn.Module):
         n, h, w, _ = s.shape
         plane = (a.to(s.dtype) / self.num_actions).reshape(n, 1, 1, 1).expand(n, h, w, 1)
         sa = torch.cat([s, plane], dim=-1)
+        if self._hip_tower_ok(s):
+            ns = self._tower_hip(s, a)  # stem + residual tower + min_max_normalize2d in ONE HIP kernel
+            return self.r_func(sa), ns
         ns = torch.relu(self.ns_stem(sa))
         for b in self.ns_blocks:
             ns = b(ns)
         return self.r_func(sa), min_max_normalize2d(ns)
+
+    # ---- HIP path of the next-state tower (mzs_resnet_tower, muax_amd/csrc/mz_conv.cuh) ----
+    use_hip_tower = True
+
+    def _hip_tower_ok(self, s):
+        return (self.use_hip_tower and s.is_cuda and s.dtype == torch.float32 and tuple(s.shape[1:]) == (6, 6, 64)
+                and self.ns_stem.out_channels == 64 and self.ns_stem.w is not None
+                and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())))
+
+    def _packed(self):
+        ps = [self.ns_stem.w] + [p for b in self.ns_blocks for p in b.parameters()]
+        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_pack_sig", None) != sig:
+            with torch.no_grad():
+                conv = torch.stack([torch.stack([b.proj_conv.w, b.conv_0.w, b.conv_1.w]) for b in self.ns_blocks])
+                ln = torch.stack([torch.stack([torch.stack([m.scale, m.offset]) for m in (b.proj_ln, b.ln_0, b.ln_1)])
+                                  for b in self.ns_blocks])
+                self._pack = (self.ns_stem.w.reshape(65, 64).contiguous(), conv.contiguous(), ln.contiguous())
+            self._pack_sig = sig
+        return self._pack
+
+    def _tower_hip(self, s, a):
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        stem, conv, ln = self._packed()
+        x = s.contiguous()
+        act = a.to(torch.int32).contiguous()
+        y = torch.empty_like(x)
+        args = _lib.MzsTowerArgs()
+        args.struct_size = C.sizeof(_lib.MzsTowerArgs)
+        args.device = x.device.index or 0
+        args.batch, args.blocks, args.normalize, args.num_actions = x.shape[0], len(self.ns_blocks), 1, self.num_actions
+        args.x, args.action, args.stem_w = x.data_ptr(), act.data_ptr(), stem.data_ptr()
+        args.conv_w, args.ln, args.y = conv.data_ptr(), ln.data_ptr(), y.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return y

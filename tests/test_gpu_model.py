@@ -280,3 +280,30 @@ def test_fit_runs_end_to_end_on_the_hip_paths(tmp_path):
     assert all(np.isfinite(r["loss"]) and "test_G" in r for r in rows) and rows[-1]["training_step"] == 30
     assert rows[-1]["loss"] < rows[0]["loss"] and model._fused_train is not None  # the HIP training kernel ran
     model.load(path)
+
+
+@pytest.mark.gpu
+def test_hip_resnet_tower_matches_the_torch_modules():
+    """mzs_resnet_tower (conv1x1 stem + 8 x ResidualConvBlockV1 + min_max_normalize2d, fp32 MFMA) against
+    the torch modules it replaces (MIOpen convolutions + LayerNorm): a floating-point kernel, tolerance
+    2e-4 absolute on outputs normalised to [0, 1] (24 convolutions and LayerNorms deep)."""
+    g = torch.Generator().manual_seed(3)
+    d = mx.nn.ResNetDynamic(18, 21, generator=g)
+    s = torch.rand(5, 6, 6, 64, generator=g)
+    a = torch.tensor([0, 3, 17, 9, 1])
+    with torch.no_grad():
+        d(s, a)  # materialise on the host
+        for blk in d.ns_blocks:  # non-trivial LayerNorm parameters
+            for ln in (blk.proj_ln, blk.ln_0, blk.ln_1):
+                ln.scale.add_(0.2 * torch.randn(64, generator=g))
+                ln.offset.add_(0.2 * torch.randn(64, generator=g))
+        d.cuda()
+        s, a = s.cuda(), a.cuda()
+        d.use_hip_tower = False
+        r_ref, ns_ref = d(s, a)
+        d.use_hip_tower = True
+        assert d._hip_tower_ok(s)
+        r_hip, ns_hip = d(s, a)
+    assert torch.equal(r_ref, r_hip) and ns_hip.shape == (5, 6, 6, 64)
+    assert float((ns_hip - ns_ref).abs().max()) < 2e-4, float((ns_hip - ns_ref).abs().max())
+    assert float(ns_hip.amin()) == 0.0 and float(ns_hip.amax()) == 1.0

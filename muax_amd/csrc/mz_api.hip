@@ -322,6 +322,10 @@ int mzs_debug_profile(mzs_handle* h, uint64_t* device_buffer) {
 // step-wise path
 // ---------------------------------------------------------------------------
 
+static void emb_xfer(const mz::StepArgs& sa, float* rows, int dir, hipStream_t stream) {
+  hipLaunchKernelGGL(mz::emb_xfer_kernel, dim3(sa.B, (sa.E + 1023) / 1024), dim3(256), 0, stream, sa, rows, dir);
+}
+
 static int ensure_step_state(mzs_handle* h) {
   const mzs_config& c = h->cfg;
   if (h->step.allocated) return MZS_OK;
@@ -356,9 +360,11 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
                               hipMemcpyHostToDevice, stream));
   }
   mz::StepArgs sa = h->step.args(c);
+  if (sa.wide) MZS_HIP(h, hipMemsetAsync(sa.embeddings, 0, sizeof(float) * (size_t)sa.B * sa.N * sa.E, stream));
   hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
                      value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction, 0,
                      static_cast<const float*>(nullptr), 0u, 0u);
+  if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   h->step.rooted = true;
   return MZS_OK;
@@ -377,9 +383,11 @@ int mzs_root_gumbel(mzs_handle* h, const float* prior_logits, const float* value
   uint32_t zero[2] = {0, 0}, gk[2];
   h_split(key ? key : zero, 2, 1, gk);
   mz::StepArgs sa = h->step.args(c);
+  if (sa.wide) MZS_HIP(h, hipMemsetAsync(sa.embeddings, 0, sizeof(float) * (size_t)sa.B * sa.N * sa.E, stream));
   hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
                      value, embedding, invalid_actions, static_cast<const float*>(nullptr), 0.0f, 1, gumbel, gk[0],
                      gk[1]);
+  if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   h->step.rooted = true;
   return MZS_OK;
@@ -400,6 +408,7 @@ int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_em
   else
     hipLaunchKernelGGL(mz::step_select_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
                        action_out, parent_embedding_out);
+  if (sa.wide) emb_xfer(sa, parent_embedding_out, 0, stream);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;
 }
@@ -418,6 +427,7 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
   mz::StepArgs sa = h->step.args(c);
   hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
                      reward, discount, prior_logits, value, next_embedding);
+  if (sa.wide) emb_xfer(sa, const_cast<float*>(next_embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;
 }

@@ -25,6 +25,11 @@ struct StepArgs {
   float* children_discounts; float* embeddings;
   uint8_t* root_invalid;
   int32_t *sel_parent, *sel_action, *sel_depth, *depth_sum, *path;
+  // wide embeddings (E >= kWideEmb): the tree kernels only note WHICH node's row moves (xfer_node); the
+  // rows themselves are moved by emb_gather / emb_scatter with a whole workgroup per KiB instead of the
+  // 16 lanes that own the root
+  int32_t* xfer_node;
+  int32_t wide;
   const uint32_t* sim_keys;
   // gumbel policy
   int32_t qtransform, max_considered;
@@ -32,6 +37,8 @@ struct StepArgs {
   float* root_gumbel;           // [B, A]
   const int32_t* visit_table;   // [(max_considered + 1), S] seq_halving.get_table_of_considered_visits
 };
+
+constexpr int kWideEmb = 256;
 
 struct StepState {
   bool allocated = false, rooted = false;
@@ -45,6 +52,7 @@ struct StepState {
   int32_t *sel_parent = nullptr, *sel_action = nullptr, *sel_depth = nullptr, *depth_sum = nullptr,
           *path = nullptr;
   uint32_t* sim_keys = nullptr;
+  int32_t* xfer_node = nullptr;
   float* root_gumbel = nullptr;
   int32_t* visit_table = nullptr;
   void* slab = nullptr;
@@ -54,6 +62,7 @@ struct StepState {
     size_t BN = (size_t)B * N;
     size_t words = 5 * BN + 7 * BN * A + BN * E + 4 * (size_t)B + BN + 2 * (size_t)N + (size_t)B * A +
                    (size_t)table_words;
+    words += (size_t)B;  // xfer_node
     size_t bytes = words * 4 + (size_t)B * A + 256;
     hipError_t e = hipMalloc(&slab, bytes);
     if (e != hipSuccess) return e;
@@ -67,6 +76,7 @@ struct StepState {
     children_discounts = (float*)take(BN * A); embeddings = (float*)take(BN * E);
     sel_parent = (int32_t*)take(B); sel_action = (int32_t*)take(B); sel_depth = (int32_t*)take(B);
     depth_sum = (int32_t*)take(B); path = (int32_t*)take(BN); sim_keys = take(2 * (size_t)N);
+    xfer_node = (int32_t*)take(B);
     root_gumbel = (float*)take((size_t)B * A); visit_table = (int32_t*)take(table_words);
     root_invalid = reinterpret_cast<uint8_t*>(w);
     allocated = true;
@@ -92,6 +102,7 @@ struct StepState {
     a.root_invalid = root_invalid;
     a.sel_parent = sel_parent; a.sel_action = sel_action; a.sel_depth = sel_depth;
     a.depth_sum = depth_sum; a.path = path; a.sim_keys = sim_keys;
+    a.xfer_node = xfer_node; a.wide = c.embed_dim >= kWideEmb ? 1 : 0;
     a.qtransform = c.qtransform; a.max_considered = c.max_num_considered_actions;
     a.gumbel_scale = c.gumbel_scale; a.root_gumbel = root_gumbel; a.visit_table = visit_table;
     return a;
@@ -149,7 +160,8 @@ __global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float*
     s.children_rewards[o] = 0.0f;
     s.children_discounts[o] = 0.0f;
   }
-  for (size_t i = j; i < (size_t)N * E; i += 16) s.embeddings[rb * E + i] = 0.0f;
+  if (!s.wide)  // (wide: zeroed by a memset on the stream)
+    for (size_t i = j; i < (size_t)N * E; i += 16) s.embeddings[rb * E + i] = 0.0f;
   float x[kMaxAS], pr[kMaxAS], lg[kMaxAS];
   bool inv[kMaxAS];
 #pragma unroll
@@ -214,7 +226,11 @@ __global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float*
       s.children_prior_probs[rb * A + a] = pq[t];
     }
   }
-  for (int i = j; i < E; i += 16) s.embeddings[rb * E + i] = embedding[(size_t)r * E + i];
+  if (s.wide) {
+    if (j == 0) s.xfer_node[r] = 0;
+  } else {
+    for (int i = j; i < E; i += 16) s.embeddings[rb * E + i] = embedding[(size_t)r * E + i];
+  }
   if (j == 0) {
     s.node_visits[rb] = 1;
     s.raw_values[rb] = value[r];
@@ -308,8 +324,12 @@ __global__ __launch_bounds__(256) void step_select_kernel(StepArgs s, int sim, i
     s.depth_sum[r] += depth;
     action_out[r] = action;
   }
-  const float* src = s.embeddings + (rb + parent) * E;
-  for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+  if (s.wide) {
+    if (j == 0) s.xfer_node[r] = parent;
+  } else {
+    const float* src = s.embeddings + (rb + parent) * E;
+    for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+  }
 }
 
 // mctx search.expand (update_tree_node + edge) and search.backward
@@ -339,7 +359,11 @@ __global__ __launch_bounds__(256) void step_expand_backup_kernel(StepArgs s, int
       s.children_prior_probs[(rb + newn) * A + a] = pr[t];
     }
   }
-  for (int i = j; i < E; i += 16) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
+  if (s.wide) {
+    if (j == 0) s.xfer_node[r] = newn;
+  } else {
+    for (int i = j; i < E; i += 16) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
+  }
   const float rew_new = reward[r], dis_new = discount[r];
   if (j == 0) {
     s.raw_values[rb + newn] = v;
@@ -587,8 +611,12 @@ __global__ __launch_bounds__(256) void step_select_gumbel_kernel(StepArgs s, int
     s.depth_sum[r] += depth;
     action_out[r] = action;
   }
-  const float* src = s.embeddings + (rb + parent) * E;
-  for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+  if (s.wide) {
+    if (j == 0) s.xfer_node[r] = parent;
+  } else {
+    const float* src = s.embeddings + (rb + parent) * E;
+    for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+  }
 }
 
 // tail of mctx gumbel_muzero_policy: best considered action + completed-Q policy target
@@ -634,5 +662,20 @@ __global__ __launch_bounds__(256) void step_finish_gumbel_kernel(StepArgs s, int
 }
 
 #undef MZ_ROW_SETUP
+
+// ---- wide embedding rows: one workgroup per (root, KiB of the row) ----
+// dir 0: rows[b] <- tree.embeddings[b][xfer_node[b]]   (parent embedding for recurrent_fn)
+// dir 1: tree.embeddings[b][xfer_node[b]] <- rows[b]   (root / next embedding)
+__global__ __launch_bounds__(256) void emb_xfer_kernel(const StepArgs s, float* rows, int dir) {
+  const int b = blockIdx.x;
+  const size_t E = (size_t)s.E;
+  float* node = s.embeddings + ((size_t)b * s.N + s.xfer_node[b]) * E;
+  float* row = rows + (size_t)b * E;
+  const size_t i0 = (size_t)blockIdx.y * 1024, i1 = i0 + 1024 < E ? i0 + 1024 : E;
+  if (dir == 0)
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) row[i] = node[i];
+  else
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) node[i] = row[i];
+}
 
 }  // namespace mz

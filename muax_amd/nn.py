@@ -200,6 +200,8 @@ class HkConv2D(nn.Module):
 
     def forward(self, x):
         self.materialize(x.shape[-1])
+        if self.k == 1 and self.stride == 1:  # a 1x1 convolution on NHWC is a matrix product over the channels
+            return x @ self.w[0, 0]
         xc = x.permute(0, 3, 1, 2)
         (ht, hb), (wl, wr) = _same_pad(x.shape[1], self.k, self.stride), _same_pad(x.shape[2], self.k, self.stride)
         if ht or hb or wl or wr:

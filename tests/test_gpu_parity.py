@@ -209,7 +209,7 @@ def _torch_recurrent(case):
 
 
 @pytest.mark.parametrize("tiebreak", [False, True])
-@pytest.mark.parametrize("A,E,S,B", [(2, 8, 20, 70), (5, 8, 24, 33), (18, 40, 30, 40)])
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 20, 70), (5, 8, 24, 33), (18, 40, 30, 40), (18, 300, 12, 21)])  # E >= 256: wide rows
 def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak):
     """Plugin-net path: torch nets between mzs_select and mzs_expand_backup; the oracle is fed the very
     same net outputs, so every tree array must agree exactly."""
@@ -382,7 +382,7 @@ def test_bad_arguments_raise_value_error():
 # ---------------------------------------------------------------- Gumbel MuZero (muax/policy.py:33-47)
 
 @pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
-@pytest.mark.parametrize("A,E,S,B,maxc", [(4, 8, 32, 70, 16), (18, 24, 40, 33, 5), (2, 8, 50, 48, 16)])
+@pytest.mark.parametrize("A,E,S,B,maxc", [(4, 8, 32, 70, 16), (18, 24, 40, 33, 5), (2, 8, 50, 48, 16), (4, 260, 10, 9, 4)])
 def test_gumbel_stepwise_matches_oracle(oracle, A, E, S, B, maxc, qt):
     """mctx.gumbel_muzero_policy on the step-wise kernels: same torch net outputs fed to both sides, Gumbel
     noise from the key; trees, chosen actions and the completed-Q policy target must agree exactly."""

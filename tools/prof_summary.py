@@ -17,7 +17,7 @@ for db in sorted(glob.glob(os.path.join(out, "*", "*_results.db"))):
                 "select name,total_calls,total_duration,average,percentage from top_kernels limit 12"):
             lines.append(f"{calls:6d} {avg / 1e3 if avg > 1e4 else avg:10.2f} {tot / 1e3 if avg > 1e4 else tot:12.2f} {pct:6.2f}  {n[:110]}")
         for r in cur.execute("select name, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, grid_x, workgroup_x, "
-                             "avg(duration), count(*) from kernels where name like 'void mz::%' group by name"):
+                             "avg(duration), count(*) from kernels where name like '%mz::%' group by name"):
             lines.append(f"   {r[0][:70]}: lds={r[1]} vgpr={r[2]} agpr={r[3]} sgpr={r[4]} grid={r[5]} wg={r[6]} "
                          f"avg_ns={r[7]:.0f} n={r[8]}")
     else:

@@ -186,7 +186,9 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights *w, const mzs_train_args *a, void *s
  * (muax/nn.py:118-148: 3 x conv3x3 + LayerNorm over (H, W, C)), per-channel min-max normalisation -- one
  * kernel, one workgroup per root, fp32 MFMA.  Weights stay in haiku's layouts:
  *   stem_w  [65][64]                 (hk.Conv2D 1x1, HWIO)  or NULL to skip the stem
- *   conv_w  [blocks][3][3][3][64][64]  order inside a block: projection conv, conv_0, conv_1 (HWIO each)
+ *   conv_w  [blocks][3] convolutions (projection conv, conv_0, conv_1), each haiku HWIO w[3][3][64][64]
+ *           re-ordered once by the caller to Wp[tap 9][c 4][g 4][co 64][i 4] = w[tap][16 c + 4 g + i][co]
+ *           (one 16-byte load per lane and 4 k-steps)
  *   ln      [blocks][3][2][64]        (scale, offset) of the projection's, ln_0's, ln_1's LayerNorm */
 typedef struct mzs_tower_args {
   int32_t struct_size;     /* = sizeof(mzs_tower_args) */

@@ -25,14 +25,14 @@ struct TowerParams {
   const float* x;          // [B][36][64]  NHWC hidden state s
   const int32_t* action;   // [B] (stem only)
   const float* stem_w;     // [65][64] 1x1 conv on [s, a / num_actions] (HWIO), or nullptr: no stem
-  const float* conv_w;     // [blocks][3][9][64][64]  (projection, conv_0, conv_1), HWIO per conv
+  const float* conv_w;     // [blocks][3] x packed conv: Wp[tap 9][c 4][g 4][co 64][i 4] = W[tap][16 c + 4 g + i][co]
   const float* ln;         // [blocks][3][2][64]      (scale, offset) of proj_ln, ln_0, ln_1
   float* y;                // [B][36][64]
   float inv_num_actions;
   int B, blocks, normalize;
 };
 
-constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 65;
+constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 68;  // 16-byte aligned pixels
 // one haloed map + an always-zero tail of 19 pixels: the rows that pad a 36-pixel map to three 16-row MFMA
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
@@ -47,22 +47,59 @@ MZ_DEV float wg_sum(float v, float* red, int wave, int lane) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// acc[mt] (+)= conv3x3 of the haloed map `in` with W[9][64][64], this wave's 16 output channels
-MZ_DEV void conv3x3_tile(const float* in, const float* __restrict__ W, const int (&abase)[3], int wcol,
-                         f32x4 (&acc)[3]) {
+// acc[mt] = conv3x3 of the haloed map `in`, this wave's 16 output channels.
+// K is walked in 36 groups of 16 input channels (9 taps x 4): lane (m, g) reads channels 16 c + 4 g + {0..3}
+// of its pixel with ONE ds_read_b128 and uses element i in k-step i; the matching weights
+// W[tap][16 c + 4 g + i][co] are one global_load_dwordx4 from the host-packed array
+//   Wp[tap][c][g][co][i]            (any bijection of K is a valid order for the sum).
+// Weight quads are fetched three groups ahead, activation quads one group ahead.
+typedef float f32x4u __attribute__((ext_vector_type(4)));
+constexpr int kConvAhead = 6;
+struct ConvPrefetch {
+  f32x4u q[kConvAhead];  // weight quads of groups 0 .. kConvAhead-1 of the NEXT convolution
+};
+MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, ConvPrefetch& pf) {
+  const f32x4u* wq = reinterpret_cast<const f32x4u*>(Wp) + wlane;
+#pragma unroll
+  for (int q = 0; q < kConvAhead; ++q) pf.q[q] = wq[q * 256];
+}
+// `pf` holds this convolution's first weight quads (fetched while the previous LayerNorm ran); on return
+// it holds those of `Wnext` (if any), so the L2 latency at the head of a convolution is never exposed.
+MZ_DEV void conv3x3_tile(const float* in, const float* __restrict__ Wp, const float* __restrict__ Wnext,
+                         const int (&abase)[3], int wlane, ConvPrefetch& pf, f32x4 (&acc)[3]) {
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  for (int tap = 0; tap < 9; ++tap) {
-    const int toff = ((tap / 3) * kHalo + (tap % 3)) * kPixStride;
-    const float* wt = W + (size_t)tap * kTowerC * kTowerC + wcol;
+  constexpr int G = 36, AHEAD = kConvAhead;
+  const f32x4u* wq = reinterpret_cast<const f32x4u*>(Wp) + wlane;  // + group * 256
+  f32x4u wbuf[AHEAD + 1];
+  f32x4u abuf[2][3];
+  auto a_off = [](int grp) { return (((grp >> 2) / 3) * kHalo + ((grp >> 2) % 3)) * kPixStride + 16 * (grp & 3); };
 #pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4) {
-      const float b = wt[c4 * 4 * kTowerC];
+  for (int q = 0; q < AHEAD; ++q) wbuf[q] = pf.q[q];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) abuf[0][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(0));
+  StaticFor<0, G>::run([&](auto gc) {
+    constexpr int grp = decltype(gc)::value;
+    if constexpr (grp + AHEAD < G) {
+      wbuf[(grp + AHEAD) % (AHEAD + 1)] = wq[(grp + AHEAD) * 256];
+    } else {
+      if (Wnext != nullptr)
+        pf.q[grp + AHEAD - G] = (reinterpret_cast<const f32x4u*>(Wnext) + wlane)[(grp + AHEAD - G) * 256];
+    }
+    if constexpr (grp + 1 < G) {
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[abase[mt] + toff + 4 * c4], b, acc[mt], 0, 0, 0);
+        abuf[(grp + 1) & 1][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(grp + 1));
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here: the scheduler otherwise sinks them
+    const f32x4u w = wbuf[grp % (AHEAD + 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], w[i], acc[mt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 // hk.LayerNorm(axis=(-3,-2,-1)) over the root's 36 x 64 map, scale / offset per channel; optional relu
@@ -107,7 +144,7 @@ MZ_DEV void store_map(const f32x4 (&acc)[3], float* buf, int ch, int lane) {
 }
 
 __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* bufA = lds;
   float* bufB = lds + kBufWords;
   float* red = lds + 2 * kBufWords;
@@ -128,10 +165,10 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   for (int mt = 0; mt < 3; ++mt) {
     const int px = 16 * mt + (lane & 15);
     abase[mt] = (px < kTowerPix ? ((px / kTowerHW) * kHalo + px % kTowerHW) * kPixStride
-                                : kHalo * kHalo * kPixStride) + (lane >> 4);
+                                : kHalo * kHalo * kPixStride) + 4 * (lane >> 4);
   }
   const int ch = 16 * wave + (lane & 15);            // this lane's output channel
-  const int wcol = (lane >> 4) * kTowerC + ch;       // B operand: W[k = 4 c4 + kk][co = ch]
+  const int wcol = (lane >> 4) * kTowerC + ch;       // B operand: quad [g = lane >> 4][co = ch] of a packed group
   f32x4 acc[3], sc[3];
 
   float* cur = bufA;
@@ -142,11 +179,16 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
     for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int ctr = (kHalo + 1) * kPixStride;  // centre tap
 #pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4) {
-      const float b = p.stem_w[c4 * 4 * kTowerC + wcol];
+    for (int c = 0; c < 4; ++c) {
+      f32x4u a[3];
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[abase[mt] + ctr + 4 * c4], b, acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < 3; ++mt) a[mt] = *reinterpret_cast<const f32x4u*>(cur + abase[mt] + ctr + 16 * c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float b = p.stem_w[(16 * c + 4 * (lane >> 4) + i) * kTowerC + ch];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], b, acc[mt], 0, 0, 0);
+      }
     }
     const float plane = (float)p.action[r] * p.inv_num_actions * p.stem_w[kTowerC * kTowerC + ch];
 #pragma unroll
@@ -158,16 +200,20 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
     float* t = cur; cur = oth; oth = t;
   }
 
+  ConvPrefetch pf;
+  if (p.blocks > 0) conv_prefetch(p.conv_w, wcol, pf);
   for (int blk = 0; blk < p.blocks; ++blk) {
     const float* W = p.conv_w + (size_t)blk * 3 * 9 * kTowerC * kTowerC;
     const float* LN = p.ln + (size_t)blk * 3 * 2 * kTowerC;
-    conv3x3_tile(cur, W, abase, wcol, sc);
+    constexpr size_t CW = 9 * kTowerC * kTowerC;
+    const float* Wn = blk + 1 < p.blocks ? W + 3 * CW : nullptr;
+    conv3x3_tile(cur, W, W + CW, abase, wcol, pf, sc);
     layer_norm_tile(sc, LN, ch, lane, wave, red, false);
-    conv3x3_tile(cur, W + 9 * kTowerC * kTowerC, abase, wcol, acc);
+    conv3x3_tile(cur, W + CW, W + 2 * CW, abase, wcol, pf, acc);
     layer_norm_tile(acc, LN + 2 * kTowerC, ch, lane, wave, red, true);
     store_map(acc, oth, ch, lane);
     __syncthreads();
-    conv3x3_tile(oth, W + 2 * 9 * kTowerC * kTowerC, abase, wcol, acc);
+    conv3x3_tile(oth, W + 2 * CW, Wn, abase, wcol, pf, acc);
     layer_norm_tile(acc, LN + 4 * kTowerC, ch, lane, wave, red, false);
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)

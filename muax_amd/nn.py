@@ -386,7 +386,10 @@ class ResNetDynamic(nn.Module):
         sig = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_pack_sig", None) != sig:
             with torch.no_grad():
-                conv = torch.stack([torch.stack([b.proj_conv.w, b.conv_0.w, b.conv_1.w]) for b in self.ns_blocks])
+                # kernel layout of a 3x3 conv: Wp[tap][c][g][co][i] = W[tap][16 c + 4 g + i][co]  (mz_conv.cuh)
+                pack = lambda w: w.reshape(9, 4, 4, 4, 64).permute(0, 1, 2, 4, 3)  # noqa: E731
+                conv = torch.stack([torch.stack([pack(b.proj_conv.w), pack(b.conv_0.w), pack(b.conv_1.w)])
+                                    for b in self.ns_blocks])
                 ln = torch.stack([torch.stack([torch.stack([m.scale, m.offset]) for m in (b.proj_ln, b.ln_0, b.ln_1)])
                                   for b in self.ns_blocks])
                 self._pack = (self.ns_stem.w.reshape(65, 64).contiguous(), conv.contiguous(), ln.contiguous())

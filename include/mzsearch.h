@@ -203,6 +203,19 @@ typedef struct mzs_tower_args {
   const float *conv_w;
   const float *ln;
   float *y;                /* [B, 6, 6, 64] out */
+  /* Optional heads, fused into the same launch when r_c1 != NULL (then all of them must be given): the
+   * whole recurrent_fn of muax/model.py:265-282 for the ResNet nets -- reward head r_func on
+   * [s, a / num_actions] (muax/nn.py:347-357) and ResNetPrediction on the normalised next state
+   * (muax/nn.py:313-341); reward / value come out as support_to_scalar(softmax(logits)).  haiku layouts:
+   * conv1x1 w[in][out], Linear w[in][out] on the NHWC-flattened map, biases [out]. */
+  const float *r_c1, *r_c2, *r_l1, *r_b1, *r_l2, *r_b2;   /* [65,64] [64,64] [2304,64] [64] [64,F] [F] */
+  const float *v_c1, *v_c2, *v_l1, *v_b1, *v_l2, *v_b2;   /* [64,16] [16,16] [576,16] [16] [16,F] [F] */
+  const float *p_c1, *p_l1, *p_b1, *p_l2, *p_b2;          /* [64,16] [576,16] [16] [16,A] [A]        */
+  float *reward;           /* [B] out */
+  float *value;            /* [B] out */
+  float *prior_logits;     /* [B, A] out */
+  int32_t support_size;    /* F = 2 * support_size + 1 <= 64 */
+  int32_t reserved0;
 } mzs_tower_args;
 int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
 

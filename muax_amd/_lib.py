@@ -64,6 +64,10 @@ class MzsTowerArgs(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("blocks", C.c_int32),
                 ("normalize", C.c_int32), ("num_actions", C.c_int32), ("x", _vp), ("action", _vp),
                 ("stem_w", _vp), ("conv_w", _vp), ("ln", _vp), ("y", _vp)]
+    HEAD_FIELDS = ["r_c1", "r_c2", "r_l1", "r_b1", "r_l2", "r_b2", "v_c1", "v_c2", "v_l1", "v_b1", "v_l2", "v_b2",
+                   "p_c1", "p_l1", "p_b1", "p_l2", "p_b2"]
+    _fields_ += [(n, _vp) for n in HEAD_FIELDS] + [("reward", _vp), ("value", _vp), ("prior_logits", _vp),
+                                                   ("support_size", C.c_int32), ("reserved0", C.c_int32)]
 
 
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",

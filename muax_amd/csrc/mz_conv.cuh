@@ -30,6 +30,29 @@ struct TowerParams {
   float* y;                // [B][36][64]
   float inv_num_actions;
   int B, blocks, normalize;
+  // optional heads (all nullptr / 0: tower only).  ResNetDynamic.r_func on [s, a / num_actions] and
+  // ResNetPrediction on the normalised next state (muax/nn.py:313-341,347-357), haiku layouts:
+  const float* r_c1;   // [65][64]   conv1x1
+  const float* r_c2;   // [64][64]   conv1x1
+  const float* r_l1;   // [2304][64] Linear on the NHWC-flattened map
+  const float* r_b1;   // [64]
+  const float* r_l2;   // [64][F]
+  const float* r_b2;   // [F]
+  const float* v_c1;   // [64][16]
+  const float* v_c2;   // [16][16]
+  const float* v_l1;   // [576][16]
+  const float* v_b1;   // [16]
+  const float* v_l2;   // [16][F]
+  const float* v_b2;   // [F]
+  const float* p_c1;   // [64][16]
+  const float* p_l1;   // [576][16]
+  const float* p_b1;   // [16]
+  const float* p_l2;   // [16][A]
+  const float* p_b2;   // [A]
+  float* reward;       // [B]   support_to_scalar(softmax(r_logits))
+  float* value;        // [B]
+  float* prior_logits; // [B][A]
+  int heads, A, F, support;
 };
 
 constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 68;  // 16-byte aligned pixels
@@ -37,6 +60,7 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
+constexpr int kHeadWords = 4 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots + scratch of the heads
 
 MZ_DEV float wg_sum(float v, float* red, int wave, int lane) {
 #pragma unroll
@@ -143,14 +167,65 @@ MZ_DEV void store_map(const f32x4 (&acc)[3], float* buf, int ch, int lane) {
     }
 }
 
+
+// ---- small pieces of the heads ----
+// conv1x1 as MFMA tiles: acc[mt] (mt = 0..2) = in[px][0..16 KC) . W[k][ncol], `in` rows addressed through
+// rowbase[mt] (word offsets of this lane's pixel row + 4 * (lane >> 4)), W row-major [K][ldw]
+MZ_DEV void conv1x1_tiles(const float* in, const int (&rowbase)[3], const float* __restrict__ W, int ldw, int ncol,
+                          int KC, int g, f32x4 (&acc)[3]) {
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int c = 0; c < KC; ++c) {
+    f32x4u a[3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) a[mt] = *reinterpret_cast<const f32x4u*>(in + rowbase[mt] + 16 * c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float b = W[(16 * c + 4 * g + i) * ldw + ncol];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], b, acc[mt], 0, 0, 0);
+    }
+  }
+}
+// one M-tile, K = 16 (the value head's second 1x1 convolution)
+MZ_DEV f32x4 conv1x1_k16(const float* row, const float* __restrict__ W, int n, int g) {
+  f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const f32x4u a = *reinterpret_cast<const f32x4u*>(row);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], W[(4 * g + i) * 16 + n], acc, 0, 0, 0);
+  return acc;
+}
+// support_to_scalar(softmax(logits[0..F))) by the first wave (F <= 64), result in every lane of that wave
+MZ_DEV float decode_support(const float* logits, int F, int support, int lane) {
+  float x = lane < F ? logits[lane] : -INFINITY;
+  float m = x;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
+  float e = lane < F ? exp_neg(x - m) : 0.0f;
+  float s = e, t = e * (float)(lane - support);
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    s = s + __shfl_xor(s, k);
+    t = t + __shfl_xor(t, k);
+  }
+  return inv_scaling(t / s);
+}
+
 __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* bufA = lds;
   float* bufB = lds + kBufWords;
   float* red = lds + 2 * kBufWords;
+  float* hv = red + 4;            // [48][16] value head map (rows >= 36 stay zero)
+  float* hv2 = hv + 768;          // [48][16]
+  float* hp = hv2 + 768;          // [48][16] policy head map
+  float* part = hp + 768;         // [256] partial sums of the flatten -> Linear layers
+  float* part2 = part + 256;      // [256]
+  float* vec = part2 + 256;       // [64] hidden vectors
+  float* lgt = vec + 64;          // [64] logits
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = blockIdx.x;
-  for (int i = tid; i < 2 * kBufWords; i += 256) lds[i] = 0.0f;
+  for (int i = tid; i < 2 * kBufWords + kHeadWords; i += 256) lds[i] = 0.0f;
   __syncthreads();
   const float* xin = p.x + (size_t)r * kTowerPix * kTowerC;
   for (int i = tid; i < kTowerPix * kTowerC; i += 256) {
@@ -170,6 +245,55 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   const int ch = 16 * wave + (lane & 15);            // this lane's output channel
   const int wcol = (lane >> 4) * kTowerC + ch;       // B operand: quad [g = lane >> 4][co = ch] of a packed group
   f32x4 acc[3], sc[3];
+
+  const int g4 = lane >> 4, n16 = lane & 15;
+  int rowc[3];  // centre-tap rows for 1x1 convolutions on a haloed map
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) rowc[mt] = abase[mt] + (kHalo + 1) * kPixStride;
+  if (p.heads) {
+    // ---- reward head on [s, a / num_actions] (muax/nn.py:347-357): two 1x1 convs, flatten, two Linears ----
+    conv1x1_tiles(bufA, rowc, p.r_c1, kTowerC, ch, 4, g4, acc);
+    const float pl = (float)p.action[r] * p.inv_num_actions * p.r_c1[kTowerC * kTowerC + ch];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v] + pl, 0.0f);
+    store_map(acc, bufB, ch, lane);
+    __syncthreads();
+    conv1x1_tiles(bufB, rowc, p.r_c2, kTowerC, ch, 4, g4, acc);
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v], 0.0f);
+    __syncthreads();  // every wave has read bufB
+    store_map(acc, bufB, ch, lane);
+    __syncthreads();
+    {
+      // Linear(2304 -> 64): wave = 9 pixels of the map, lane = output unit; weights stream from L2
+      float sacc = 0.0f;
+      for (int px = 9 * wave; px < 9 * wave + 9; ++px) {
+        const float* row = bufB + ((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride;
+        const float* wr = p.r_l1 + (size_t)px * kTowerC * kTowerC + lane;
+#pragma unroll 8
+        for (int c = 0; c < kTowerC; ++c) sacc = __builtin_fmaf(row[c], wr[c * kTowerC], sacc);
+      }
+      part[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < 64) vec[tid] = fmaxf(((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + p.r_b1[tid], 0.0f);
+    __syncthreads();
+    if (tid < p.F) {
+      float a = 0.0f;
+      for (int k = 0; k < 64; ++k) a = __builtin_fmaf(vec[k], p.r_l2[k * p.F + tid], a);
+      lgt[tid] = a + p.r_b2[tid];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float rw = decode_support(lgt, p.F, p.support, lane);
+      if (lane == 0) p.reward[r] = rw;
+    }
+    __syncthreads();
+  }
 
   float* cur = bufA;
   float* oth = bufB;
@@ -265,6 +389,72 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
         const int px = 16 * mt + 4 * g + v;
         if (px < kTowerPix) yout[px * kTowerC + ch] = acc[mt][v];
       }
+  }
+  if (p.heads) {
+    // ---- prediction heads on the normalised next state (muax/nn.py:313-341) ----
+    store_map(acc, cur, ch, lane);
+    __syncthreads();
+    if (wave < 2) {  // wave 0: value head, wave 1: policy head -- first 1x1 conv (64 -> 16) + relu
+      f32x4 h[3];
+      conv1x1_tiles(cur, rowc, wave == 0 ? p.v_c1 : p.p_c1, 16, n16, 4, g4, h);
+      float* dst = wave == 0 ? hv : hp;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int px = 16 * mt + 4 * g4 + v;
+          if (px < kTowerPix) dst[px * 16 + n16] = fmaxf(h[mt][v], 0.0f);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {  // value head: second 1x1 conv (16 -> 16) + relu
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const f32x4 h = conv1x1_k16(hv + (16 * mt + n16) * 16 + 4 * g4, p.v_c2, n16, g4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int px = 16 * mt + 4 * g4 + v;
+          if (px < kTowerPix) hv2[px * 16 + n16] = fmaxf(h[v], 0.0f);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // Linear(576 -> 16) of both heads: thread = (output unit n, one of 16 slices of 36 inputs)
+      const int n = tid & 15, sl = tid >> 4;
+      float sv = 0.0f, sp = 0.0f;
+      for (int i = 36 * sl; i < 36 * sl + 36; ++i) {
+        sv = __builtin_fmaf(hv2[i], p.v_l1[i * 16 + n], sv);
+        sp = __builtin_fmaf(hp[i], p.p_l1[i * 16 + n], sp);
+      }
+      __syncthreads();
+      part[tid] = sv;
+      part2[tid] = sp;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int n = tid & 15;
+      const float* src = tid < 16 ? part : part2;
+      float a = 0.0f;
+      for (int sl = 0; sl < 16; ++sl) a = a + src[sl * 16 + n];
+      vec[tid] = fmaxf(a + (tid < 16 ? p.v_b1[n] : p.p_b1[n]), 0.0f);
+    }
+    __syncthreads();
+    if (tid < p.F) {
+      float a = 0.0f;
+      for (int k = 0; k < 16; ++k) a = __builtin_fmaf(vec[k], p.v_l2[k * p.F + tid], a);
+      lgt[tid] = a + p.v_b2[tid];
+    } else if (tid >= 64 && tid < 64 + p.A) {
+      const int j = tid - 64;
+      float a = 0.0f;
+      for (int k = 0; k < 16; ++k) a = __builtin_fmaf(vec[16 + k], p.p_l2[k * p.A + j], a);
+      p.prior_logits[(size_t)r * p.A + j] = a + p.p_b2[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float vl = decode_support(lgt, p.F, p.support, lane);
+      if (lane == 0) p.value[r] = vl;
+    }
   }
 }
 

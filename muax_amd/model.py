@@ -142,6 +142,11 @@ class MuZero:
 
     def _recurrent_inference(self, params, rng_key, action, embedding):
         """muax/model.py:265-282 -> ((reward, discount, prior_logits, value), next_embedding)."""
+        if self._recurrent_pred_on == "child" and hasattr(self.dy_func, "hip_recurrent"):
+            out = self.dy_func.hip_recurrent(self.pred_func, embedding, action, self._support_size)
+            if out is not None:  # ResNet nets: the whole recurrent_fn is one HIP launch (mz_conv.cuh)
+                r, v, logits, next_embedding = out
+                return (r, torch.full_like(r, self._discount), logits, v), next_embedding
         with torch.no_grad():
             r, next_embedding = self.dy_func(embedding, action)
             v, logits = self.pred_func(embedding if self._recurrent_pred_on == "parent" else next_embedding)

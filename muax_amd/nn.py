@@ -206,8 +206,19 @@ class HkConv2D(nn.Module):
         (ht, hb), (wl, wr) = _same_pad(x.shape[1], self.k, self.stride), _same_pad(x.shape[2], self.k, self.stride)
         if ht or hb or wl or wr:
             xc = torch.nn.functional.pad(xc, (wl, wr, ht, hb))
-        y = torch.nn.functional.conv2d(xc, self.w.permute(3, 2, 0, 1), stride=self.stride)
+        y = torch.nn.functional.conv2d(xc, self._oihw(), stride=self.stride)
         return y.permute(0, 2, 3, 1)
+
+    def _oihw(self):
+        """The HWIO parameter as a packed channels_last OIHW tensor (a strided view sends MIOpen to its naive
+        kernel); rebuilt when the parameter changes, differentiable view while training."""
+        if torch.is_grad_enabled() and self.w.requires_grad:
+            return self.w.permute(3, 2, 0, 1)
+        sig = (self.w.data_ptr(), self.w._version)
+        if getattr(self, "_oihw_sig", None) != sig:
+            self._oihw_cache = self.w.detach().permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
+            self._oihw_sig = sig
+        return self._oihw_cache
 
 
 class HkLayerNorm(nn.Module):
@@ -376,10 +387,10 @@ class ResNetDynamic(nn.Module):
     # ---- HIP path of the next-state tower (mzs_resnet_tower, muax_amd/csrc/mz_conv.cuh) ----
     use_hip_tower = True
 
-    def _hip_tower_ok(self, s):
+    def _hip_tower_ok(self, s, inference=False):
         return (self.use_hip_tower and s.is_cuda and s.dtype == torch.float32 and tuple(s.shape[1:]) == (6, 6, 64)
                 and self.ns_stem.out_channels == 64 and self.ns_stem.w is not None
-                and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())))
+                and (inference or not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))))
 
     def _packed(self):
         ps = [self.ns_stem.w] + [p for b in self.ns_blocks for p in b.parameters()]
@@ -396,7 +407,7 @@ class ResNetDynamic(nn.Module):
             self._pack_sig = sig
         return self._pack
 
-    def _tower_hip(self, s, a):
+    def _tower_hip(self, s, a, pred=None, support_size=None):
         import ctypes as C
 
         from . import _lib
@@ -411,6 +422,41 @@ class ResNetDynamic(nn.Module):
         args.batch, args.blocks, args.normalize, args.num_actions = x.shape[0], len(self.ns_blocks), 1, self.num_actions
         args.x, args.action, args.stem_w = x.data_ptr(), act.data_ptr(), stem.data_ptr()
         args.conv_w, args.ln, args.y = conv.data_ptr(), ln.data_ptr(), y.data_ptr()
+        outs = None
+        if pred is not None:
+            B = x.shape[0]
+            rf, vf, pf = self.r_func, pred.v_func, pred.pi_func
+            heads = [rf[0].w, rf[2].w, rf[5].w, rf[5].b, rf[7].w, rf[7].b,
+                     vf[0].w, vf[2].w, vf[5].w, vf[5].b, vf[7].w, vf[7].b,
+                     pf[0].w, pf[3].w, pf[3].b, pf[5].w, pf[5].b]
+            keep = [h.detach().contiguous() for h in heads]
+            for name, t in zip(_lib.MzsTowerArgs.HEAD_FIELDS, keep):
+                setattr(args, name, t.data_ptr())
+            outs = (torch.empty(B, device=x.device), torch.empty(B, device=x.device),
+                    torch.empty(B, pred.num_actions, device=x.device))
+            args.reward, args.value, args.prior_logits = (o.data_ptr() for o in outs)
+            args.support_size = support_size
         with torch.cuda.device(x.device):
             _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        return y
+        return y if outs is None else (outs[0], outs[1], outs[2], y)
+
+    def hip_recurrent(self, pred, s, a, support_size: int):
+        """The whole recurrent_fn of muax/model.py:265-282 for the ResNet nets in ONE HIP launch: reward head,
+        next-state tower, prediction heads on the next state, both support decodes.  Returns
+        (reward [B], value [B], prior_logits [B, A], next_state [B, 6, 6, 64]) or None when the nets are not
+        the shapes the kernel is built for (the caller then runs the torch modules)."""
+        def head_ok(seq, convs, hidden, in_ch):
+            ws = [m for m in seq if isinstance(m, HkConv2D)]
+            ls = [m for m in seq if isinstance(m, LazyHkLinear)]
+            return (len(ws) == len(convs) and len(ls) == 2 and all(m.w is not None for m in ws + ls)
+                    and [tuple(m.w.shape[2:]) for m in ws] == convs and ls[0].w.shape[1] == hidden
+                    and all(m.with_bias for m in ls))
+        if not (isinstance(pred, ResNetPrediction) and self._hip_tower_ok(s, inference=True) and 2 * support_size + 1 <= 64
+                and pred.num_actions <= 64 and pred.num_actions == self.num_actions
+                and head_ok(self.r_func, [(65, 64), (64, 64)], 64, 65)
+                and head_ok(pred.v_func, [(64, 16), (16, 16)], 16, 64)
+                and head_ok(pred.pi_func, [(64, 16)], 16, 64)
+                and self.r_func[7].w.shape[1] == 2 * support_size + 1
+                and pred.v_func[7].w.shape[1] == 2 * support_size + 1):
+            return None
+        return self._tower_hip(s, a, pred, support_size)

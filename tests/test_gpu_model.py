@@ -307,3 +307,31 @@ def test_hip_resnet_tower_matches_the_torch_modules():
     assert torch.equal(r_ref, r_hip) and ns_hip.shape == (5, 6, 6, 64)
     assert float((ns_hip - ns_ref).abs().max()) < 2e-4, float((ns_hip - ns_ref).abs().max())
     assert float(ns_hip.amin()) == 0.0 and float(ns_hip.amax()) == 1.0
+
+
+@pytest.mark.gpu
+def test_hip_resnet_recurrent_fn_matches_the_torch_modules():
+    """One launch for recurrent_fn of the ResNet nets (reward head + tower + prediction heads + decodes)
+    against the torch modules: reward / value to 2e-4 relative (+1e-4), logits and next state to 3e-4."""
+    g = torch.Generator().manual_seed(5)
+    mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(18, 21, generator=g),
+            mx.nn.ResNetDynamic(18, 21, generator=g))
+    m = mx.MuZero(*mods)
+    m.init(0, np.zeros((1, 84, 84, 4), F32))
+    with torch.no_grad():
+        for mod in mods[1:]:  # biases away from zero
+            for p in mod.parameters():
+                if p.dim() == 1 and p.shape[0] in (16, 18, 21, 64):
+                    p.add_(0.1 * torch.randn(p.shape, generator=g).to(p.device))
+    s = torch.rand(7, 6, 6, 64, generator=g).cuda()
+    a = torch.tensor([0, 17, 3, 9, 12, 1, 5]).cuda()
+    hip = mods[2].hip_recurrent(mods[1], s, a, 10)
+    assert hip is not None
+    (r1, d1, lg1, v1), ns1 = m._recurrent_inference(None, None, a, s)
+    mods[2].use_hip_tower = False
+    (r0, d0, lg0, v0), ns0 = m._recurrent_inference(None, None, a, s)
+    mods[2].use_hip_tower = True
+    assert torch.equal(hip[0], r1) and torch.equal(d0, d1)
+    for x1, x0, tol in ((r1, r0, 2e-4), (v1, v0, 2e-4), (lg1, lg0, 3e-4), (ns1, ns0, 3e-4)):
+        assert x1.shape == x0.shape and float((x1 - x0).abs().max()) <= tol * float(x0.abs().max()) + 1e-4, \
+            (float((x1 - x0).abs().max()), float(x0.abs().max()))

@@ -206,7 +206,12 @@ class HkConv2D(nn.Module):
         (ht, hb), (wl, wr) = _same_pad(x.shape[1], self.k, self.stride), _same_pad(x.shape[2], self.k, self.stride)
         if ht or hb or wl or wr:
             xc = torch.nn.functional.pad(xc, (wl, wr, ht, hb))
-        y = torch.nn.functional.conv2d(xc, self._oihw(), stride=self.stride)
+        w = self._oihw()
+        if x.shape[-1] < 8 and not (torch.is_grad_enabled() and self.w.requires_grad):
+            # few input channels (raw frames): MIOpen has no fast NHWC fp32 kernel and falls back to a naive
+            # one (2.2 ms for 128 x 84 x 84 x 4); the plain NCHW problem gets a proper solver
+            xc, w = xc.contiguous(), w.contiguous()
+        y = torch.nn.functional.conv2d(xc, w, stride=self.stride)
         return y.permute(0, 2, 3, 1)
 
     def _oihw(self):

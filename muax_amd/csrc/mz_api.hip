@@ -322,6 +322,11 @@ int mzs_debug_profile(mzs_handle* h, uint64_t* device_buffer) {
 // step-wise path
 // ---------------------------------------------------------------------------
 
+// Small batches run one wavefront (4 roots) per workgroup: the tree of a root is then always walked from the
+// same XCD, all 8 L2s share the trees, and the dependent per-level loads hit L2 instead of HBM.
+static int step_block(int batch) { return batch >= 4096 ? 256 : 64; }
+static int step_grid(int batch) { const int per = step_block(batch) / 16; return (batch + per - 1) / per; }
+
 static void emb_xfer(const mz::StepArgs& sa, float* rows, int dir, hipStream_t stream) {
   hipLaunchKernelGGL(mz::emb_xfer_kernel, dim3(sa.B, (sa.E + 1023) / 1024), dim3(256), 0, stream, sa, rows, dir);
 }
@@ -361,7 +366,7 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
   }
   mz::StepArgs sa = h->step.args(c);
   if (sa.wide) MZS_HIP(h, hipMemsetAsync(sa.embeddings, 0, sizeof(float) * (size_t)sa.B * sa.N * sa.E, stream));
-  hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
+  hipLaunchKernelGGL(mz::step_root_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, prior_logits,
                      value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction, 0,
                      static_cast<const float*>(nullptr), 0u, 0u);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
@@ -384,7 +389,7 @@ int mzs_root_gumbel(mzs_handle* h, const float* prior_logits, const float* value
   h_split(key ? key : zero, 2, 1, gk);
   mz::StepArgs sa = h->step.args(c);
   if (sa.wide) MZS_HIP(h, hipMemsetAsync(sa.embeddings, 0, sizeof(float) * (size_t)sa.B * sa.N * sa.E, stream));
-  hipLaunchKernelGGL(mz::step_root_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, prior_logits,
+  hipLaunchKernelGGL(mz::step_root_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, prior_logits,
                      value, embedding, invalid_actions, static_cast<const float*>(nullptr), 0.0f, 1, gumbel, gk[0],
                      gk[1]);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
@@ -403,10 +408,10 @@ int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_em
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
   if (c.policy == 1)
-    hipLaunchKernelGGL(mz::step_select_gumbel_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+    hipLaunchKernelGGL(mz::step_select_gumbel_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        action_out, parent_embedding_out);
   else
-    hipLaunchKernelGGL(mz::step_select_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+    hipLaunchKernelGGL(mz::step_select_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        action_out, parent_embedding_out);
   if (sa.wide) emb_xfer(sa, parent_embedding_out, 0, stream);
   MZS_HIP(h, hipGetLastError());
@@ -425,7 +430,7 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
-  hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, sim,
+  hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                      reward, discount, prior_logits, value, next_embedding);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(next_embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
@@ -442,10 +447,10 @@ int mzs_finish(mzs_handle* h, float temperature, const float* gumbel, int32_t* a
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
   if (c.policy == 1)
-    hipLaunchKernelGGL(mz::step_finish_gumbel_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa,
+    hipLaunchKernelGGL(mz::step_finish_gumbel_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa,
                        action_out, action_weights_out, search_value_out, depth_sum_out);
   else
-    hipLaunchKernelGGL(mz::step_finish_kernel, dim3((c.batch + 15) / 16), dim3(256), 0, stream, sa, temperature,
+    hipLaunchKernelGGL(mz::step_finish_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, temperature,
                        gumbel, h->k_sample[0], h->k_sample[1], action_out, action_weights_out, search_value_out,
                        depth_sum_out);
   MZS_HIP(h, hipGetLastError());

@@ -131,7 +131,7 @@ MZ_DEV void row_softmax_rt(const float (&x)[kMaxAS], int A, int j, float (&p)[kM
 #define MZ_ROW_SETUP                                              \
   const int lane = threadIdx.x & 63;                              \
   const int j = lane & 15;                                        \
-  const int r = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4); \
+  const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);  \
   if (r >= s.B) return;                                           \
   const int N = s.N, A = s.A, E = s.E;                            \
   const size_t rb = (size_t)r * N;
@@ -277,37 +277,73 @@ __global__ __launch_bounds__(256) void step_select_kernel(StepArgs s, int sim, i
     for (int t = 0; t < kMaxAS; ++t) {
       int a = j + 16 * t;
       bool ok = a < A;
-      size_t o = nb + (ok ? a : 0);
-      cidx[t] = s.children_index[o];
-      cvis[t] = s.children_visits[o];
-      prob[t] = s.children_prior_probs[o];
-      q[t] = s.children_rewards[o] + s.children_discounts[o] * s.children_values[o];
-      float safe = (ok && cvis[t] > 0) ? q[t] : nval;
-      lo = fminf(lo, safe);
-      hi = fmaxf(hi, safe);
+      cidx[t] = -1; cvis[t] = 0; prob[t] = 0.0f; q[t] = 0.0f;
+      if (16 * t < A) {  // (wave-uniform: slots past the action count cost nothing)
+        size_t o = nb + (ok ? a : 0);
+        cidx[t] = s.children_index[o];
+        cvis[t] = s.children_visits[o];
+        prob[t] = s.children_prior_probs[o];
+        q[t] = s.children_rewards[o] + s.children_discounts[o] * s.children_values[o];
+        float safe = (ok && cvis[t] > 0) ? q[t] : nval;
+        lo = fminf(lo, safe);
+        hi = fmaxf(hi, safe);
+      }
     }
     lo = row_min<4>(lo);
     hi = row_max<4>(hi);
     float span = fmaxf(hi - lo, 1e-8f);
+    float sc[kMaxAS];
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      int a = j + 16 * t;
+      bool ok = a < A;
+      sc[t] = -INFINITY;
+      if (16 * t < A) {
+        float value_score = ((cvis[t] > 0 ? q[t] : lo) - lo) / span;
+        float policy_score = (tn * prob[t]) / (float)(cvis[t] + 1);
+        sc[t] = value_score + policy_score;
+        if (depth == 0 && ok && s.root_invalid[(size_t)r * A + a]) sc[t] = -INFINITY;
+        if (!ok) sc[t] = -INFINITY;
+      }
+    }
+    // mctx adds 1e-7 * uniform[0,1) to every score.  If fl(score_a + 1e-7) < best for every other action
+    // the argmax cannot depend on the draw (rounding is monotone): only waves that hold a near tie pay for
+    // the threefry blocks.  (-inf scores stay -inf with or without noise.)
     float bscore = -INFINITY;
     int best = 1 << 20, bnext = -1;
 #pragma unroll
     for (int t = 0; t < kMaxAS; ++t) {
       int a = j + 16 * t;
-      bool ok = a < A;
-      float value_score = ((cvis[t] > 0 ? q[t] : lo) - lo) / span;
-      float policy_score = (tn * prob[t]) / (float)(cvis[t] + 1);
-      float score = value_score + policy_score;
-      if (s.tiebreak) {
-        int jb = a < NB ? a : a - NB;
-        uint32_t x0 = (uint32_t)jb, x1 = (NB + jb < A) ? (uint32_t)(NB + jb) : 0u;
-        threefry2x32(s0, s1, x0, x1);
-        score = score + 1e-7f * uniform_from_bits(a < NB ? x0 : x1);
+      bool take = (t == 0) || (sc[t] > bscore);  // first max wins inside the lane
+      if (take) { bscore = sc[t]; best = (a < A) ? a : (1 << 20); bnext = cidx[t]; }
+    }
+    row_argmax<4>(bscore, best, bnext);
+    bool need_noise = false;
+    if (s.tiebreak) {
+      bool unsafe = false;
+#pragma unroll
+      for (int t = 0; t < kMaxAS; ++t) {
+        int a = j + 16 * t;
+        unsafe = unsafe || (a < A && a != best && !((sc[t] + 1e-7f) < bscore));
       }
-      if (depth == 0 && ok && s.root_invalid[(size_t)r * A + a]) score = -INFINITY;
-      if (!ok) score = -INFINITY;
-      bool take = (t == 0) || (score > bscore);  // first max wins inside the lane
-      if (take) { bscore = score; best = ok ? a : (1 << 20); bnext = cidx[t]; }
+      need_noise = __any(unsafe);
+    }
+    if (need_noise) {
+      bscore = -INFINITY; best = 1 << 20; bnext = -1;
+#pragma unroll
+      for (int t = 0; t < kMaxAS; ++t) {
+        int a = j + 16 * t;
+        float score = sc[t];
+        if (16 * t < A) {
+          int jb = a < NB ? a : a - NB;
+          uint32_t x0 = (uint32_t)jb, x1 = (NB + jb < A) ? (uint32_t)(NB + jb) : 0u;
+          threefry2x32(s0, s1, x0, x1);
+          score = score + 1e-7f * uniform_from_bits(a < NB ? x0 : x1);
+        }
+        bool take = (t == 0) || (score > bscore);
+        if (take) { bscore = score; best = (a < A) ? a : (1 << 20); bnext = cidx[t]; }
+      }
+      row_argmax<4>(bscore, best, bnext);
     }
     row_argmax<4>(bscore, best, bnext);
     if (j == 0) s.path[rb + depth] = node | (best << 16);

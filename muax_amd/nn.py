@@ -211,6 +211,10 @@ class HkConv2D(nn.Module):
             # few input channels (raw frames): MIOpen has no fast NHWC fp32 kernel and falls back to a naive
             # one (2.2 ms for 128 x 84 x 84 x 4); the plain NCHW problem gets a proper solver
             xc, w = xc.contiguous(), w.contiguous()
+            y = torch.nn.functional.conv2d(xc, w, stride=self.stride).contiguous(memory_format=torch.channels_last)
+            return y.permute(0, 2, 3, 1)
+        if not xc.is_contiguous(memory_format=torch.channels_last):  # keep every conv on packed NHWC operands
+            xc = xc.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(xc, w, stride=self.stride)
         return y.permute(0, 2, 3, 1)
 

@@ -780,6 +780,15 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   }
 
   int depth_total = 0;
+  // embeddings in HBM: the parent row of the NEXT simulation is prefetched behind the backup's stores
+  int pref_parent = 0;
+  float pre[C::ES];
+#pragma unroll
+  for (int t = 0; t < C::ES; ++t) pre[t] = 0.0f;
+  if constexpr (!C::EMB_LDS) {
+#pragma unroll
+    for (int t = 0; t < C::ES; ++t) pre[t] = s[t];  // simulation 0 expands below the root
+  }
   MZ_TICKW(12);  // prologue: weights, tree init, root inference
 
   // ---- simulations (mctx search.search body_fun) ----
@@ -872,10 +881,15 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     float sp[C::ES];
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
-      if constexpr (C::EMB_LDS)
+      if constexpr (C::EMB_LDS) {
         sp[t] = (j + 16 * t < E) ? tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + j + 16 * t] : 0.0f;
-      else
-        sp[t] = (j + 16 * t < E) ? gemb[(size_t)parent * E + j + 16 * t] : 0.0f;
+      } else {
+        // the row was requested at the end of the previous simulation (from the root's fresh JUMP word);
+        // only a near-tie redraw or a max_depth cut can have picked another parent
+        float v = pre[t];
+        if (parent != pref_parent && j + 16 * t < E) v = gemb[(size_t)parent * E + j + 16 * t];
+        sp[t] = (j + 16 * t < E) ? v : 0.0f;
+      }
     // LDS reads the expansion needs are issued before the network pass so their latency hides behind it
     float* nn = tree + __umul24((unsigned)newn, (unsigned)NS);
     int* nni = reinterpret_cast<int*>(nn);
@@ -1085,6 +1099,12 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           nd[C::ST0 + C::STW * pa + 1] = cvn;
           ndi[C::ST0 + C::STW * pa + 2] = cin;
         }
+      }
+      if constexpr (!C::EMB_LDS) {
+        pref_parent = carry_j & 0xfff;  // the root's refreshed JUMP word: where the next descent ends
+#pragma unroll
+        for (int t = 0; t < C::ES; ++t)
+          pre[t] = (j + 16 * t < E) ? gemb[(size_t)pref_parent * E + j + 16 * t] : 0.0f;
       }
     }
     MZ_TICK(5);  // backward + score refresh

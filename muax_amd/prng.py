@@ -32,9 +32,29 @@ def threefry2x32(key, x0, x1):
     return x0.astype(np.uint32), x1.astype(np.uint32)
 
 
+def _threefry_int(k0: int, k1: int, x0: int, x1: int):
+    """One block on Python ints: an order of magnitude faster than NumPy for the two or three blocks of a
+    key split (the per-environment-step cost of muax.fit's loop)."""
+    M = 0xFFFFFFFF
+    ks = (k0, k1, k0 ^ k1 ^ 0x1BD11BDA)
+    x0 = (x0 + k0) & M
+    x1 = (x1 + k1) & M
+    for g in range(5):
+        for r in _R[g & 1]:
+            x0 = (x0 + x1) & M
+            x1 = (((x1 << r) | (x1 >> (32 - r))) & M) ^ x0
+        x0 = (x0 + ks[(g + 1) % 3]) & M
+        x1 = (x1 + ks[(g + 2) % 3] + g + 1) & M
+    return x0, x1
+
+
 def random_bits(key, size: int) -> np.ndarray:
     """threefry_2x32(key, iota(size)): odd sizes are zero padded, the pad's output dropped."""
     half = (size + 1) // 2
+    if half <= 8:
+        k0, k1 = int(key[0]), int(key[1])
+        out = [_threefry_int(k0, k1, i, half + i if half + i < size else 0) for i in range(half)]
+        return np.array([o[0] for o in out] + [o[1] for o in out], np.uint32)[:size]
     x0 = np.arange(half, dtype=np.uint64)
     x1 = x0 + np.uint64(half)
     x1 = np.where(x1 < size, x1, 0)

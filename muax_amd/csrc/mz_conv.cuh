@@ -1,17 +1,20 @@
-// mz_conv.cuh -- the next-state tower of the ResNet dynamics net (muax/nn.py:344-378 with the residual
-// block of muax/nn.py:118-148) as ONE kernel: conv1x1 stem, `blocks` x ResidualConvBlockV1(64, projection)
-// = 3 x (conv3x3 + LayerNorm) each, min_max_normalize2d.  SURVEY.md 8(f) n3: this tower is 98 % of the
-// flops of BASELINE config 4's recurrent_fn (24 of its 3x3 convolutions, 6x6x64 maps).
+// mz_conv.cuh -- recurrent_fn of the reference's ResNet nets (muax/model.py:265-282 on muax/nn.py:313-378,
+// residual block muax/nn.py:118-148) as ONE kernel: reward head r_func on [s, a / num_actions]; next-state
+// tower = conv1x1 stem + `blocks` x ResidualConvBlockV1(64, projection) = 3 x (conv3x3 + LayerNorm) each +
+// min_max_normalize2d; ResNetPrediction on the next state; both support decodes.  SURVEY.md 8(f) n3: the
+// tower is 98 % of the flops of BASELINE config 4's recurrent_fn (24 3x3 convolutions on 6x6x64 maps).
 //
 // One workgroup owns one root's 6x6x64 map, which never leaves the CU: two zero-haloed 8x8-pixel buffers in
-// LDS (pixel stride 65 words, so the 16 pixels of an MFMA tile sit in 16 different banks).  A 3x3
-// convolution is an implicit GEMM  out[36 px (padded to 48)][64 co] = sum_{tap, ci} in[px + tap][ci] W[tap][ci][co]
-// on v_mfma_f32_16x16x4_f32: wave w owns output channels 16 w .. 16 w + 15 for all three pixel tiles
-// (12 accumulator registers); per k-step of 4 input channels it fetches ONE weight register from L2
-// (haiku's HWIO layout is already [k][co]) and three activation registers from LDS.  LayerNorm over the
-// whole map (two-pass mean / variance, as jnp.var) needs two workgroup reductions per convolution; the
-// projection shortcut stays in registers until the block's final add.  fp32 throughout (the search's
-// parity bar is 1e-5 on values): 65 MFLOP per root and simulation at the fp32-MFMA rate.
+// LDS (pixel stride 68 words: 16-byte aligned rows that still spread over the banks).  A 3x3 convolution is
+// an implicit GEMM  out[36 px (padded to 48)][64 co] = sum_{tap, ci} in[px + tap][ci] W[tap][ci][co]  on
+// v_mfma_f32_16x16x4_f32: wave w owns output channels 16 w .. 16 w + 15 for all three pixel tiles (12
+// accumulator registers).  K is walked in 36 groups of 16 input channels; per group a lane issues ONE
+// ds_read_b128 of activations per tile and ONE global_load_dwordx4 of weights (host-packed so that the four
+// k-steps of a lane are contiguous), six groups ahead and across convolution boundaries.  LayerNorm over the
+// whole map (two-pass mean / variance, as jnp.var) is two workgroup reductions per convolution; the
+// projection shortcut stays in registers until the block's final add.  The heads are small: 1x1 convolutions
+// on the same MFMA tiles, flatten -> Linear layers as VALU dot products with the weights streamed from L2.
+// fp32 throughout (the search's parity bar is 1e-5 on values): 65 MFLOP per root and simulation.
 //
 // Floating-point kernel: checked against the torch modules of muax_amd/nn.py (tests), tolerance there.
 #pragma once
@@ -76,7 +79,7 @@ MZ_DEV float wg_sum(float v, float* red, int wave, int lane) {
 // of its pixel with ONE ds_read_b128 and uses element i in k-step i; the matching weights
 // W[tap][16 c + 4 g + i][co] are one global_load_dwordx4 from the host-packed array
 //   Wp[tap][c][g][co][i]            (any bijection of K is a valid order for the sum).
-// Weight quads are fetched three groups ahead, activation quads one group ahead.
+// Weight quads are fetched kConvAhead groups ahead, activation quads one group ahead.
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 constexpr int kConvAhead = 6;
 struct ConvPrefetch {

@@ -181,38 +181,10 @@ struct RowLinear {
   }
 };
 
-// first layer of Dynamic: input [s, onehot(a)] (muax/nn.py:104-110).  The
-// one-hot rows are E..E+A-1 of W; zero terms of the chain are exact no-ops, so
-// the chain is "s terms, then + W[E+a]".
-template <int E, int A>
-struct RowLinearOneHot {
-  static constexpr int IS = (E + 15) / 16;
-  float w[E];
-  float wa[A];
-  float b;
-  MZ_DEV void load(const float* __restrict__ W, const float* __restrict__ Bv, int j) {
-    b = Bv[j];
-#pragma unroll
-    for (int i = 0; i < E; ++i) w[i] = W[i * kHidden + j];
-#pragma unroll
-    for (int a = 0; a < A; ++a) wa[a] = W[(E + a) * kHidden + j];
-  }
-  MZ_DEV float apply(const float (&x)[IS], int action) const {
-    float acc = 0.0f;
-    StaticFor<0, E>::run([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      acc = __builtin_fmaf(bcast<(i & 15)>(x[i >> 4]), w[i], acc);
-    });
-    float wsel = wa[0];
-#pragma unroll
-    for (int a = 1; a < A; ++a) wsel = (action == a) ? wa[a] : wsel;
-    acc = acc + wsel;
-    return acc + b;
-  }
-};
-
-// the two first layers of Dynamic (reward net, next-state net) share their input: their weights are
-// kept as (reward, state) pairs from the start, the operand form of v_pk_fma_f32
+// first layer of Dynamic: input [s, onehot(a)] (muax/nn.py:104-110).  The one-hot rows are E..E+A-1 of W;
+// zero terms of the chain are exact no-ops, so the chain is "s terms, then + W[E+a]".  The two first layers
+// (reward net, next-state net) share their input: their weights are kept as (reward, state) pairs from the
+// start, the operand form of v_pk_fma_f32
 template <int E, int A>
 struct RowLinearOneHot2 {
   f32x2 w[E];
@@ -1197,9 +1169,6 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       if (j == 0) {
         p.t_node_visits[o] = ndi[C::HDR0];
         p.t_node_values[o] = nd[C::HDR0 + 1];
-#ifdef MZ_DEBUG_JUMP
-        p.t_raw_values[o] = nd[C::JUMP];  // debugging aid: raw JUMP word bits
-#endif
       }
       if (j < A) {
         int so = C::ST0 + C::STW * j;

@@ -26,8 +26,12 @@
 //     stores its own root path as packed bytes (written once at expansion), so
 //     the backup lanes find their entries without a walk.  One simulation's
 //     selection is O(1) LDS reads plus one exact noisy evaluation per near tie;
-//   * backup's discounted-return chain runs over row broadcasts, everything
-//     else of backup is lane-parallel;
+//   * backup is lane-parallel: the discounted-return chain advances all path
+//     entries at once (G[e] = r[e] + g G[e+1] through a row_shl:1 DPP operand),
+//     running means and prior / (visits + 1) divide by small integers with a
+//     correctly rounded reciprocal from an LDS table (Markstein, 3 ops);
+//   * the node record has an odd word stride (16 records of a row in 16 banks),
+//     embeddings move to HBM when E > 16 so that 16 roots still fit a CU;
 //   * the MLPs run as row-distributed fma chains: input element i lives in lane
 //     i&15 (slot i>>4) and is fetched with a row_newbcast DPP modifier; each
 //     lane keeps its own column of every weight matrix in VGPRs.

@@ -304,6 +304,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   MZS_INST(4, 32, 21, 51, 4)   // LunarLander (BASELINE cfg3)
   MZS_INST(3, 8, 21, 33, 4)    // odd action count (tests)
   MZS_INST(4, 8, 21, 51, 2)
+  MZS_INST(2, 8, 21, 64, 3)    // CartPole up to 63 simulations (12 roots per workgroup)
 #undef MZS_INST
   return fail(h, MZS_E_UNSUPPORTED,
               "mzs_act_mlp: no fused kernel instance for this (A, E, F, S); use the step-wise path");

@@ -535,6 +535,9 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
   if (A == 2 && E == 8 && F == 21) return launch_train<mz::TrainCfg<2, 8, 21>>(p, stream);
   if (A == 4 && E == 32 && F == 21) return launch_train<mz::TrainCfg<4, 32, 21>>(p, stream);
   if (A == 3 && E == 8 && F == 21) return launch_train<mz::TrainCfg<3, 8, 21>>(p, stream);
+  if (A == 4 && E == 8 && F == 21) return launch_train<mz::TrainCfg<4, 8, 21>>(p, stream);
+  if (A == 2 && E == 16 && F == 21) return launch_train<mz::TrainCfg<2, 16, 21>>(p, stream);
+  if (A == 4 && E == 16 && F == 21) return launch_train<mz::TrainCfg<4, 16, 21>>(p, stream);
   return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: no kernel instance for this (A, E, F)");
 }
 

@@ -189,3 +189,78 @@ def fit(model, env_id=None, env=None, test_env=None, tracer=None, buffer=None, m
         if metrics is not None:
             metrics.append(row)
     return model_path
+
+
+def collect_batched(model, envs, tracers, key, num_simulations: int = 50, temperature: float = 1.0, max_steps=None):
+    """Acting half of fit() for a LIST of gym-style environments stepped in lock step: one batched
+    act(obs_from_batch=True) per step for all of them -- the use the batched HIP search is built for; the
+    reference's fit() acts on one environment at a time.  Each environment keeps its own tracer
+    (muax/train.py:150-173 per environment).  Returns the finished trajectories and the advanced key."""
+    n = len(envs)
+    obs = [e.reset()[0] for e in envs]
+    for t in tracers:
+        t.reset()
+    trajs = [Trajectory() for _ in range(n)]
+    live = list(range(n))
+    steps = max_steps if max_steps is not None else envs[0].spec.max_episode_steps
+    for _ in range(steps):
+        if not live:
+            break
+        key, subkey = prng.split(key)
+        batch = np.stack([np.asarray(obs[i], np.float32) for i in live])
+        a, pi, v = model.act(subkey, batch, with_pi=True, with_value=True, obs_from_batch=True,
+                             num_simulations=num_simulations, temperature=temperature)
+        still = []
+        for row, i in enumerate(live):
+            obs_next, r, done, truncated, info = envs[i].step(int(a[row]))
+            tracers[i].add(obs[i], int(a[row]), r, done or truncated, v=float(v[row]), pi=pi[row:row + 1])
+            while tracers[i]:
+                trajs[i].add(tracers[i].pop())
+            if not (done or truncated):
+                obs[i] = obs_next
+                still.append(i)
+        live = still
+    for tr in trajs:
+        tr.finalize()
+    return trajs, key
+
+
+def fit_batched(model, envs, test_env, tracer_factory=None, buffer=None, iterations: int = 100,
+                num_simulations: int = 50, k_steps: int = 10, num_trajectory: int = 32, sample_per_trajectory: int = 10,
+                num_update_per_iteration: int = 50, max_training_steps: int = 10000, test_interval: int = 10,
+                num_test_episodes: int = 10, random_seed: int = 42, temperature_fn=_temperature_fn, metrics=None):
+    """fit() with the acting half batched over `envs` (see collect_batched); losses, buffer sampling, the
+    temperature schedule and the greedy test are the reference's (muax/train.py:175-241).  Every iteration:
+    one lock-step episode of all environments -> buffer, `num_update_per_iteration` updates."""
+    tracer_factory = tracer_factory or (lambda: PNStep(50, 0.997, 0.5))
+    buffer = buffer if buffer is not None else TrajectoryReplayBuffer(500)
+    tracers = [tracer_factory() for _ in envs]
+    sample_input = np.expand_dims(np.asarray(envs[0].observation_space.sample()), 0).astype(float)
+    key = prng.PRNGKey(random_seed)
+    key, test_key, subkey = prng.split(key, 3)
+    model.init(subkey, sample_input)
+    training_step = 0
+    for it in range(iterations):
+        temperature = temperature_fn(max_training_steps=max_training_steps, training_steps=training_step)
+        trajs, key = collect_batched(model, envs, tracers, key, num_simulations, temperature)
+        for tr in trajs:
+            if len(tr) >= k_steps:
+                buffer.add(tr, tr.batched_transitions.w.mean())
+        row = {"iteration": it, "env_steps": int(sum(len(t) for t in trajs)),
+               "G": float(np.mean([float(np.sum(t.batched_transitions.r)) for t in trajs]))}
+        if len(buffer):
+            loss = 0.0
+            for _ in range(num_update_per_iteration):
+                loss += model.update(buffer.sample(num_trajectory=num_trajectory,
+                                                   sample_per_trajectory=sample_per_trajectory, k_steps=k_steps))["loss"]
+                training_step += 1
+            row["loss"] = loss / num_update_per_iteration
+        row["training_step"] = training_step
+        if it % test_interval == 0:
+            row["test_G"] = test(model, test_env, test_key, num_simulations=num_simulations,
+                                 num_test_episodes=num_test_episodes)
+        if metrics is not None:
+            metrics.append(row)
+        if training_step >= max_training_steps:
+            break
+    return model

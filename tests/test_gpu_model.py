@@ -335,3 +335,29 @@ def test_hip_resnet_recurrent_fn_matches_the_torch_modules():
     for x1, x0, tol in ((r1, r0, 2e-4), (v1, v0, 2e-4), (lg1, lg0, 3e-4), (ns1, ns0, 3e-4)):
         assert x1.shape == x0.shape and float((x1 - x0).abs().max()) <= tol * float(x0.abs().max()) + 1e-4, \
             (float((x1 - x0).abs().max()), float(x0.abs().max()))
+
+
+@pytest.mark.gpu
+def test_fit_batched_acts_on_all_environments_with_one_launch_per_step():
+    class Env(_ToyEnv):
+        class observation_space:
+            @staticmethod
+            def sample():
+                return np.zeros(4, F32)
+
+        def __init__(self, seed):
+            self.rng = np.random.default_rng(seed)
+
+    g = torch.Generator().manual_seed(0)
+    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
+                          mx.nn.Dynamic(8, 2, 21, generator=g))
+    model = mx.MuZero(net, optimizer=mx.optimizers.create_optimizer("adam", 5e-3))
+    rows = []
+    envs = [Env(s) for s in range(24)]
+    mx.fit_batched(model, envs, Env(99), tracer_factory=lambda: mx.PNStep(5, 0.99, 0.5), iterations=3, num_simulations=8,
+                   k_steps=4, num_trajectory=16, sample_per_trajectory=2, num_update_per_iteration=8, test_interval=2,
+                   num_test_episodes=2, metrics=rows)
+    assert len(rows) == 3 and all(r["env_steps"] >= 24 * 4 for r in rows) and rows[-1]["training_step"] == 24
+    assert "test_G" in rows[0] and "test_G" in rows[2] and all(np.isfinite(r["loss"]) for r in rows)
+    trajs, _ = mx.collect_batched(model, envs[:5], [mx.NStep(3, 0.9) for _ in range(5)], mx.prng.PRNGKey(1), 8, 1.0)
+    assert len(trajs) == 5 and all(len(t) >= 1 and t.batched_transitions.pi.shape[-2:] == (1, 2) for t in trajs)

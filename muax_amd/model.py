@@ -99,6 +99,7 @@ class MuZero:
         self._params = MZNetworkParams(*[dict(m.named_parameters()) if isinstance(m, torch.nn.Module) else None
                                          for m in self.network])
         self._weights_version += 1
+        self._fused_train = None
         return self._params
 
     @property
@@ -205,7 +206,8 @@ class MuZero:
             out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
                                invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
                                max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
-                               gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph)
+                               gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph,
+                               graph_version=self._weights_version)
             return out, root[1]
         if dirichlet_noise is None and dirichlet_fraction:
             k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
@@ -230,7 +232,7 @@ class MuZero:
                            temperature=temperature, invalid_actions=invalid_actions, max_depth=max_depth,
                            dirichlet_fraction=dirichlet_fraction, dirichlet_noise=dirichlet_noise,
                            pb_c_init=pb_c_init, pb_c_base=pb_c_base, gumbel=gumbel, tiebreak=tiebreak,
-                           with_tree=with_tree, graph=self.capture_graph)
+                           with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version)
         return out, root[1]
 
     def act(self, rng_key, obs, with_pi: bool = False, with_value: bool = False, obs_from_batch: bool = False,

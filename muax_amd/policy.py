@@ -57,7 +57,8 @@ class MuZeroPolicy(Policy):
                         dirichlet_fraction=kwargs.get("dirichlet_fraction", 0.25),
                         temperature=kwargs.get("temperature", 1.0), gumbel=kwargs.get("gumbel"),
                         with_tree=kwargs.get("with_tree", False), graph=kwargs.get("graph", False),
-                        graph_key=(fn_identity(recurrent_fn), id(params), shape))
+                        graph_key=(fn_identity(recurrent_fn), id(params), shape),
+                        graph_version=kwargs.get("graph_version", 0))
 
 
 class GumbelMuZeroPolicy(Policy):
@@ -99,7 +100,8 @@ class GumbelMuZeroPolicy(Policy):
         return h.search((prior_logits, value, emb), rec, key=rng_key,
                         invalid_actions=kwargs.get("invalid_actions"), gumbel=kwargs.get("gumbel"),
                         with_tree=kwargs.get("with_tree", False), graph=kwargs.get("graph", False),
-                        graph_key=(fn_identity(recurrent_fn), id(params), shape))
+                        graph_key=(fn_identity(recurrent_fn), id(params), shape),
+                        graph_version=kwargs.get("graph_version", 0))
 
 
 class StochasticMuZeroPolicy(Policy):

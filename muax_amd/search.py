@@ -301,7 +301,7 @@ class MuZeroSearch:
 
     def search(self, root_fn_output, recurrent_fn, key=0, invalid_actions=None,
                dirichlet_noise=None, dirichlet_fraction=0.25, temperature=1.0, gumbel=None,
-               with_tree=False, graph=False, graph_key=None) -> PolicyOutput:
+               with_tree=False, graph=False, graph_key=None, graph_version=0) -> PolicyOutput:
         """mctx.muzero_policy with a caller-supplied recurrent_fn(action, embedding) ->
         (reward, discount, prior_logits, value, next_embedding) of torch tensors.
 
@@ -310,7 +310,9 @@ class MuZeroSearch:
         them) and replays it on later calls: the loop is launch-bound -- two tree kernels plus the
         plugin's own small kernels per simulation -- and a graph launch removes the per-kernel host cost.
         recurrent_fn must then be capture-safe (no host synchronisation, static shapes); the per-call
-        PRNG keys live in device memory (root) or in the un-captured root/finish calls."""
+        PRNG keys live in device memory (root) or in the un-captured root/finish calls.  `graph_version`
+        is the caller's weights version: host-side work of recurrent_fn (e.g. re-packing convolution weights)
+        is frozen into a capture, so a new version re-captures and replaces the old graph."""
         prior_logits, value, embedding = root_fn_output
 
         def do_root():
@@ -331,6 +333,8 @@ class MuZeroSearch:
         else:
             gkey = graph_key if graph_key is not None else fn_identity(recurrent_fn)
             entry = self._graphs.get(gkey)
+            if entry is not None and entry[3] != graph_version:
+                entry = None
             if entry is None:
                 # warm-up run (lazy library initialisation must not happen under capture), then the tree
                 # is rebuilt from the same root and the loop is captured (capture records, it does not run)
@@ -344,6 +348,6 @@ class MuZeroSearch:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         loop()
-                entry = self._graphs[gkey] = (g, recurrent_fn, self._keep)
+                entry = self._graphs[gkey] = (g, recurrent_fn, self._keep, graph_version)
             entry[0].replay()
         return self.finish(temperature, None if self.cfg.policy == "gumbel" else gumbel, with_tree)

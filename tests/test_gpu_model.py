@@ -361,3 +361,26 @@ def test_fit_batched_acts_on_all_environments_with_one_launch_per_step():
     assert "test_G" in rows[0] and "test_G" in rows[2] and all(np.isfinite(r["loss"]) for r in rows)
     trajs, _ = mx.collect_batched(model, envs[:5], [mx.NStep(3, 0.9) for _ in range(5)], mx.prng.PRNGKey(1), 8, 1.0)
     assert len(trajs) == 5 and all(len(t) >= 1 and t.batched_transitions.pi.shape[-2:] == (1, 2) for t in trajs)
+
+
+@pytest.mark.gpu
+def test_captured_graph_follows_weight_updates():
+    """The hipGraph of the plugin loop freezes host-side work of recurrent_fn (the ResNet dynamics re-packs its
+    convolution weights for the HIP tower): after the weights change the graph must be re-captured."""
+    g = torch.Generator().manual_seed(2)
+    mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(18, 21, generator=g),
+            mx.nn.ResNetDynamic(18, 21, generator=g))
+    obs = np.random.default_rng(1).integers(0, 256, (4, 84, 84, 4)).astype(F32)
+    eager, graph = mx.MuZero(*mods), mx.MuZero(*mods, capture_graph=True)
+    eager.init(0, obs[:1])
+    graph.init(0, obs[:1])
+    kw = dict(with_pi=True, with_value=True, obs_from_batch=True, num_simulations=6)
+    for step in range(2):
+        a1, pi1, v1 = eager.act(9, obs, **kw)
+        a2, pi2, v2 = graph.act(9, obs, **kw)
+        assert (pi1 == pi2).all() and np.allclose(v1, v2, rtol=1e-5), step
+        with torch.no_grad():  # a "training step": every tower weight moves
+            for p in mods[2].ns_blocks.parameters():
+                p.mul_(1.05)
+        eager.weights_changed()
+        graph.weights_changed()

@@ -1,0 +1,39 @@
+"""Randomised parity stress (not part of the suite): the fused kernel against the C oracle over many seeds,
+shapes, simulation counts, depth cuts, invalid-action masks, weight scales.  Run on the GPU box:
+    python tools/stress_parity.py [cases]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import assert_trees_equal, make_case  # noqa: E402
+from oracle import pyoracle as oracle  # noqa: E402
+import test_gpu_parity as tp  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(2024)
+shapes = [(2, 8, 4), (3, 8, 6), (4, 8, 5), (2, 16, 4), (4, 16, 8), (4, 32, 8)]
+bad = 0
+for c in range(n):
+    A, E, obs_dim = shapes[rng.integers(len(shapes))]
+    S = int(rng.integers(1, 51))
+    B = int(rng.integers(1, 200))
+    tiebreak = bool(rng.integers(2))
+    max_depth = None if rng.random() < 0.6 else int(rng.integers(1, S + 1))
+    case = make_case(oracle, 1000 + c, B, obs_dim, E, A, S, invalid_frac=0.3 if (A > 2 and rng.random() < 0.4) else 0.0)
+    scale = float(rng.choice([0.3, 1.0, 3.0]))  # sharper / flatter heads: other depths and tie patterns
+    case["w"] = {k: (v * scale).astype(np.float32) if k.endswith(("w1", "w2")) else v for k, v in case["w"].items()}
+    temperature = float(rng.choice([0.0, 0.5, 1.0]))
+    key = [int(rng.integers(2 ** 31)), int(rng.integers(2 ** 31))]
+    try:
+        s, out = tp._fused(case, tiebreak, key, max_depth=max_depth, temperature=temperature)
+        ref = tp._oracle(oracle, case, tiebreak, key, max_depth=max_depth or 0, temperature=temperature)
+        tp._compare(ref, s, out)
+    except AssertionError as e:
+        bad += 1
+        print(f"MISMATCH case {c}: A={A} E={E} S={S} B={B} tb={tiebreak} md={max_depth} scale={scale} T={temperature}: {str(e)[:200]}")
+print(f"{n} cases, {bad} mismatches; mean depth of the last case {float(s.depth_sum.float().mean()) / S:.2f}")

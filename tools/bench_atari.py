@@ -33,7 +33,10 @@ def main():
             m.act(10 + i, obs, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"{name:9s} roots={B} S={S} A=18 E=2304: {dt * 1e3:9.2f} ms/act  {B / dt:10.1f} env-steps/s")
+        h = list(m._policy._handles.values())[0]
+        depth = float(h.depth_sum.float().mean()) / S
+        print(f"{name:9s} roots={B} S={S} A=18 E=2304: {dt * 1e3:9.2f} ms/act  {B / dt:10.1f} env-steps/s  "
+              f"(mean selection depth {depth:.1f})")
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -11,6 +12,7 @@
 #include "../../include/mzsearch.h"
 #include "mz_fused.cuh"
 #include "mz_step.cuh"
+#include "mz_step_jump.cuh"
 #include "mz_train.cuh"
 #include "mz_conv.cuh"
 
@@ -62,6 +64,9 @@ struct mzs_handle {
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
   int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
   float* fused_emb = nullptr;      // fused path, embed_dim > 16: [B][S+1][E] embeddings in HBM
+  mz::JumpArgs jump = {nullptr, nullptr, nullptr, nullptr};  // step-wise path with cached decisions
+  void* jump_slab = nullptr;
+  bool use_jump = false;
 };
 
 namespace {
@@ -211,6 +216,7 @@ int mzs_destroy(mzs_handle* h) {
   h->step.release();
   if (h->fused_table) hipFree(h->fused_table);
   if (h->fused_emb) hipFree(h->fused_emb);
+  if (h->jump_slab) hipFree(h->jump_slab);
   delete h;
   return MZS_OK;
 }
@@ -341,6 +347,21 @@ static int ensure_step_state(mzs_handle* h) {
   const int table_words = rows * c.num_simulations;
   hipError_t e = h->step.allocate(c.batch, c.num_simulations + 1, c.num_actions, c.embed_dim, table_words);
   if (e != hipSuccess) return fail(h, MZS_E_RUNTIME, "tree allocation: %s", hipGetErrorString(e));
+  // cached-decision kernels (mz_step_jump.cuh): MuZero policy, bounded tree, B N^2 path words within 1 GiB;
+  // MZS_STEP_WALK=1 keeps the level-by-level kernels (A/B testing)
+  {
+    const size_t B = (size_t)c.batch, N = (size_t)c.num_simulations + 1;
+    const char* walk = getenv("MZS_STEP_WALK");
+    if (c.policy == 0 && N <= (size_t)mz::kJumpMaxNodes && B * N * N * 4 <= ((size_t)1 << 30) && !(walk && walk[0] == '1')) {
+      const size_t words = 3 * B * N + B * N * N;
+      if (hipMalloc(&h->jump_slab, words * 4) == hipSuccess) {
+        int32_t* w = static_cast<int32_t*>(h->jump_slab);
+        h->jump.jump_pa = w; h->jump.jump_lv = w + B * N; h->jump.node_depth = w + 2 * B * N;
+        h->jump.node_path = reinterpret_cast<uint32_t*>(w + 3 * B * N);
+        h->use_jump = true;
+      }
+    }
+  }
   if (table_words) {
     std::vector<int32_t> table((size_t)table_words);
     for (int m = 0; m < rows; ++m) considered_visits(m, c.num_simulations, table.data() + (size_t)m * c.num_simulations);
@@ -372,6 +393,8 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
   hipLaunchKernelGGL(mz::step_root_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, prior_logits,
                      value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction, 0,
                      static_cast<const float*>(nullptr), 0u, 0u);
+  if (h->use_jump)
+    hipLaunchKernelGGL(mz::jump_root_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, h->jump);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   h->step.rooted = true;
@@ -410,7 +433,10 @@ int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_em
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
-  if (c.policy == 1)
+  if (h->use_jump)
+    hipLaunchKernelGGL(mz::jump_select_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, h->jump, sim,
+                       action_out, parent_embedding_out);
+  else if (c.policy == 1)
     hipLaunchKernelGGL(mz::step_select_gumbel_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        action_out, parent_embedding_out);
   else
@@ -433,8 +459,14 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
-  hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
-                     reward, discount, prior_logits, value, next_embedding);
+  if (h->use_jump)
+    // small batches: 16 levels in flight per root; large ones: one wavefront per root keeps the launch small
+    hipLaunchKernelGGL(mz::jump_expand_backup_kernel, dim3(c.batch), dim3(c.batch <= 1024 ? 256 : 64),
+                       sizeof(int32_t) * 15 * ((size_t)c.num_simulations + 2),
+                       stream, sa, h->jump, sim, reward, discount, prior_logits, value, next_embedding);
+  else
+    hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
+                       reward, discount, prior_logits, value, next_embedding);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(next_embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;

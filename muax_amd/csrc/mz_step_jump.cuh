@@ -1,0 +1,358 @@
+// mz_step_jump.cuh -- step-wise MuZero search with cached decisions (the fused kernel's scheme) on the
+// HBM-resident tree of mz_step.cuh.  Same C-ABI entry points (mzs_root / mzs_select / mzs_expand_backup),
+// same arithmetic per node, same results bit for bit; what changes is WHERE the per-level work happens:
+//
+//   * mctx's simulate() walks the tree level by level, a chain of dependent decisions.  Here every node
+//     carries a JUMP record: the end point (parent, action, level) of the greedy, noise-free descent below
+//     it, stopped early at the first node whose argmax is a near tie (fl(score + 1e-7) !< best for some
+//     other action: only there can mctx's 1e-7 * uniform tie-break noise matter).  Sub-trees off a
+//     backed-up path never change, so their records stay valid.  mzs_select reads the root's record: O(1),
+//     plus one exact noisy evaluation per near tie (JAX's key chain is walked lazily down to that level);
+//   * the decisions of the nodes ON the backed-up path are refreshed by mzs_expand_backup, where the path
+//     is known up front: one workgroup per root, one 16-lane row per LEVEL (lanes over the actions), 16
+//     levels in flight, all their loads independent.  The discounted-return chain is the only sequential
+//     part and runs over LDS.
+//
+// Every node stores its own root path (written once at expansion: parent's path + one entry), so the
+// backup finds its levels without a pointer chase.  Used for the MuZero policy when N <= kJumpMaxNodes
+// and B N^2 words fit the budget; otherwise mz_step.cuh's walking kernels run.
+#pragma once
+#include "mz_step.cuh"
+
+#pragma clang fp contract(off)
+
+namespace mz {
+
+constexpr int kJumpMaxNodes = 1024;
+
+#define MZ_JROW_SETUP                                                 \
+  const int lane = threadIdx.x & 63;                                  \
+  const int j = lane & 15;                                            \
+  const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);  \
+  if (r >= s.B) return;                                               \
+  const int N = s.N, A = s.A, E = s.E;                                \
+  const size_t rb = (size_t)r * N;                                    \
+  (void)lane; (void)N; (void)A; (void)E;
+
+struct JumpArgs {
+  int32_t* jump_pa;     // [B][N]  parent | action << 16 | near tie << 31
+  int32_t* jump_lv;     // [B][N]  level of `parent` (edges from the root)
+  int32_t* node_depth;  // [B][N]  length of the node's own root path
+  uint32_t* node_path;  // [B][N][N]  entry e = node at level e | action taken there << 16
+};
+
+// pUCT scores of all children of `node` (muzero_action_selection with qtransform_by_parent_and_siblings),
+// noise-free; first-max argmax; `near` = some other action is within the reach of the tie-break noise.
+MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, float (&sc)[kMaxAS],
+                         int (&cidx)[kMaxAS], int& best, int& child, bool& near) {
+  const int A = s.A;
+  const size_t nb = (rb + node) * A;
+  const int nvis = s.node_visits[rb + node];
+  const float nval = s.node_values[rb + node];
+  const float tn = puct_scale(nvis, s.pb_c_init, s.pb_c_base);
+  float q[kMaxAS], prob[kMaxAS];
+  int cvis[kMaxAS];
+  float lo = nval, hi = nval;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    const int a = j + 16 * t;
+    const bool ok = a < A;
+    cidx[t] = -1; cvis[t] = 0; prob[t] = 0.0f; q[t] = 0.0f;
+    if (16 * t < A) {
+      const size_t o = nb + (ok ? a : 0);
+      cidx[t] = s.children_index[o];
+      cvis[t] = s.children_visits[o];
+      prob[t] = s.children_prior_probs[o];
+      q[t] = s.children_rewards[o] + s.children_discounts[o] * s.children_values[o];
+      const float safe = (ok && cvis[t] > 0) ? q[t] : nval;
+      lo = fminf(lo, safe);
+      hi = fmaxf(hi, safe);
+    }
+  }
+  lo = row_min<4>(lo);
+  hi = row_max<4>(hi);
+  const float span = fmaxf(hi - lo, 1e-8f);
+  float bscore = -INFINITY;
+  best = 1 << 20;
+  child = -1;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    const int a = j + 16 * t;
+    const bool ok = a < A;
+    sc[t] = -INFINITY;
+    if (16 * t < A) {
+      const float value_score = ((cvis[t] > 0 ? q[t] : lo) - lo) / span;
+      const float policy_score = (tn * prob[t]) / (float)(cvis[t] + 1);
+      sc[t] = value_score + policy_score;
+      if (node == 0 && ok && s.root_invalid[(size_t)r * A + a]) sc[t] = -INFINITY;  // the root is level 0 only
+      if (!ok) sc[t] = -INFINITY;
+    }
+    const bool take = (t == 0) || (sc[t] > bscore);  // first max wins inside the lane
+    if (take) { bscore = sc[t]; best = ok ? a : (1 << 20); child = cidx[t]; }
+  }
+  row_argmax<4>(bscore, best, child);
+  bool unsafe = false;
+  if (s.tiebreak) {
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      const int a = j + 16 * t;
+      unsafe = unsafe || (a < A && a != best && !((sc[t] + 1e-7f) < bscore));
+    }
+  }
+  near = ((__builtin_amdgcn_ballot_w64(unsafe) >> (threadIdx.x & 48)) & 0xffffull) != 0;  // any lane of the row
+}
+
+// root decision (after step_root_kernel): one row per root
+__global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) {
+  MZ_JROW_SETUP
+  float sc[kMaxAS];
+  int cidx[kMaxAS], best, child;
+  bool near;
+  level_decide(s, rb, r, 0, j, sc, cidx, best, child, near);
+  if (j == 0) {
+    g.jump_pa[rb] = best << 16 | (near ? (int)0x80000000 : 0);
+    g.jump_lv[rb] = 0;
+    g.node_depth[rb] = 0;
+  }
+}
+
+// mctx search.simulate through the JUMP records
+__global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g, int sim, int32_t* action_out,
+                                                           float* parent_embedding_out) {
+  MZ_JROW_SETUP
+  const uint64_t rg = s.root_offset + (uint64_t)r;
+  const int NB = (A + 1) / 2;
+  uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 0;
+  int klevel = -1;  // key walk not started
+  int jw = g.jump_pa[rb], level = g.jump_lv[rb];
+  int parent, action;
+  for (;;) {
+    parent = jw & 0xffff;
+    action = (jw >> 16) & 0xff;
+    if (jw < 0 && level + 1 <= s.max_depth) {
+      // near tie at `parent`: score + 1e-7 * uniform(action_selection_key of this level), as mctx
+      if (klevel < 0) {
+        uint32_t x0, x1;
+        bool second;
+        bits_block(2 * s.global_batch, 2 * rg + (uint64_t)(j & 1), x0, x1, second);
+        threefry2x32(s.sim_keys[2 * sim], s.sim_keys[2 * sim + 1], x0, x1);
+        const uint32_t word = second ? x1 : x0;
+        k0 = bcast_u<0>(word);
+        k1 = bcast_u<1>(word);
+        klevel = 0;
+      }
+      while (klevel <= level) {  // rng_key, action_selection_key = split(rng_key), level by level
+        uint32_t x0 = (uint32_t)(j & 1), x1 = 2u + (uint32_t)(j & 1);
+        threefry2x32(k0, k1, x0, x1);
+        k0 = bcast_u<0>(x0); k1 = bcast_u<1>(x0);
+        s0 = bcast_u<0>(x1); s1 = bcast_u<1>(x1);
+        klevel += 1;
+      }
+      float sc[kMaxAS];
+      int cidx[kMaxAS], best, child;
+      bool near;
+      level_decide(s, rb, r, parent, j, sc, cidx, best, child, near);
+      float bscore = -INFINITY;
+      best = 1 << 20;
+      child = -1;
+#pragma unroll
+      for (int t = 0; t < kMaxAS; ++t) {
+        const int a = j + 16 * t;
+        float score = sc[t];
+        if (16 * t < A) {
+          const int jb = a < NB ? a : a - NB;
+          uint32_t x0 = (uint32_t)jb, x1 = (NB + jb < A) ? (uint32_t)(NB + jb) : 0u;
+          threefry2x32(s0, s1, x0, x1);
+          score = score + 1e-7f * uniform_from_bits(a < NB ? x0 : x1);
+        }
+        const bool take = (t == 0) || (score > bscore);
+        if (take) { bscore = score; best = (a < A) ? a : (1 << 20); child = cidx[t]; }
+      }
+      row_argmax<4>(bscore, best, child);
+      action = best;
+      if (child >= 0 && level + 1 < s.max_depth) {
+        jw = g.jump_pa[rb + child];
+        level = g.jump_lv[rb + child];
+        continue;
+      }
+    }
+    break;
+  }
+  int depth = level + 1;
+  if (depth > s.max_depth) {
+    // the cached descent overshoots max_depth: stop at level max_depth - 1 of the same path
+    depth = s.max_depth;
+    const uint32_t ent = g.node_path[(rb + parent) * N + depth - 1];
+    parent = (int)(ent & 0xffffu);
+    action = (int)(ent >> 16);
+  }
+  if (j == 0) {
+    s.sel_parent[r] = parent;
+    s.sel_action[r] = action;
+    s.sel_depth[r] = depth;
+    s.depth_sum[r] += depth;
+    action_out[r] = action;
+  }
+  if (s.wide) {
+    if (j == 0) s.xfer_node[r] = parent;
+  } else {
+    const float* src = s.embeddings + (rb + parent) * E;
+    for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
+  }
+}
+
+// mctx search.expand + search.backward + refresh of the decisions on the path: one workgroup per root
+__global__ __launch_bounds__(256) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
+                                                                  const float* discount, const float* prior_logits,
+                                                                  const float* value, const float* next_embedding) {
+  extern __shared__ int lds_i[];
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x, j = tid & 15, row = tid >> 4;
+  const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 256 threads (16 levels in flight) or one wavefront (4)
+  const int N = s.N, A = s.A, E = s.E;
+  const size_t rb = (size_t)r * N;
+  const int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
+  const size_t eo = (rb + parent) * A + action;
+  const int next = s.children_index[eo];
+  __syncthreads();  // every thread has read the edge before row 0 rewrites it
+  const bool fresh = next == -1;
+  const int newn = fresh ? sim + 1 : next;
+  const float v = value[r], rew_new = reward[r], dis_new = discount[r];
+  // LDS: per level e in [0, depth] (entry `depth` is the leaf)
+  const int D1 = N + 1;
+  int* pn = lds_i;                 // node at level e
+  int* pa = pn + D1;               // action taken at level e (e < depth)
+  int* cnt = pa + D1;              // node_visits before this backup
+  float* val = reinterpret_cast<float*>(cnt + D1);  // node_values before this backup
+  float* rw = val + D1;            // reward of edge e
+  float* ds = rw + D1;             // discount of edge e
+  float* Gs = ds + D1;             // leaf_value arriving at level e
+  float* nv = Gs + D1;             // node value after this backup
+  int* bst = reinterpret_cast<int*>(nv + D1);  // refreshed decision
+  int* chd = bst + D1;             // its child index
+  int* flg = chd + D1;             // near tie
+  int* cjp = flg + D1;             // stored JUMP record of that child
+  int* cjl = cjp + D1;
+  int* njp = cjl + D1;             // new JUMP record of the level's node
+  int* njl = njp + D1;
+
+  // -- path of the leaf: the parent's own root path + (parent, action) --
+  for (int e = tid; e < depth; e += nthr) {
+    const uint32_t ent = (e < depth - 1) ? g.node_path[(rb + parent) * N + e] : ((uint32_t)parent | ((uint32_t)action << 16));
+    pn[e] = (int)(ent & 0xffffu);
+    pa[e] = (int)(ent >> 16);
+    if (fresh) g.node_path[(rb + newn) * N + e] = ent;
+  }
+  if (tid == 0) {
+    pn[depth] = newn;
+    pa[depth] = 0;
+    if (fresh) g.node_depth[rb + newn] = depth;
+  }
+  // -- expand (row 0): prior of the new node, node and edge records --
+  if (row == 0) {
+    float x[kMaxAS], pr[kMaxAS];
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      const int a = j + 16 * t;
+      x[t] = a < A ? prior_logits[(size_t)r * A + a] : 0.0f;
+    }
+    row_softmax_rt(x, A, j, pr);
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      const int a = j + 16 * t;
+      if (a < A) {
+        s.children_prior_logits[(rb + newn) * A + a] = x[t];
+        s.children_prior_probs[(rb + newn) * A + a] = pr[t];
+      }
+    }
+    if (j == 0) {
+      s.raw_values[rb + newn] = v;
+      s.node_values[rb + newn] = v;
+      s.node_visits[rb + newn] = s.node_visits[rb + newn] + 1;
+      s.children_index[eo] = newn;
+      s.children_rewards[eo] = rew_new;
+      s.children_discounts[eo] = dis_new;
+      s.parents[rb + newn] = parent;
+      s.action_from_parent[rb + newn] = action;
+      s.xfer_node[r] = newn;
+    }
+  }
+  if (!s.wide)
+    for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
+  __syncthreads();
+  // -- per-level inputs of the backward pass --
+  for (int e = tid; e < depth; e += nthr) {
+    const size_t e2 = (rb + pn[e]) * A + pa[e];
+    cnt[e] = s.node_visits[rb + pn[e]];
+    val[e] = s.node_values[rb + pn[e]];
+    rw[e] = (e == depth - 1) ? rew_new : s.children_rewards[e2];
+    ds[e] = (e == depth - 1) ? dis_new : s.children_discounts[e2];
+  }
+  __syncthreads();
+  // -- leaf_value = reward + discount * leaf_value, leaf to root (the one sequential chain) --
+  if (tid == 0) {
+    float G = v;
+    for (int e = depth - 1; e >= 0; --e) {
+      G = rw[e] + ds[e] * G;
+      Gs[e] = G;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e <= depth; e += nthr)
+    nv[e] = (e == depth) ? v : (val[e] * (float)cnt[e] + Gs[e]) / ((float)cnt[e] + 1.0f);
+  __syncthreads();
+  for (int e = tid; e < depth; e += nthr) {
+    const size_t e2 = (rb + pn[e]) * A + pa[e];
+    s.node_values[rb + pn[e]] = nv[e];
+    s.node_visits[rb + pn[e]] = cnt[e] + 1;
+    s.children_values[e2] = nv[e + 1];
+    s.children_visits[e2] = s.children_visits[e2] + 1;
+  }
+  __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
+  // -- decisions of the path nodes and the leaf: one row per level --
+  for (int base = 0; base <= depth; base += nrows) {
+    const int e = base + row;
+    if (e <= depth) {
+      float sc[kMaxAS];
+      int cidx[kMaxAS], best, child;
+      bool near;
+      level_decide(s, rb, r, pn[e], j, sc, cidx, best, child, near);
+      if (j == 0) {
+        bst[e] = best;
+        chd[e] = child;
+        flg[e] = near ? 1 : 0;
+        const bool off_path = child >= 0 && !(e < depth && child == pn[e + 1]);
+        cjp[e] = off_path ? g.jump_pa[rb + child] : 0;
+        cjl[e] = off_path ? g.jump_lv[rb + child] : 0;
+      }
+    }
+  }
+  __syncthreads();
+  // -- JUMP records bottom-up: own end point, the off-path child's record, or the next level's new one --
+  if (tid == 0) {
+    for (int e = depth; e >= 0; --e) {
+      int jp, jl;
+      if (flg[e] || chd[e] < 0) {
+        jp = pn[e] | (bst[e] << 16) | (flg[e] ? (int)0x80000000 : 0);
+        jl = e;
+      } else if (e < depth && chd[e] == pn[e + 1]) {
+        jp = njp[e + 1];
+        jl = njl[e + 1];
+      } else {
+        jp = cjp[e];
+        jl = cjl[e];
+      }
+      njp[e] = jp;
+      njl[e] = jl;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e <= depth; e += nthr) {
+    g.jump_pa[rb + pn[e]] = njp[e];
+    g.jump_lv[rb + pn[e]] = njl[e];
+  }
+}
+
+#undef MZ_JROW_SETUP
+
+}  // namespace mz

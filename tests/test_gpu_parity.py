@@ -210,9 +210,13 @@ def _torch_recurrent(case):
 
 @pytest.mark.parametrize("tiebreak", [False, True])
 @pytest.mark.parametrize("A,E,S,B", [(2, 8, 20, 70), (5, 8, 24, 33), (18, 40, 30, 40), (18, 300, 12, 21)])  # E >= 256: wide rows
-def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak):
+@pytest.mark.parametrize("walk", [False, True])
+def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak, walk, monkeypatch):
     """Plugin-net path: torch nets between mzs_select and mzs_expand_backup; the oracle is fed the very
-    same net outputs, so every tree array must agree exactly."""
+    same net outputs, so every tree array must agree exactly.  Both sets of tree kernels: cached decisions
+    (mz_step_jump.cuh, the default) and the level-by-level walk (mz_step.cuh, MZS_STEP_WALK=1)."""
+    if walk:
+        monkeypatch.setenv("MZS_STEP_WALK", "1")
     from muax_amd import MuZeroSearch, SearchConfig
     case = make_case(oracle, 20 + A, B, 6, E, A, S, invalid_frac=0.2 if A > 2 else 0.0)
     root, rec = _torch_recurrent(case)

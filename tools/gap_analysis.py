@@ -19,7 +19,7 @@ for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
     g[1] += 1
 for k, (tot, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
     print(f"{tot / 1e6:8.2f} ms  n={n:5d}  avg {tot / n / 1e3:7.1f} us   {k[0]}  ->  {k[1]}")
-idx = [i for i, r in enumerate(rows) if 'step_select' in r[0]]
+idx = [i for i, r in enumerate(rows) if 'select_kernel' in r[0]]
 mid = idx[-6] - 2 if len(idx) > 6 else len(rows) - 400
 print("--- a stretch of the trace (gap before, duration, kernel) ---")
 for (n0, s0, e0), (n1, s1, e1) in list(zip(rows, rows[1:]))[mid:mid + 36]:

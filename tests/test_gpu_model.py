@@ -384,3 +384,25 @@ def test_captured_graph_follows_weight_updates():
                 p.mul_(1.05)
         eager.weights_changed()
         graph.weights_changed()
+
+
+@pytest.mark.gpu
+def test_update_trains_the_resnet_plugin_nets_through_autograd():
+    """Plugin nets have no fused training kernel: update() takes the torch autograd route (and refuses
+    backend='hip'); acting afterwards uses the refreshed weights in the HIP recurrent kernel."""
+    g = torch.Generator().manual_seed(4)
+    mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(18, 21, generator=g),
+            mx.nn.ResNetDynamic(18, 21, generator=g))
+    m = mx.MuZero(*mods, optimizer=mx.optimizers.create_optimizer("adam", 1e-3))
+    rng = np.random.default_rng(0)
+    obs = rng.integers(0, 256, (3, 2, 84, 84, 4)).astype(F32)
+    m.init(0, obs[:1, 0])
+    batch = mx.Transition(obs=obs, a=rng.integers(0, 18, (3, 2)), r=rng.uniform(0, 1, (3, 2)).astype(F32),
+                          Rn=rng.uniform(0, 5, (3, 2)).astype(F32), pi=rng.dirichlet(np.ones(18), (3, 2)).astype(F32))
+    with pytest.raises(ValueError):
+        m.update(batch, backend="hip")
+    a0, pi0, v0 = m.act(1, obs[:, 0], with_pi=True, with_value=True, obs_from_batch=True, num_simulations=6)
+    losses = [m.update(batch)["loss"] for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    a1, pi1, v1 = m.act(1, obs[:, 0], with_pi=True, with_value=True, obs_from_batch=True, num_simulations=6)
+    assert not np.array_equal(v0, v1)  # the search sees the updated weights

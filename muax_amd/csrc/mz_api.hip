@@ -311,6 +311,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   MZS_INST(3, 8, 21, 51, 4)    // three actions (Acrobot / MountainCar shapes)
   MZS_INST(4, 8, 21, 51, 3)    // four actions, small embedding: 12 roots per workgroup
   MZS_INST(2, 8, 21, 64, 3)    // CartPole up to 63 simulations (12 roots per workgroup)
+  MZS_INST(2, 8, 21, 128, 1)   // ... up to 127 (4 roots per workgroup)
   MZS_INST(2, 16, 21, 51, 4)   // wider embeddings / more actions of the same default trio
   MZS_INST(4, 16, 21, 51, 3)
 #undef MZS_INST

@@ -130,8 +130,10 @@ struct FusedCfg {
   // HBM ([root][node][E], one coalesced E*4-byte row per access, L2-resident while the root is active)
   static constexpr bool EMB_LDS = E_ <= 16;
   static constexpr int EMB0 = ST0 + STW * A;
-  static constexpr int ENTRY_BITS = (NMAX <= 64 && A <= 4) ? 8 : 16;
-  static constexpr int ENTRY_ACT_SHIFT = ENTRY_BITS == 8 ? 6 : 12;
+  // a path entry packs (node, action): one byte while ceil(log2 NMAX) + ceil(log2 A) <= 8, else 16 bits
+  static constexpr int NODE_BITS = ceil_log2(NMAX), ACT_BITS = ceil_log2(A) < 1 ? 1 : ceil_log2(A);
+  static constexpr int ENTRY_BITS = (NODE_BITS + ACT_BITS <= 8) ? 8 : 16;
+  static constexpr int ENTRY_ACT_SHIFT = ENTRY_BITS == 8 ? NODE_BITS : 12;
   static constexpr int PATH0 = EMB0 + (EMB_LDS ? E : 0);
   static constexpr int PATHW = (NMAX * ENTRY_BITS + 31) / 32;
   // odd record stride: lane e of the backup reads node(e)'s record, and with an odd stride the 16 records
@@ -142,7 +144,8 @@ struct FusedCfg {
   static constexpr int NOISE_WORDS = 0;
   static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
   static_assert(A <= PATHW, "the root's (empty) path slot holds its Gumbel noise");
-  static_assert(PATHW <= 16, "a node's path is copied by one lane per word");
+  static constexpr int PATHS = (PATHW + 15) / 16;  // path words per lane when a node's path is copied
+  static_assert(PATHS <= 4, "a node's path is copied by the 16 lanes of its row");
   // the four roots of a wave start 8 banks apart: row-uniform reads of the same field of four trees
   // (selection, expansion) then hit four different banks
   static constexpr int pad_root(int w) { return w + ((8 - w % 32 + 32) % 32); }
@@ -875,7 +878,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     int* nni = reinterpret_cast<int*>(nn);
     const unsigned po = __umul24((unsigned)parent, (unsigned)NS);
     const int vis_old = nni[C::HDR0];
-    const int ppw = itree[po + C::PATH0 + (j < C::PATHW ? j : 0)];
+    int ppw[C::PATHS];
+#pragma unroll
+    for (int t = 0; t < C::PATHS; ++t) ppw[t] = itree[po + C::PATH0 + (j + 16 * t < C::PATHW ? j + 16 * t : 0)];
     float reward, value, pil, pprob;
     float ns[C::ES];
     nets.forward(sp, action, j, support, p.pred_on_parent != 0, reward, value, pil, pprob, ns);
@@ -899,16 +904,20 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         itree[po + C::SEL0 + 2 * action] = newn;
         tree[po + C::ST0 + C::STW * action + 3] = reward;
       }
-      if (fresh && j < C::PATHW) {
+      if (fresh) {
         // the new node's root path = its parent's path + (parent, action); written once
         const int e = depth - 1;
-        int w = ppw;
         const int sh = (e * C::ENTRY_BITS) & 31;
         const int ent = parent | (action << C::ENTRY_ACT_SHIFT);
-        w = (j == ((e * C::ENTRY_BITS) >> 5))
-                ? (int)(((unsigned)w & ~(((1u << C::ENTRY_BITS) - 1u) << sh)) | ((unsigned)ent << sh))
-                : w;
-        nni[C::PATH0 + j] = w;
+#pragma unroll
+        for (int t = 0; t < C::PATHS; ++t) {
+          const int wi = j + 16 * t;
+          int w = ppw[t];
+          w = (wi == ((e * C::ENTRY_BITS) >> 5))
+                  ? (int)(((unsigned)w & ~(((1u << C::ENTRY_BITS) - 1u) << sh)) | ((unsigned)ent << sh))
+                  : w;
+          if (wi < C::PATHW) nni[C::PATH0 + wi] = w;
+        }
       }
       if (ex) {
         size_t o = (size_t)r * N + newn;

@@ -54,7 +54,7 @@ def _compare(ref, s, out):
 
 
 @pytest.mark.parametrize("tiebreak", [False, True])
-@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100), (2, 8, 63, 150), (3, 8, 50, 90), (2, 16, 50, 70), (4, 16, 40, 50)])
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100), (2, 8, 63, 150), (3, 8, 50, 90), (2, 16, 50, 70), (4, 16, 40, 50), (2, 8, 100, 60), (2, 8, 127, 30)])
 def test_fused_matches_oracle(oracle, A, E, S, B, tiebreak):
     case = make_case(oracle, 10 * A + E, B, 4 if E == 8 else 8, E, A, S)
     key = [123, 456 + A]
@@ -354,7 +354,7 @@ def test_stepwise_many_simulations_and_wide_actions(oracle):
 
 
 def test_model_act_falls_back_to_stepwise_above_fused_limits():
-    """num_simulations = 64 has no fused instance for the default trio: act() must still work (step-wise
+    """num_simulations = 160 has no fused instance for the default trio: act() must still work (step-wise
     kernels + torch nets) and keep the reference's conventions."""
     import muax_amd as mx
     g = torch.Generator().manual_seed(0)
@@ -363,8 +363,9 @@ def test_model_act_falls_back_to_stepwise_above_fused_limits():
     m = mx.MuZero(net)
     m.init(0, np.zeros((1, 4)))
     obs = np.random.default_rng(0).uniform(-1, 1, (10, 4)).astype(F32)
-    a, pi = m.act(2, obs, with_pi=True, obs_from_batch=True, num_simulations=64)
-    assert a.shape == (10,) and np.allclose(pi.sum(1), 1, atol=1e-6) and (pi * 64 == np.round(pi * 64)).all()
+    a, pi = m.act(2, obs, with_pi=True, obs_from_batch=True, num_simulations=160)
+    assert a.shape == (10,) and np.allclose(pi.sum(1), 1, atol=1e-6) and np.allclose(pi * 160, np.round(pi * 160), atol=1e-4)
+    assert len(m._policy._handles) == 1  # went through the step-wise policy adapter
 
 
 def test_bad_arguments_raise_value_error():

@@ -308,6 +308,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   if (A == A_ && E == E_ && F == F_ && N <= NMAX_) return dispatch_mode<A_, E_, F_, NMAX_, WAVES_>(h, p, stream);
   MZS_INST(2, 8, 21, 51, 4)    // CartPole   (BASELINE cfg1/cfg2; README.md:102-132)
   MZS_INST(4, 32, 21, 51, 4)   // LunarLander (BASELINE cfg3)
+  MZS_INST(4, 32, 21, 101, 1)  // ... up to 100 simulations (4 roots per workgroup)
   MZS_INST(3, 8, 21, 51, 4)    // three actions (Acrobot / MountainCar shapes)
   MZS_INST(4, 8, 21, 51, 3)    // four actions, small embedding: 12 roots per workgroup
   MZS_INST(2, 8, 21, 64, 3)    // CartPole up to 63 simulations (12 roots per workgroup)

@@ -354,7 +354,7 @@ static int ensure_step_state(mzs_handle* h) {
   {
     const size_t B = (size_t)c.batch, N = (size_t)c.num_simulations + 1;
     const char* walk = getenv("MZS_STEP_WALK");
-    if (c.policy == 0 && N <= (size_t)mz::kJumpMaxNodes && B * N * N * 4 <= ((size_t)1 << 30) && !(walk && walk[0] == '1')) {
+    if (N <= (size_t)mz::kJumpMaxNodes && B * N * N * 4 <= ((size_t)1 << 30) && !(walk && walk[0] == '1')) {
       const size_t words = 3 * B * N + B * N * N;
       if (hipMalloc(&h->jump_slab, words * 4) == hipSuccess) {
         int32_t* w = static_cast<int32_t*>(h->jump_slab);
@@ -396,7 +396,7 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
                      value, embedding, invalid_actions, dirichlet_noise, dirichlet_fraction, 0,
                      static_cast<const float*>(nullptr), 0u, 0u);
   if (h->use_jump)
-    hipLaunchKernelGGL(mz::jump_root_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, h->jump);
+    hipLaunchKernelGGL(mz::jump_root_kernel<false>, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, h->jump);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   h->step.rooted = true;
@@ -420,6 +420,8 @@ int mzs_root_gumbel(mzs_handle* h, const float* prior_logits, const float* value
   hipLaunchKernelGGL(mz::step_root_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, prior_logits,
                      value, embedding, invalid_actions, static_cast<const float*>(nullptr), 0.0f, 1, gumbel, gk[0],
                      gk[1]);
+  if (h->use_jump)
+    hipLaunchKernelGGL(mz::jump_root_kernel<true>, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, h->jump);
   if (sa.wide) emb_xfer(sa, const_cast<float*>(embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   h->step.rooted = true;
@@ -463,9 +465,16 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
   mz::StepArgs sa = h->step.args(c);
   if (h->use_jump)
     // small batches: 16 levels in flight per root; large ones: one wavefront per root keeps the launch small
-    hipLaunchKernelGGL(mz::jump_expand_backup_kernel, dim3(c.batch), dim3(c.batch <= 1024 ? 256 : 64),
-                       sizeof(int32_t) * 15 * ((size_t)c.num_simulations + 2),
-                       stream, sa, h->jump, sim, reward, discount, prior_logits, value, next_embedding);
+  {
+    const dim3 blk(c.batch <= 1024 ? 256 : 64);
+    const size_t lds = sizeof(int32_t) * 15 * ((size_t)c.num_simulations + 2);
+    if (c.policy == 1)
+      hipLaunchKernelGGL(mz::jump_expand_backup_kernel<true>, dim3(c.batch), blk, lds, stream, sa, h->jump, sim, reward,
+                         discount, prior_logits, value, next_embedding);
+    else
+      hipLaunchKernelGGL(mz::jump_expand_backup_kernel<false>, dim3(c.batch), blk, lds, stream, sa, h->jump, sim, reward,
+                         discount, prior_logits, value, next_embedding);
+  }
   else
     hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        reward, discount, prior_logits, value, next_embedding);

@@ -14,8 +14,8 @@
 //     part and runs over LDS.
 //
 // Every node stores its own root path (written once at expansion: parent's path + one entry), so the
-// backup finds its levels without a pointer chase.  Used for the MuZero policy when N <= kJumpMaxNodes
-// and B N^2 words fit the budget; otherwise mz_step.cuh's walking kernels run.
+// backup finds its levels without a pointer chase.  Used (both policies) when N <= kJumpMaxNodes and B N^2
+// words fit the budget; otherwise mz_step.cuh's walking kernels run.
 #pragma once
 #include "mz_step.cuh"
 
@@ -102,13 +102,64 @@ MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, f
   near = ((__builtin_amdgcn_ballot_w64(unsafe) >> (threadIdx.x & 48)) & 0xffffull) != 0;  // any lane of the row
 }
 
+// mctx gumbel_muzero_{root,interior}_action_selection at `node` (the root is only ever selected at level 0):
+// deterministic in the node's statistics -- the root's sequential-halving table entry is indexed by its
+// own visit sum, i.e. by the number of the NEXT simulation once the backup has run.
+MZ_DEV void gumbel_decide(const StepArgs& s, size_t rb, int r, int node, int j, int& best, int& child) {
+  const int A = s.A;
+  const size_t nb = (rb + node) * A;
+  float qv[kMaxAS], logits[kMaxAS];
+  int vc[kMaxAS], cidx[kMaxAS], sum_visits;
+  row_qtransform(s, rb, node, A, j, qv, vc, logits, sum_visits);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) cidx[t] = s.children_index[nb + (j + 16 * t < A ? j + 16 * t : 0)];
+  if (node == 0) {
+    int ninv = 0;
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) ninv += (j + 16 * t < A && s.root_invalid[(size_t)r * A + j + 16 * t]) ? 1 : 0;
+    const int num_valid = A - row_sum_i(ninv);
+    const int num_considered = min(s.max_considered, num_valid);
+    const int si = min(sum_visits, s.S - 1);
+    const int considered_visit = s.visit_table[(size_t)num_considered * s.S + si];
+    best = row_gumbel_argmax(s, r, A, j, considered_visit, logits, qv, vc, cidx, child);
+  } else {
+    float x[kMaxAS], p[kMaxAS];
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) x[t] = logits[t] + qv[t];
+    row_softmax_rt(x, A, j, p);
+    float bscore = -INFINITY;
+    best = 1 << 20;
+    child = -1;
+#pragma unroll
+    for (int t = 0; t < kMaxAS; ++t) {
+      const int a = j + 16 * t;
+      const bool ok = a < A;
+      const float sc = ok ? p[t] - (float)vc[t] / (float)(1 + sum_visits) : -INFINITY;
+      const bool take = (t == 0) || (sc > bscore);
+      if (take) { bscore = sc; best = ok ? a : (1 << 20); child = cidx[t]; }
+    }
+    row_argmax<4>(bscore, best, child);
+  }
+}
+template <bool GUMBEL>
+MZ_DEV void decide_any(const StepArgs& s, size_t rb, int r, int node, int j, int& best, int& child, bool& near) {
+  if constexpr (GUMBEL) {
+    gumbel_decide(s, rb, r, node, j, best, child);
+    near = false;
+  } else {
+    float sc[kMaxAS];
+    int cidx[kMaxAS];
+    level_decide(s, rb, r, node, j, sc, cidx, best, child, near);
+  }
+}
+
 // root decision (after step_root_kernel): one row per root
+template <bool GUMBEL>
 __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) {
   MZ_JROW_SETUP
-  float sc[kMaxAS];
-  int cidx[kMaxAS], best, child;
+  int best, child;
   bool near;
-  level_decide(s, rb, r, 0, j, sc, cidx, best, child, near);
+  decide_any<GUMBEL>(s, rb, r, 0, j, best, child, near);
   if (j == 0) {
     g.jump_pa[rb] = best << 16 | (near ? (int)0x80000000 : 0);
     g.jump_lv[rb] = 0;
@@ -202,6 +253,7 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
 }
 
 // mctx search.expand + search.backward + refresh of the decisions on the path: one workgroup per root
+template <bool GUMBEL>
 __global__ __launch_bounds__(256) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
                                                                   const float* discount, const float* prior_logits,
                                                                   const float* value, const float* next_embedding) {
@@ -313,10 +365,9 @@ __global__ __launch_bounds__(256) void jump_expand_backup_kernel(StepArgs s, Jum
   for (int base = 0; base <= depth; base += nrows) {
     const int e = base + row;
     if (e <= depth) {
-      float sc[kMaxAS];
-      int cidx[kMaxAS], best, child;
+      int best, child;
       bool near;
-      level_decide(s, rb, r, pn[e], j, sc, cidx, best, child, near);
+      decide_any<GUMBEL>(s, rb, r, pn[e], j, best, child, near);
       if (j == 0) {
         bst[e] = best;
         chd[e] = child;

@@ -388,9 +388,13 @@ def test_bad_arguments_raise_value_error():
 
 @pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
 @pytest.mark.parametrize("A,E,S,B,maxc", [(4, 8, 32, 70, 16), (18, 24, 40, 33, 5), (2, 8, 50, 48, 16), (4, 260, 10, 9, 4)])
-def test_gumbel_stepwise_matches_oracle(oracle, A, E, S, B, maxc, qt):
-    """mctx.gumbel_muzero_policy on the step-wise kernels: same torch net outputs fed to both sides, Gumbel
-    noise from the key; trees, chosen actions and the completed-Q policy target must agree exactly."""
+@pytest.mark.parametrize("walk", [False, True])
+def test_gumbel_stepwise_matches_oracle(oracle, A, E, S, B, maxc, qt, walk, monkeypatch):
+    """mctx.gumbel_muzero_policy on the step-wise kernels (both sets): same torch net outputs fed to both
+    sides, Gumbel noise from the key; trees, chosen actions and the completed-Q policy target must agree
+    exactly."""
+    if walk:
+        monkeypatch.setenv("MZS_STEP_WALK", "1")
     from muax_amd import MuZeroSearch, SearchConfig
     kind = 1 if qt.endswith("mix_value") else 0
     case = make_case(oracle, 60 + A, B, 6, E, A, S, invalid_frac=0.25 if A > 2 else 0.0)

@@ -617,7 +617,6 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 
   Nets<C> nets;
   nets.load(p, j);
-  int root_jw = 0;  // the root's JUMP word also lives in a register: one LDS hop less per simulation
 
   // ---- tree init (mctx instantiate_tree_from_root) ----
   // all-zero records written 16 bytes per lane, then children_index = -1 (same wave: LDS keeps the order)
@@ -757,7 +756,6 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       for (int a = 0; a < A; ++a) tree[C::SEL0 + 2 * a + 1] = sc[a];
       itree[C::JUMP] = jump_word(0, best, 0, !safe);
     }
-    root_jw = jump_word(0, best, 0, !safe);
   }
 
   int depth_total = 0;
@@ -782,8 +780,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     {
       uint32_t fk0 = 0, fk1 = 0, fs0 = 0, fs1 = 0;  // lazy key walk: rng_key / action_selection_key
       int fk_level = -1;                             // levels already split off (-1: not started)
-      int jw = root_jw;
+      int cur = 0;
       for (;;) {
+        const int jw = itree[__umul24((unsigned)cur, (unsigned)NS) + C::JUMP];
         parent = jw & 0xfff;
         action = (jw >> 12) & 0xf;
         dP = (jw >> 16) & 0xff;
@@ -833,8 +832,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
             }
             action = best;
             if (bn >= 0 && dP + 1 < max_depth) {
-              // the noisy choice is an expanded child within reach: keep descending from it
-              jw = itree[__umul24((unsigned)bn, (unsigned)NS) + C::JUMP];
+              cur = bn;  // the noisy choice is an expanded child within reach: keep descending from it
               continue;
             }
           }
@@ -852,9 +850,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       parent = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
       action = ent >> C::ENTRY_ACT_SHIFT;
     }
-    // a descent only ends at an already expanded child when max_depth cuts it short
-    int next = -1;
-    if (max_depth < S) next = itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
+    const int next = itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
     depth_total += depth;
     MZ_TICK(1);  // select
     const bool fresh = next < 0;
@@ -1089,7 +1085,6 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           ndi[C::ST0 + C::STW * pa + 2] = cin;
         }
       }
-      root_jw = carry_j;  // entry 0 of chunk 0 is the root
       if constexpr (!C::EMB_LDS) {
         pref_parent = carry_j & 0xfff;  // the root's refreshed JUMP word: where the next descent ends
 #pragma unroll

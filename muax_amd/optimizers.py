@@ -15,7 +15,15 @@ class Optimizer:
         self.opt = self.sched = None
 
     def init(self, params):
-        self.opt = self._factory(list(params))
+        params = list(params)
+        self.opt = self._factory(params)
+        if isinstance(self.opt, (torch.optim.Adam, torch.optim.AdamW)) and params and all(p.is_cuda for p in params):
+            try:  # one multi-tensor kernel for all 18 small arrays instead of a dozen launches
+                fused = type(self.opt)(params, fused=True, **{k: v for k, v in self.opt.defaults.items()
+                                                              if k in ("lr", "betas", "eps", "weight_decay", "amsgrad")})
+                self.opt = fused
+            except (RuntimeError, TypeError, ValueError):
+                pass
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, self._lr_lambda) if self._lr_lambda else None
         return self.opt.state_dict()
 

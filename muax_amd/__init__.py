@@ -5,7 +5,7 @@ mctx.muzero_policy loop as hand-written gfx950 HIP kernels behind a C-ABI
 (include/mzsearch.h), and the host-side mirror of the reference interface
 (MuZero.act, the repr_fn/pred_fn/dy_fn plugin surface, the policy adapters).
 """
-from . import episode_tracer, loss, nn, optimizers, prng, replay_buffer, utils  # noqa: F401
+from . import checkpoint, episode_tracer, loss, nn, optimizers, prng, replay_buffer, utils  # noqa: F401
 from .episode_tracer import NStep, PNStep  # noqa: F401
 from .replay_buffer import Trajectory, TrajectoryReplayBuffer  # noqa: F401
 from .loss import Transition, default_loss_fn  # noqa: F401

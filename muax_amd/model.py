@@ -12,6 +12,7 @@ the points where mctx calls root_fn / recurrent_fn.  There is no CPU search path
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -332,6 +333,10 @@ class MuZero:
         if save:
             torch.save({"params": {n: m.state_dict() for n, m in mods.items()}, "optimizer_state": self._opt_state},
                        file)
+        elif str(file).endswith(".npy") or (not os.path.exists(file) and os.path.exists(f"{file}.npy")):
+            # a checkpoint written by the reference (jnp.save of haiku params): best-effort reader, no jax needed
+            from .checkpoint import load_reference_params
+            load_reference_params(self, str(file))
         else:
             saved = torch.load(file, map_location=self.device)
             for n, m in mods.items():

@@ -162,3 +162,75 @@ def test_oracle_reproduces_golden_fixtures(oracle, name):
     assert good.any()
     assert np.array_equal(rn["tree"].children_index[good], g["tree_children_index"][good])
     assert np.array_equal(rn["tree"].children_visits[good], g["tree_children_visits"][good])
+
+
+def test_reference_checkpoint_reader_on_a_synthetic_file_of_the_believed_layout(tmp_path):
+    """muax_amd/checkpoint.py reads `jnp.save`d checkpoints without jax.  No real file exists here, so this
+    writes one of the layout the reader assumes -- jax Arrays reduced through jax._src.array._reconstruct_array,
+    muax.nn.MZNetworkParams, an optax-like state -- with stand-in modules, removes them, and reads it back."""
+    import sys
+    import types
+    from collections import namedtuple
+
+    import numpy as np
+
+    import muax_amd as mx
+    from muax_amd import checkpoint
+
+    fake = {n: types.ModuleType(n) for n in ("jax", "jax._src", "jax._src.array", "muax", "muax.nn", "optax", "optax._src",
+                                             "optax._src.transform")}
+
+    class Array:  # pickles like jax's ArrayImpl
+        def __init__(self, v):
+            self.v = np.asarray(v)
+
+        def __reduce__(self):
+            fun, args, state = self.v.__reduce__()
+            return fake["jax._src.array"]._reconstruct_array, (fun, args, state, {"weak_type": False})
+
+    def _reconstruct_array(fun, args, arr_state, aval_state):
+        raise AssertionError("the real reconstructor must not be needed")
+
+    _reconstruct_array.__module__ = "jax._src.array"
+    _reconstruct_array.__qualname__ = "_reconstruct_array"
+    fake["jax._src.array"]._reconstruct_array = _reconstruct_array
+    Params = namedtuple("MZNetworkParams", "representation prediction dynamic")
+    Params.__module__, Params.__qualname__ = "muax.nn", "MZNetworkParams"
+    fake["muax.nn"].MZNetworkParams = Params
+    State = namedtuple("ScaleByAdamState", "count mu nu")
+    State.__module__, State.__qualname__ = "optax._src.transform", "ScaleByAdamState"
+    fake["optax._src.transform"].ScaleByAdamState = State
+
+    rng = np.random.default_rng(0)
+    lin = lambda i, o: {"w": Array(rng.normal(size=(i, o)).astype(np.float32)), "b": Array(rng.normal(size=o).astype(np.float32))}  # noqa: E731
+    rep = {"representation/~/linear": lin(4, 8)}
+    pred = {"prediction/~/linear": lin(8, 16), "prediction/~/linear_1": lin(16, 21),
+            "prediction/~/linear_2": lin(8, 16), "prediction/~/linear_3": lin(16, 2)}
+    dyn = {"dynamic/~/linear": lin(10, 16), "dynamic/~/linear_1": lin(16, 8),
+           "dynamic/~/linear_2": lin(10, 16), "dynamic/~/linear_3": lin(16, 21)}
+    path = str(tmp_path / "model_params.npy")
+    sys.modules.update(fake)
+    try:
+        np.save(path, {"params": Params(rep, pred, dyn), "optimizer_state": (State(Array(3), rep, rep),)})
+    finally:
+        for n in fake:
+            sys.modules.pop(n, None)
+
+    saved = checkpoint.read_reference_checkpoint(path)
+    assert isinstance(saved["params"], mx.MZNetworkParams)
+    assert np.array_equal(saved["params"].prediction["prediction/~/linear_3"]["w"], pred["prediction/~/linear_3"]["w"].v)
+    g = torch.Generator().manual_seed(0)
+    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
+                          mx.nn.Dynamic(8, 2, 21, generator=g))
+    m = mx.MuZero(net, device="cpu")
+    m.init(0, np.zeros((1, 4)))
+    checkpoint.load_reference_params(m, path)
+    w = mx.nn.mlp_trio_weights(m.network)
+    for ours, theirs in (("repr_w", rep["representation/~/linear"]["w"]), ("pv_w2", pred["prediction/~/linear_1"]["w"]),
+                         ("pp_b2", pred["prediction/~/linear_3"]["b"]), ("dn_w1", dyn["dynamic/~/linear"]["w"]),
+                         ("dr_b2", dyn["dynamic/~/linear_3"]["b"])):
+        assert np.array_equal(w[ours].detach().numpy(), theirs.v), ours
+    bad = mx.MuZero(mx.nn.MZNetwork(mx.nn.Representation(16), mx.nn.Prediction(2, 21), mx.nn.Dynamic(16, 2, 21)), device="cpu")
+    bad.init(0, np.zeros((1, 4)))
+    with pytest.raises(ValueError):
+        checkpoint.load_reference_params(bad, path)

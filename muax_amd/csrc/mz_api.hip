@@ -478,7 +478,7 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
   else
     hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        reward, discount, prior_logits, value, next_embedding);
-  if (sa.wide) emb_xfer(sa, const_cast<float*>(next_embedding), 1, stream);
+  if (sa.wide && !h->use_jump) emb_xfer(sa, const_cast<float*>(next_embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;
 }

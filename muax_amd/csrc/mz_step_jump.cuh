@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256) void jump_expand_backup_kernel(StepArgs s, Jum
       s.xfer_node[r] = newn;
     }
   }
-  if (!s.wide)
-    for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
+  // (a whole workgroup per root: wide rows need no separate transfer kernel here)
+  for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
   __syncthreads();
   // -- per-level inputs of the backward pass --
   for (int e = tid; e < depth; e += nthr) {

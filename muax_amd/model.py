@@ -78,6 +78,7 @@ class MuZero:
         self._params = None
         self._opt_state = None
         self._fused_train = None
+        self._disc_const = None
         self._fused = {}
         self._weights_version = 0
 
@@ -148,7 +149,9 @@ class MuZero:
             out = self.dy_func.hip_recurrent(self.pred_func, embedding, action, self._support_size)
             if out is not None:  # ResNet nets: the whole recurrent_fn is one HIP launch (mz_conv.cuh)
                 r, v, logits, next_embedding = out
-                return (r, torch.full_like(r, self._discount), logits, v), next_embedding
+                if self._disc_const is None or self._disc_const.shape != r.shape or self._disc_const.device != r.device:
+                    self._disc_const = torch.full_like(r, self._discount)  # one constant tensor, not a fill per simulation
+                return (r, self._disc_const, logits, v), next_embedding
         with torch.no_grad():
             r, next_embedding = self.dy_func(embedding, action)
             v, logits = self.pred_func(embedding if self._recurrent_pred_on == "parent" else next_embedding)

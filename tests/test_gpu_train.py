@@ -107,3 +107,32 @@ def test_update_hip_and_torch_routes_take_the_same_step():
     with pytest.raises(ValueError):
         custom.update(b, backend="hip")
     assert np.isfinite(custom.update(b)["loss"]) and custom._fused_train is None
+
+
+def test_c_abi_rejects_bad_training_and_tower_arguments():
+    """Error behaviour of the next-tier entry points: negative status + message, mapped to ValueError."""
+    import ctypes as C
+
+    from muax_amd import _lib
+    L = _lib.load()
+    w = _lib.MzsMlpWeights()
+    a = _lib.MzsTrainArgs()
+    assert L.mzs_mlp_loss_grad(C.byref(w), C.byref(a), None) == _lib.MZS_E_INVALID  # struct_size not set
+    w.struct_size, a.struct_size = C.sizeof(w), C.sizeof(a)
+    with pytest.raises(ValueError, match="null weight pointer"):
+        _lib.check(L.mzs_mlp_loss_grad(C.byref(w), C.byref(a), None))
+    m = _model(2, 8, 4, seed=1)
+    f = mx.loss.FusedLossGrad(m)
+    with pytest.raises(ValueError, match="features"):
+        f(_batch(4, 2, 2, 5, seed=0))  # obs width does not match the network
+    t = _lib.MzsTowerArgs()
+    assert L.mzs_resnet_tower(C.byref(t), None) == _lib.MZS_E_INVALID
+    t.struct_size, t.batch, t.blocks = C.sizeof(t), 2, 1
+    with pytest.raises(ValueError, match="null tensor pointer"):
+        _lib.check(L.mzs_resnet_tower(C.byref(t), None))
+    x = torch.zeros(2, 6, 6, 64, device="cuda")
+    t.x = t.y = t.conv_w = t.ln = x.data_ptr()
+    t.stem_w = x.data_ptr()
+    with pytest.raises(ValueError, match="stem needs actions"):
+        _lib.check(L.mzs_resnet_tower(C.byref(t), None))
+    assert L.mzs_mlp_num_params(4, 8, 2, 10) == 4 * 8 + 8 + 2 * (8 * 16 + 16) + 16 * 21 + 21 + 16 * 2 + 2 + 2 * (10 * 16 + 16) + 16 * 21 + 21 + 16 * 8 + 8

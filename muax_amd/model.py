@@ -267,9 +267,13 @@ class MuZero:
             pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak,
             max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale)
         if not obs_from_batch:
-            action = int(plan_output.action.item())
-            weights = plan_output.action_weights.cpu().numpy()
-            root_value = float(root_value.item())
+            # one device-to-host copy instead of three (each costs a synchronisation): action, weights, value
+            A = plan_output.action_weights.shape[1]
+            host = torch.cat([plan_output.action.to(torch.float32), plan_output.action_weights.reshape(-1),
+                              root_value.reshape(-1).to(torch.float32)]).cpu().numpy()
+            action = int(host[0])
+            weights = host[1:1 + A].reshape(1, A).copy()
+            root_value = float(host[1 + A])
         elif device_outputs:
             action, weights = plan_output.action, plan_output.action_weights
         else:

@@ -63,15 +63,21 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
-constexpr int kHeadWords = 4 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots + scratch of the heads
+constexpr int kHeadWords = 8 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots + scratch of the heads
 
-MZ_DEV float wg_sum(float v, float* red, int wave, int lane) {
+template <int NV>
+MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m);
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v[i] = v[i] + __shfl_xor(v[i], m);
   __syncthreads();  // previous use of red[] is over
-  if (lane == 0) red[wave] = v;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[NV * wave + i] = v[i];
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
 }
 
 // acc[mt] = conv3x3 of the haloed map `in`, this wave's 16 output channels.
@@ -83,35 +89,45 @@ MZ_DEV float wg_sum(float v, float* red, int wave, int lane) {
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 constexpr int kConvAhead = 6;
 struct ConvPrefetch {
-  f32x4u q[kConvAhead];  // weight quads of groups 0 .. kConvAhead-1 of the NEXT convolution
+  f32x4u q[2][kConvAhead];  // weight quads of groups 0 .. kConvAhead-1 of the NEXT call's stream(s)
 };
-MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, ConvPrefetch& pf) {
+MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, f32x4u (&q)[kConvAhead]) {
   const f32x4u* wq = reinterpret_cast<const f32x4u*>(Wp) + wlane;
 #pragma unroll
-  for (int q = 0; q < kConvAhead; ++q) pf.q[q] = wq[q * 256];
+  for (int i = 0; i < kConvAhead; ++i) q[i] = wq[i * 256];
 }
-// `pf` holds this convolution's first weight quads (fetched while the previous LayerNorm ran); on return
-// it holds those of `Wnext` (if any), so the L2 latency at the head of a convolution is never exposed.
-MZ_DEV void conv3x3_tile(const float* in, const float* __restrict__ Wp, const float* __restrict__ Wnext,
-                         const int (&abase)[3], int wlane, ConvPrefetch& pf, f32x4 (&acc)[3]) {
+// NW convolutions of the SAME input in one pass over K (the projection and conv_0 of a residual block share
+// their activation reads).  `pf` holds the first weight quads of this call's stream(s), fetched while the
+// previous LayerNorm ran; on return it holds those of the next call's (Wnext[0 .. nnext)), so the L2
+// latency at the head of a convolution is never exposed.
+template <int NW>
+MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const float* const (&Wnext)[2], int nnext,
+                          const int (&abase)[3], int wlane, ConvPrefetch& pf, f32x4 (&acc)[NW][3]) {
 #pragma unroll
-  for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) acc[s][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   constexpr int G = 36, AHEAD = kConvAhead;
-  const f32x4u* wq = reinterpret_cast<const f32x4u*>(Wp) + wlane;  // + group * 256
-  f32x4u wbuf[AHEAD + 1];
+  f32x4u wbuf[NW][AHEAD + 1];
   f32x4u abuf[2][3];
   auto a_off = [](int grp) { return (((grp >> 2) / 3) * kHalo + ((grp >> 2) % 3)) * kPixStride + 16 * (grp & 3); };
 #pragma unroll
-  for (int q = 0; q < AHEAD; ++q) wbuf[q] = pf.q[q];
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) wbuf[s][q] = pf.q[s][q];
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) abuf[0][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(0));
   StaticFor<0, G>::run([&](auto gc) {
     constexpr int grp = decltype(gc)::value;
     if constexpr (grp + AHEAD < G) {
-      wbuf[(grp + AHEAD) % (AHEAD + 1)] = wq[(grp + AHEAD) * 256];
+#pragma unroll
+      for (int s = 0; s < NW; ++s)
+        wbuf[s][(grp + AHEAD) % (AHEAD + 1)] = (reinterpret_cast<const f32x4u*>(Wp[s]) + wlane)[(grp + AHEAD) * 256];
     } else {
-      if (Wnext != nullptr)
-        pf.q[grp + AHEAD - G] = (reinterpret_cast<const f32x4u*>(Wnext) + wlane)[(grp + AHEAD - G) * 256];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (s < nnext)
+          pf.q[s][grp + AHEAD - G] = (reinterpret_cast<const f32x4u*>(Wnext[s]) + wlane)[(grp + AHEAD - G) * 256];
     }
     if constexpr (grp + 1 < G) {
 #pragma unroll
@@ -119,44 +135,58 @@ MZ_DEV void conv3x3_tile(const float* in, const float* __restrict__ Wp, const fl
         abuf[(grp + 1) & 1][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(grp + 1));
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here: the scheduler otherwise sinks them
-    const f32x4u w = wbuf[grp % (AHEAD + 1)];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], w[i], acc[mt], 0, 0, 0);
+      for (int s = 0; s < NW; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+          acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], wbuf[s][grp % (AHEAD + 1)][i],
+                                                            acc[s][mt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   });
 }
 
 // hk.LayerNorm(axis=(-3,-2,-1)) over the root's 36 x 64 map, scale / offset per channel; optional relu
-MZ_DEV void layer_norm_tile(f32x4 (&acc)[3], const float* __restrict__ so, int ch, int lane, int wave,
-                            float* red, bool relu) {
+template <int NW>
+MZ_DEV void layer_norm_tiles(f32x4 (&acc)[NW][3], const float* const (&so)[NW], const bool (&relu)[NW], int ch, int lane,
+                             int wave, float* red) {
   const int g = lane >> 4;
-  float s = 0.0f;
+  float mean[NW], var[NW];
 #pragma unroll
-  for (int mt = 0; mt < 3; ++mt)
+  for (int s = 0; s < NW; ++s) {
+    mean[s] = 0.0f;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) s = s + ((16 * mt + 4 * g + v < kTowerPix) ? acc[mt][v] : 0.0f);
-  const float mean = wg_sum(s, red, wave, lane) * (1.0f / (kTowerPix * kTowerC));
-  float q = 0.0f;
+    for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-  for (int mt = 0; mt < 3; ++mt)
+      for (int v = 0; v < 4; ++v) mean[s] = mean[s] + ((16 * mt + 4 * g + v < kTowerPix) ? acc[s][mt][v] : 0.0f);
+  }
+  wg_sum<NW>(mean, red, wave, lane);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float d = acc[mt][v] - mean;
-      q = q + ((16 * mt + 4 * g + v < kTowerPix) ? d * d : 0.0f);
-    }
-  const float var = wg_sum(q, red, wave, lane) * (1.0f / (kTowerPix * kTowerC));
-  const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
-  const float sc = so[ch], of = so[kTowerC + ch];
+  for (int s = 0; s < NW; ++s) {
+    mean[s] = mean[s] * (1.0f / (kTowerPix * kTowerC));
+    var[s] = 0.0f;
 #pragma unroll
-  for (int mt = 0; mt < 3; ++mt)
+    for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      float o = (acc[mt][v] - mean) * rstd * sc + of;
-      acc[mt][v] = relu ? fmaxf(o, 0.0f) : o;
-    }
+      for (int v = 0; v < 4; ++v) {
+        const float d = acc[s][mt][v] - mean[s];
+        var[s] = var[s] + ((16 * mt + 4 * g + v < kTowerPix) ? d * d : 0.0f);
+      }
+  }
+  wg_sum<NW>(var, red, wave, lane);
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    const float rstd = 1.0f / __builtin_sqrtf(var[s] * (1.0f / (kTowerPix * kTowerC)) + 1e-5f);
+    const float sc = so[s][ch], of = so[s][kTowerC + ch];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float o = (acc[s][mt][v] - mean[s]) * rstd * sc + of;
+        acc[s][mt][v] = relu[s] ? fmaxf(o, 0.0f) : o;
+      }
+  }
 }
 
 MZ_DEV void store_map(const f32x4 (&acc)[3], float* buf, int ch, int lane) {
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   float* bufA = lds;
   float* bufB = lds + kBufWords;
   float* red = lds + 2 * kBufWords;
-  float* hv = red + 4;            // [48][16] value head map (rows >= 36 stay zero)
+  float* hv = red + 8;            // [48][16] value head map (rows >= 36 stay zero)
   float* hv2 = hv + 768;          // [48][16]
   float* hp = hv2 + 768;          // [48][16] policy head map
   float* part = hp + 768;         // [256] partial sums of the flatten -> Linear layers
@@ -247,7 +277,7 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   }
   const int ch = 16 * wave + (lane & 15);            // this lane's output channel
   const int wcol = (lane >> 4) * kTowerC + ch;       // B operand: quad [g = lane >> 4][co = ch] of a packed group
-  f32x4 acc[3], sc[3];
+  f32x4 acc[3];
 
   const int g4 = lane >> 4, n16 = lane & 15;
   int rowc[3];  // centre-tap rows for 1x1 convolutions on a haloed map
@@ -328,24 +358,40 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   }
 
   ConvPrefetch pf;
-  if (p.blocks > 0) conv_prefetch(p.conv_w, wcol, pf);
+  constexpr size_t CW = 9 * kTowerC * kTowerC;
+  if (p.blocks > 0) {
+    conv_prefetch(p.conv_w, wcol, pf.q[0]);
+    conv_prefetch(p.conv_w + CW, wcol, pf.q[1]);
+  }
   for (int blk = 0; blk < p.blocks; ++blk) {
-    const float* W = p.conv_w + (size_t)blk * 3 * 9 * kTowerC * kTowerC;
+    const float* W = p.conv_w + (size_t)blk * 3 * CW;
     const float* LN = p.ln + (size_t)blk * 3 * 2 * kTowerC;
-    constexpr size_t CW = 9 * kTowerC * kTowerC;
-    const float* Wn = blk + 1 < p.blocks ? W + 3 * CW : nullptr;
-    conv3x3_tile(cur, W, W + CW, abase, wcol, pf, sc);
-    layer_norm_tile(sc, LN, ch, lane, wave, red, false);
-    conv3x3_tile(cur, W + CW, W + 2 * CW, abase, wcol, pf, acc);
-    layer_norm_tile(acc, LN + 2 * kTowerC, ch, lane, wave, red, true);
-    store_map(acc, oth, ch, lane);
+    const bool last = blk + 1 == p.blocks;
+    // projection and conv_0 read the same map: one pass over K, one pair of LayerNorm reductions
+    f32x4 pr[2][3];
+    {
+      const float* const w2[2] = {W, W + CW};
+      const float* const nx[2] = {W + 2 * CW, nullptr};
+      conv3x3_tiles<2>(cur, w2, nx, 1, abase, wcol, pf, pr);
+      const float* const so[2] = {LN, LN + 2 * kTowerC};
+      const bool rl[2] = {false, true};
+      layer_norm_tiles<2>(pr, so, rl, ch, lane, wave, red);
+    }
+    store_map(pr[1], oth, ch, lane);
     __syncthreads();
-    conv3x3_tile(oth, W + 2 * CW, Wn, abase, wcol, pf, acc);
-    layer_norm_tile(acc, LN + 4 * kTowerC, ch, lane, wave, red, false);
+    f32x4 out[1][3];
+    {
+      const float* const w1[1] = {W + 2 * CW};
+      const float* const nx[2] = {W + 3 * CW, W + 4 * CW};
+      conv3x3_tiles<1>(oth, w1, nx, last ? 0 : 2, abase, wcol, pf, out);
+      const float* const so[1] = {LN + 4 * kTowerC};
+      const bool rl[1] = {false};
+      layer_norm_tiles<1>(out, so, rl, ch, lane, wave, red);
+    }
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(sc[mt][v] + acc[mt][v], 0.0f);
+      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(pr[0][mt][v] + out[0][mt][v], 0.0f);
     store_map(acc, cur, ch, lane);  // every wave is past its reads of `cur` (the LayerNorm barriers)
     __syncthreads();
   }

@@ -620,6 +620,12 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
   p.inv_num_actions = a->stem_w ? 1.0f / (float)a->num_actions : 0.0f;
   p.B = a->batch; p.blocks = a->blocks; p.normalize = a->normalize;
   const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords);
+  static bool tower_attr = false;
+  if (!tower_attr) {
+    MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    tower_attr = true;
+  }
   hipLaunchKernelGGL(mz::mz_resnet_tower_kernel, dim3(a->batch), dim3(256), lds, static_cast<hipStream_t>(stream_), p);
   MZS_HIP(nullptr, hipGetLastError());
   return MZS_OK;

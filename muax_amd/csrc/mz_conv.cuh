@@ -63,7 +63,7 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
-constexpr int kHeadWords = 8 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots + scratch of the heads
+constexpr int kHeadWords = 8 + 3 * 768 + 2 * 256 + 64 + 64 + 2 * 4 * 4 * 64;  // ... + remainder-row partial sums  // reduction slots + scratch of the heads
 
 template <int NV>
 MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
@@ -100,23 +100,40 @@ MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, f32x4u (&q)[k
 // their activation reads).  `pf` holds the first weight quads of this call's stream(s), fetched while the
 // previous LayerNorm ran; on return it holds those of the next call's (Wnext[0 .. nnext)), so the L2
 // latency at the head of a convolution is never exposed.
+// Rows 0..31 of the 36-pixel map are two 16x16x4 tiles per wave (its 16 output channels).  The last four
+// rows would waste 3/4 of a third tile, so they run on v_mfma_f32_4x4x1_16b_f32 instead: its 16 blocks are
+// the 16 groups of four output channels (lane = channel), its four rows the four pixels, k = 1 per
+// instruction -- and the four waves SPLIT K: wave w takes the channels 16 c + 4 w + {0..3} of every group, the
+// same packed weight quads [grp][g = w][co = lane], 144 quarter-cost MFMAs per wave.  The partial sums meet
+// in LDS (`part`, NW x 4 waves x 64 lanes x 4 rows) and land in acc[.][2] of the lanes that own those pixels.
 template <int NW>
 MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const float* const (&Wnext)[2], int nnext,
-                          const int (&abase)[3], int wlane, ConvPrefetch& pf, f32x4 (&acc)[NW][3]) {
+                          const int (&abase)[3], int wlane, int lane, int wave, float* part, ConvPrefetch& pf,
+                          f32x4 (&acc)[NW][3]) {
 #pragma unroll
   for (int s = 0; s < NW; ++s)
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) acc[s][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 rem[NW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s) rem[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   constexpr int G = 36, AHEAD = kConvAhead;
   f32x4u wbuf[NW][AHEAD + 1];
-  f32x4u abuf[2][3];
+  f32x4u abuf[2][2];
   auto a_off = [](int grp) { return (((grp >> 2) / 3) * kHalo + ((grp >> 2) % 3)) * kPixStride + 16 * (grp & 3); };
+  // remainder rows: pixel 32 + (lane & 3), input channels 16 c + 4 wave + {0..3}; weights [grp][g = wave][co = lane]
+  const int rbase = ((32 + (lane & 3)) / kTowerHW * kHalo + (32 + (lane & 3)) % kTowerHW) * kPixStride + 4 * wave;
+  const int rlane = wave * kTowerC + lane;
+  f32x4u rw[NW][2], ra[2];
 #pragma unroll
-  for (int s = 0; s < NW; ++s)
+  for (int s = 0; s < NW; ++s) {
 #pragma unroll
     for (int q = 0; q < AHEAD; ++q) wbuf[s][q] = pf.q[s][q];
+    rw[s][0] = (reinterpret_cast<const f32x4u*>(Wp[s]) + rlane)[0];
+  }
 #pragma unroll
-  for (int mt = 0; mt < 3; ++mt) abuf[0][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(0));
+  for (int mt = 0; mt < 2; ++mt) abuf[0][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(0));
+  ra[0] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(0));
   StaticFor<0, G>::run([&](auto gc) {
     constexpr int grp = decltype(gc)::value;
     if constexpr (grp + AHEAD < G) {
@@ -131,23 +148,41 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
     }
     if constexpr (grp + 1 < G) {
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
         abuf[(grp + 1) & 1][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(grp + 1));
+      ra[(grp + 1) & 1] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(grp + 1));
+#pragma unroll
+      for (int s = 0; s < NW; ++s) rw[s][(grp + 1) & 1] = (reinterpret_cast<const f32x4u*>(Wp[s]) + rlane)[(grp + 1) * 256];
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here: the scheduler otherwise sinks them
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int s = 0; s < NW; ++s)
+      for (int s = 0; s < NW; ++s) {
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
           acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], wbuf[s][grp % (AHEAD + 1)][i],
                                                             acc[s][mt], 0, 0, 0);
+        rem[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], rw[s][grp & 1][i], rem[s], 0, 0, 0);
+      }
     __builtin_amdgcn_sched_barrier(0);
   });
+  // partial sums of the remainder rows: [s][wave][row v][channel = lane]
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[((s * 4 + wave) * 4 + v) * 64 + lane] = rem[s][v];
+  __syncthreads();
+  if (lane < 16) {
+    const int ch = 16 * wave + lane;
+#pragma unroll
+    for (int s = 0; s < NW; ++s)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        acc[s][2][v] = (part[((s * 4 + 0) * 4 + v) * 64 + ch] + part[((s * 4 + 1) * 4 + v) * 64 + ch]) +
+                       (part[((s * 4 + 2) * 4 + v) * 64 + ch] + part[((s * 4 + 3) * 4 + v) * 64 + ch]);
+  }
 }
-
-// hk.LayerNorm(axis=(-3,-2,-1)) over the root's 36 x 64 map, scale / offset per channel; optional relu
 template <int NW>
 MZ_DEV void layer_norm_tiles(f32x4 (&acc)[NW][3], const float* const (&so)[NW], const bool (&relu)[NW], int ch, int lane,
                              int wave, float* red) {
@@ -256,6 +291,7 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   float* part2 = part + 256;      // [256]
   float* vec = part2 + 256;       // [64] hidden vectors
   float* lgt = vec + 64;          // [64] logits
+  float* part3 = lgt + 64;        // [2][4 waves][4 rows][64] partial sums of the 4x4x1 remainder tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = blockIdx.x;
   for (int i = tid; i < 2 * kBufWords + kHeadWords; i += 256) lds[i] = 0.0f;
@@ -372,7 +408,7 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
     {
       const float* const w2[2] = {W, W + CW};
       const float* const nx[2] = {W + 2 * CW, nullptr};
-      conv3x3_tiles<2>(cur, w2, nx, 1, abase, wcol, pf, pr);
+      conv3x3_tiles<2>(cur, w2, nx, 1, abase, wcol, lane, wave, part3, pf, pr);
       const float* const so[2] = {LN, LN + 2 * kTowerC};
       const bool rl[2] = {false, true};
       layer_norm_tiles<2>(pr, so, rl, ch, lane, wave, red);
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
     {
       const float* const w1[1] = {W + 2 * CW};
       const float* const nx[2] = {W + 3 * CW, W + 4 * CW};
-      conv3x3_tiles<1>(oth, w1, nx, last ? 0 : 2, abase, wcol, pf, out);
+      conv3x3_tiles<1>(oth, w1, nx, last ? 0 : 2, abase, wcol, lane, wave, part3, pf, out);
       const float* const so[1] = {LN + 4 * kTowerC};
       const bool rl[1] = {false};
       layer_norm_tiles<1>(out, so, rl, ch, lane, wave, red);

@@ -7,10 +7,11 @@
 // One workgroup owns one root's 6x6x64 map, which never leaves the CU: two zero-haloed 8x8-pixel buffers in
 // LDS (pixel stride 68 words: 16-byte aligned rows that still spread over the banks).  A 3x3 convolution is
 // an implicit GEMM  out[36 px (padded to 48)][64 co] = sum_{tap, ci} in[px + tap][ci] W[tap][ci][co]  on
-// v_mfma_f32_16x16x4_f32: wave w owns output channels 16 w .. 16 w + 15 for all three pixel tiles (12
-// accumulator registers).  K is walked in 36 groups of 16 input channels; per group a lane issues ONE
-// ds_read_b128 of activations per tile and ONE global_load_dwordx4 of weights (host-packed so that the four
-// k-steps of a lane are contiguous), six groups ahead and across convolution boundaries.  LayerNorm over the
+// v_mfma_f32_16x16x4_f32: wave w owns output channels 16 w .. 16 w + 15 for the two full pixel tiles; the
+// last four pixels run on v_mfma_f32_4x4x1 with K split across the waves (see conv3x3_tiles).  K is walked
+// in 36 groups of 16 input channels; per group a lane issues ONE ds_read_b128 of activations per tile and
+// ONE global_load_dwordx4 of weights (host-packed so that the four k-steps of a lane are contiguous), six
+// groups ahead and across convolution boundaries; the projection and conv_0 of a block share one pass.  LayerNorm over the
 // whole map (two-pass mean / variance, as jnp.var) is two workgroup reductions per convolution; the
 // projection shortcut stays in registers until the block's final add.  The heads are small: 1x1 convolutions
 // on the same MFMA tiles, flatten -> Linear layers as VALU dot products with the weights streamed from L2.

@@ -24,8 +24,8 @@ for db in sorted(glob.glob(os.path.join(out, "*", "*_results.db"))):
         lines.append(f"== {name} (rocprofv3 --pmc), per-dispatch averages ==")
         for k, c, v, n in cur.execute(
                 "select kernel_name, counter_name, avg(value), count(*) from counters_collection "
-                "where kernel_name like 'void mz::%' group by kernel_name, counter_name"):
-            lines.append(f"   {k[9:60]:52s} {c:24s} {v:16.1f}  (n={n})")
+                "where kernel_name like '%mz::%' group by kernel_name, counter_name"):
+            lines.append(f"   {k[k.index('mz::') + 4:][:51]:52s} {c:28s} {v:16.1f}  (n={n})")
 text = "\n".join(lines)
 print(text)
 with open(os.path.join(out, "summary.txt"), "w") as f:

@@ -135,10 +135,12 @@ def test_fused_small_batch_and_plumbing_config(oracle):
     _compare(_oracle(oracle, case, True, [0, 42]), s, out)
 
 
-def test_fused_full_size_properties(oracle):
-    """BASELINE config 2 at full size (4096 roots, S=50): structural invariants that do not need the
-    oracle, plus exact agreement with the oracle on a 256-root sample of the same batch."""
-    case = make_case(oracle, 0, 4096, 4, 8, 2, 50, bias_scale=0.0)
+@pytest.mark.parametrize("B,obs_dim,E,A", [(4096, 4, 8, 2), (8192, 8, 32, 4)])
+def test_fused_full_size_properties(oracle, B, obs_dim, E, A):
+    """BASELINE configs 2 and 3 at full size (4096 CartPole-shaped / 8192 LunarLander-shaped roots, S=50):
+    structural invariants that do not need the oracle, plus exact agreement with the oracle on a 256-root
+    sample of the same batch."""
+    case = make_case(oracle, 0, B, obs_dim, E, A, 50, bias_scale=0.0)
     s, out = _fused(case, True, [0, 0], use_gumbel=False)
     t = out.search_tree
     nv, cv, ci, par, afp = (x.cpu().numpy() for x in
@@ -150,19 +152,19 @@ def test_fused_full_size_properties(oracle):
     b, n, a = np.nonzero(ci >= 0)
     c = ci[b, n, a]
     assert (par[b, c] == n).all() and (afp[b, c] == a).all() and (cv[b, n, a] == nv[b, c]).all()
-    assert (np.sort(c.reshape(4096, S), axis=1) == np.arange(1, S + 1)).all()  # every node expanded exactly once
+    assert (np.sort(c.reshape(B, S), axis=1) == np.arange(1, S + 1)).all()  # every node expanded exactly once
     w = out.action_weights.cpu().numpy()
     assert np.allclose(w.sum(1), 1, atol=1e-6) and np.array_equal(w, (cv[:, 0] / F32(S)).astype(F32))
     # depth_sum equals the sum of node depths recomputed from the parents array
     depth = np.zeros_like(par)
     for k in range(1, S + 1):
-        depth[:, k] = depth[np.arange(4096), par[:, k]] + 1
+        depth[:, k] = depth[np.arange(B), par[:, k]] + 1
     assert np.array_equal(depth.sum(1), s.depth_sum.cpu().numpy())
     sub = dict(case)
     for k in ("obs", "noise", "gumbel"):
         sub[k] = case[k][:256]
-    mlp = oracle.Mlp(case["w"], 4, 8, 2, 21)
-    ref = oracle.act_mlp(mlp, oracle.SearchCfg(S, tiebreak=1, global_batch=4096), sub["obs"], [0, 0], sub["noise"],
+    mlp = oracle.Mlp(case["w"], obs_dim, E, A, 21)
+    ref = oracle.act_mlp(mlp, oracle.SearchCfg(S, tiebreak=1, global_batch=B), sub["obs"], [0, 0], sub["noise"],
                          0.25, None, 1.0, None)
     assert np.array_equal(ref["action"], out.action.cpu().numpy()[:256])
     assert np.array_equal(ref["tree"].children_index, ci[:256])

@@ -471,7 +471,8 @@ def _gumbel_oracle_act(oracle, case, key, kind, maxc, gumbel=None, max_depth=0):
 
 
 @pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
-@pytest.mark.parametrize("A,E,S,B,maxc", [(2, 8, 50, 200, 16), (4, 8, 50, 90, 3), (4, 32, 40, 50, 16), (3, 8, 30, 40, 2)])
+@pytest.mark.parametrize("A,E,S,B,maxc", [(2, 8, 50, 200, 16), (4, 8, 50, 90, 3), (4, 32, 40, 50, 16), (3, 8, 30, 40, 2),
+                                          (2, 8, 50, 4096, 16)])  # the last: BASELINE config 5's acting half at full size
 def test_gumbel_fused_matches_oracle(oracle, A, E, S, B, maxc, qt):
     """The whole Gumbel MuZero act() in the fused kernel (sequential halving at the root, cached
     deterministic interior decisions through the JUMP words) against the oracle: bit-exact."""

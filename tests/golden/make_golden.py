@@ -41,7 +41,41 @@ def make(name):
     np.savez_compressed(os.path.join(HERE, f"act_mlp_{name}.npz"), **data)
 
 
+def gumbel_act(w, obs_dim, E, A, S, obs, key, kind, maxc):
+    """mctx.gumbel_muzero_policy composed from the oracle's pieces (root Gumbel noise from split(key)[1])."""
+    B = obs.shape[0]
+    mlp = po.Mlp(w, obs_dim, E, A, 21)
+    pl, v, emb = po.root_inference(mlp, obs)
+    g = po.gumbel(po.split(list(key), 2)[1], B * A).reshape(B, A)
+    tree = po.Tree(B, S + 1, A, E)
+    cfg = po.SearchCfg(S)
+    po.tree_init(tree, po.mask_root_logits(pl, None), v, emb, None)
+    dsum = np.zeros(B, np.int64)
+    for sim in range(S):
+        p_, a_, d_ = po.gumbel_step_select(tree, cfg, g, kind, maxc)
+        dsum += d_
+        po.step_expand_backup(tree, sim, p_, a_, *po.recurrent_inference(mlp, a_, tree.embeddings[np.arange(B), p_]))
+    action, weights = po.gumbel_finish(tree, g, kind)
+    return {"action": action, "action_weights": weights, "root_value": v, "depth_sum": dsum, "tree": tree}
+
+
+def make_gumbel():
+    """Gumbel MuZero (config 5's policy), CartPole shapes, 8 roots, S=32, mix-value qtransform, 16 considered."""
+    seed, B, obs_dim, E, A, S, key = 5, 8, 4, 8, 2, 32, (11, 13)
+    w = po.random_mlp_weights(seed, obs_dim, E, A, 21, bias_scale=0.1)
+    obs = np.random.default_rng(seed + 100).uniform(-1, 1, (B, obs_dim)).astype(np.float32)
+    out = gumbel_act(w, obs_dim, E, A, S, obs, key, 1, 16)
+    data = {"obs": obs, "key": np.array(key, np.uint32), "meta": np.array([B, obs_dim, E, A, S, 16], np.int64),
+            "action": out["action"], "action_weights": out["action_weights"], "root_value": out["root_value"],
+            "depth_sum": out["depth_sum"]}
+    data.update({"w_" + k: v for k, v in w.items()})
+    data.update({"tree_" + k: v for k, v in out["tree"].arrays().items()})
+    np.savez_compressed(os.path.join(HERE, "act_gumbel_cartpole_s32.npz"), **data)
+
+
 if __name__ == "__main__":
     for n in CASES:
         make(n)
         print("wrote", n)
+    make_gumbel()
+    print("wrote gumbel_cartpole_s32")

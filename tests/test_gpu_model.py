@@ -40,6 +40,22 @@ def test_fused_path_reproduces_golden_fixtures(name):
         assert np.array_equal(getattr(out.search_tree, f).cpu().numpy(), g["tree_" + f]), f
 
 
+def test_fused_gumbel_reproduces_its_golden_fixture():
+    """Frozen oracle vectors of the Gumbel MuZero act through the C-ABI (fused MODE 3 kernel): bit-exact."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "act_gumbel_cartpole_s32.npz"))
+    B, obs_dim, E, A, S, maxc = (int(x) for x in g["meta"])
+    s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, E, policy="gumbel", qtransform="qtransform_completed_by_mix_value",
+                                           max_num_considered_actions=maxc, tiebreak=False))
+    s.set_mlp_weights({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")}, obs_dim)
+    out = s.act_mlp(torch.from_numpy(g["obs"]), g["key"], with_tree=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.action.cpu().numpy(), g["action"])
+    assert np.array_equal(out.action_weights.cpu().numpy(), g["action_weights"])
+    assert np.array_equal(s.depth_sum.cpu().numpy(), g["depth_sum"])
+    for f in out.search_tree._fields:
+        assert np.array_equal(getattr(out.search_tree, f).cpu().numpy(), g["tree_" + f]), f
+
+
 def test_act_return_conventions():
     """muax/model.py:173-179: unbatched -> (int, [1,A] weights, float); batched -> arrays; flag order."""
     m = _model()

@@ -234,3 +234,19 @@ def test_reference_checkpoint_reader_on_a_synthetic_file_of_the_believed_layout(
     bad.init(0, np.zeros((1, 4)))
     with pytest.raises(ValueError):
         checkpoint.load_reference_params(bad, path)
+
+
+def test_oracle_reproduces_the_gumbel_golden_fixture(oracle):
+    """tests/golden/act_gumbel_cartpole_s32.npz freezes the oracle's Gumbel MuZero act (generator beside it)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "act_gumbel_cartpole_s32.npz"))
+    B, obs_dim, E, A, S, maxc = (int(x) for x in g["meta"])
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w_")}
+    out = mg.gumbel_act(w, obs_dim, E, A, S, g["obs"], tuple(int(x) for x in g["key"]), 1, maxc)
+    assert np.array_equal(out["action"], g["action"]) and np.array_equal(out["action_weights"], g["action_weights"])
+    for k, a in out["tree"].arrays().items():
+        assert np.array_equal(a, g["tree_" + k]), k
+    assert (g["tree_children_visits"][:, 0].sum(-1) == S).all()

@@ -22,6 +22,7 @@ from . import nn as mz_nn
 from . import prng
 from . import utils as mx_utils
 from .nn import MZNetwork, MZNetworkParams
+from .optimizers import optimizer  # noqa: F401  (the README's `muax.model.optimizer(...)`)
 from .policy import GumbelMuZeroPolicy, MuZeroPolicy, Policy
 from .search import MuZeroSearch, PolicyOutput, SearchConfig
 

@@ -14,7 +14,8 @@ from oracle import pyoracle as oracle  # noqa: E402
 import test_gpu_parity as tp  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(7)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+rng = np.random.default_rng(seed)
 bad = 0
 for c in range(n):
     A = int(rng.choice([1, 2, 3, 5, 8, 18, 33, 64]))
@@ -23,7 +24,7 @@ for c in range(n):
     B = int(rng.integers(1, 40))
     tiebreak = bool(rng.integers(2))
     max_depth = None if rng.random() < 0.5 else int(rng.integers(1, S + 1))
-    case = make_case(oracle, 5000 + c, B, 6, E, A, S, invalid_frac=0.3 if (A > 2 and rng.random() < 0.4) else 0.0)
+    case = make_case(oracle, 5000 + c + 100003 * abs(seed - 7), B, 6, E, A, S, invalid_frac=0.3 if (A > 2 and rng.random() < 0.4) else 0.0)
     scale = float(rng.choice([0.0, 0.3, 1.0, 4.0]))  # 0: every score ties exactly, the noise decides
     case["w"] = {k: (v * scale).astype(np.float32) for k, v in case["w"].items()}
     try:
@@ -31,4 +32,4 @@ for c in range(n):
     except AssertionError as e:
         bad += 1
         print(f"MISMATCH case {c}: A={A} E={E} S={S} B={B} tb={tiebreak} md={max_depth} scale={scale}: {str(e)[:160]}")
-print(f"{n} step-wise cases, {bad} mismatches")
+print(f"seed {seed}: {n} step-wise cases, {bad} mismatches")

@@ -62,3 +62,41 @@ class CartPole:
         terminated = bool(abs(x) > self.X_LIMIT or abs(th) > self.THETA_LIMIT)
         truncated = bool(self._t >= self.spec.max_episode_steps)
         return self._state.astype(np.float32), 1.0, terminated, truncated, {}
+
+
+class VectorCartPole:
+    """N cart-poles stepped as arrays, with auto-reset: `step` returns (obs, reward, done) where `done`
+    marks the last step of an episode and the observation of a finished cart-pole is already the first one
+    of its next episode (the protocol of muax_amd.rollout_batched / VectorCollector)."""
+
+    def __init__(self, n, max_episode_steps=500, seed=None):
+        self.n = int(n)
+        self.spec = SimpleNamespace(id="CartPole-v1", max_episode_steps=max_episode_steps)
+        self._rng = np.random.default_rng(seed)
+        self._state = np.zeros((self.n, 4))
+        self._t = np.zeros(self.n, np.int64)
+
+    def reset(self):
+        self._state = self._rng.uniform(-0.05, 0.05, (self.n, 4))
+        self._t[:] = 0
+        return self._state.astype(np.float32)
+
+    def step(self, actions):
+        c = CartPole
+        x, x_dot, th, th_dot = self._state.T
+        f = np.where(np.asarray(actions).reshape(-1) == 1, c.FORCE, -c.FORCE)
+        m_total, pm_l = c.M_CART + c.M_POLE, c.M_POLE * c.HALF_LEN
+        cos, sin = np.cos(th), np.sin(th)
+        tmp = (f + pm_l * th_dot * th_dot * sin) / m_total
+        th_acc = (c.GRAVITY * sin - cos * tmp) / (c.HALF_LEN * (4.0 / 3.0 - c.M_POLE * cos * cos / m_total))
+        x_acc = tmp - pm_l * th_acc * cos / m_total
+        x, x_dot = x + c.DT * x_dot, x_dot + c.DT * x_acc
+        th, th_dot = th + c.DT * th_dot, th_dot + c.DT * th_acc
+        self._state = np.stack([x, x_dot, th, th_dot], 1)
+        self._t += 1
+        done = (np.abs(x) > c.X_LIMIT) | (np.abs(th) > c.THETA_LIMIT) | (self._t >= self.spec.max_episode_steps)
+        k = int(done.sum())
+        if k:
+            self._state[done] = self._rng.uniform(-0.05, 0.05, (k, 4))
+            self._t[done] = 0
+        return self._state.astype(np.float32), np.ones(self.n), done

@@ -24,23 +24,62 @@ class Trajectory:
         self.trajectory, self._transition_weight = [], []
         self.transition_class = transition_class
         self._batched_transitions = None
+        self._rows, self._length = None, 0
+
+    @classmethod
+    def from_arrays(cls, obs, a, r, done, Rn, v, pi, w, transition_class=Transition, _checked=False):
+        """A whole episode handed over as arrays [T, ...] (the vectorised tracer of muax_amd/vector.py):
+        same sampling behaviour as a trajectory filled by `add`, without T Python objects."""
+        self = cls(transition_class)
+        cols = (obs, a, r, done, Rn, v, pi, w) if _checked else [np.asarray(x) for x in (obs, a, r, done, Rn, v, pi, w)]
+        if not _checked and len({len(c) for c in cols}) != 1:
+            raise ValueError("Trajectory.from_arrays: all fields need the same leading length")
+        self._rows = cols  # the Transition views are built on first use: most episodes of a big collection
+        self._length = len(cols[0])  # are dropped by the buffer before anything samples them
+        self._transition_weight = None
+        return self
 
     def add(self, transition):
+        if self._rows is not None:
+            raise ValueError("an array-backed trajectory is complete: it cannot be extended")
         self.trajectory.append(transition)
         self._transition_weight.append(transition.w)
 
+    def _materialise(self):
+        if self._batched_transitions is None:
+            self._transition_weight = self._rows[7].reshape(self._length, -1)[:, 0].tolist()
+            self._batched_transitions = self.transition_class(*(c[None] for c in self._rows))
+
+    @property
+    def weights(self):
+        """Priority weights of the transitions, [T]."""
+        if self._rows is not None:
+            return self._rows[7].reshape(self._length, -1)[:, 0]
+        return np.asarray(self._transition_weight, dtype=np.float64).reshape(len(self), -1)[:, 0]
+
+    @property
+    def rewards(self):
+        return self._rows[2] if self._rows is not None else np.asarray([t.r for t in self.trajectory])
+
     def finalize(self):
         """Every field becomes one array [1, T, ...]."""
+        if self._rows is not None:
+            self._materialise()
+            return
         b = _stack(self.trajectory, self.transition_class)
         self._batched_transitions = self.transition_class(*(np.expand_dims(x, 0) for x in b))
 
     @property
     def batched_transitions(self):
+        if self._rows is not None:
+            self._materialise()
         return self._batched_transitions
 
     def sample(self, num_samples: int = 1, k_steps: int = 5):
         if len(self) <= k_steps:
             return []
+        if self._rows is not None:
+            self._materialise()
         max_idx = len(self) - k_steps
         idxes = random.choices(range(max_idx), weights=self._transition_weight[:max_idx], k=num_samples)
         if self._batched_transitions is None:
@@ -48,10 +87,12 @@ class Trajectory:
         return [self._batched_transitions[:, i:i + k_steps] for i in idxes]
 
     def __getitem__(self, index):
+        if self._rows is not None:
+            return self.transition_class(*(c[index] for c in self._rows))
         return self.trajectory[index]
 
     def __len__(self):
-        return len(self.trajectory)
+        return self._length if self._rows is not None else len(self.trajectory)
 
     def __repr__(self):
         return f"{type(self)}(len={len(self)})"

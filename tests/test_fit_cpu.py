@@ -67,3 +67,124 @@ def test_fit_argument_errors_match_the_reference():
         mx.fit(None, env_id="CartPole-v1", env=object())
     with pytest.raises(ValueError):
         mx.fit(None, env=object())
+
+
+# ---- vectorised tracer / collector (muax_amd/vector.py) against the per-step tracers ----
+def _trace_with(tracer, obs, a, r, v, pi):
+    tracer.reset()
+    out = []
+    T = len(r)
+    for t in range(T):
+        tracer.add(obs[t], int(a[t]), float(r[t]), t == T - 1, v=float(v[t]), pi=pi[t:t + 1])
+        while tracer:
+            out.append(tracer.pop())
+    return out
+
+
+@pytest.mark.parametrize("T", [1, 3, 5, 6, 23])
+@pytest.mark.parametrize("alpha", [None, 0.5])
+def test_vectorised_nstep_equals_the_per_step_tracer(T, alpha):
+    import muax_amd as mx
+    rng = np.random.default_rng(T)
+    n, gamma = 5, 0.97
+    obs = rng.normal(size=(T, 4)).astype(np.float32)
+    a, r, v = rng.integers(0, 3, T), rng.normal(size=T), rng.normal(size=T)
+    pi = rng.dirichlet(np.ones(3), T).astype(np.float32)
+    ref = _trace_with(mx.NStep(n, gamma) if alpha is None else mx.PNStep(n, gamma, alpha), obs, a, r, v, pi)
+    tr = mx.episode_trajectory(obs, a, r, v, pi, n, gamma, alpha)
+    assert len(tr) == len(ref) == T
+    for t, want in enumerate(ref):
+        got = tr[t]
+        assert np.array_equal(got.obs, want.obs) and int(got.a) == want.a and float(got.r) == want.r
+        assert bool(got.done) == want.done and float(got.v) == want.v and np.array_equal(got.pi, want.pi)
+        assert abs(float(got.Rn) - want.Rn) <= 1e-12 * max(1.0, abs(want.Rn))
+        assert abs(float(got.w) - want.w) <= 1e-9
+    # the batch a sample produces has the shapes of a trajectory filled by add()
+    listed = mx.Trajectory()
+    for tt in ref:
+        listed.add(tt)
+    listed.finalize()
+    for x, y in zip(tr.batched_transitions, listed.batched_transitions):
+        assert x.shape == y.shape
+    if T > 3:
+        s = tr.sample(num_samples=4, k_steps=3)
+        assert len(s) == 4 and s[0].obs.shape == (1, 3, 4) and s[0].pi.shape == (1, 3, 1, 3)
+    with pytest.raises(ValueError):
+        tr.add(ref[0])
+
+
+class _ScriptedVecEnv:
+    """Episode lengths scripted per environment; observation = (env id, episode, step)."""
+
+    def __init__(self, lengths):
+        self.lengths, self.n = lengths, len(lengths)
+
+    def _obs(self):
+        return np.stack([np.array([e, self.ep[e], self.t[e]], np.float32) for e in range(self.n)])
+
+    def reset(self):
+        self.ep, self.t = [0] * self.n, [0] * self.n
+        return self._obs()
+
+    def step(self, actions):
+        r, d = np.zeros(self.n), np.zeros(self.n, bool)
+        for e in range(self.n):
+            r[e] = 1.0 + 0.1 * e + 0.01 * self.t[e] + float(actions[e])
+            self.t[e] += 1
+            if self.t[e] == self.lengths[e][self.ep[e] % len(self.lengths[e])]:
+                d[e], self.ep[e], self.t[e] = True, self.ep[e] + 1, 0
+        return self._obs(), r, d
+
+
+class _FakeModel:
+    """act() as a pure function of the observation, so two collection schemes can be compared."""
+
+    def act(self, key, obs, with_pi=False, with_value=False, obs_from_batch=False, **kw):
+        obs = np.asarray(obs, np.float32)
+        a = (obs.sum(1) % 2).astype(np.int64)
+        pi = np.stack([0.25 + 0.5 * (a == 0), 0.25 + 0.5 * (a == 1)], 1).astype(np.float32)
+        v = obs.sum(1).astype(np.float64) * 0.1
+        return a, pi, v
+
+
+def test_vector_collector_cuts_the_stream_into_the_same_episodes_as_per_env_tracers():
+    import muax_amd as mx
+    lengths = [[3, 7], [12], [1, 2, 30], [9, 4]]
+    n, gamma, alpha = 4, 0.9, 0.5
+    col = mx.VectorCollector(_ScriptedVecEnv(lengths), n, gamma, alpha)
+    key = mx.prng.PRNGKey(0)
+    got = []
+    for steps in (5, 11, 8, 17):  # episodes straddle the call boundaries
+        trajs, key, count = col.collect(_FakeModel(), key, steps, num_simulations=4)
+        assert count == steps * 4
+        got += trajs
+    # the same stream through one PNStep per environment
+    env, model = _ScriptedVecEnv(lengths), _FakeModel()
+    obs = env.reset()
+    tracers = [mx.PNStep(n, gamma, alpha) for _ in lengths]
+    want = {e: [] for e in range(len(lengths))}
+    cur = {e: mx.Trajectory() for e in range(len(lengths))}
+    for _ in range(5 + 11 + 8 + 17):
+        a, pi, v = model.act(None, obs)
+        nxt, r, d = env.step(a)
+        for e in range(len(lengths)):
+            tracers[e].add(obs[e], int(a[e]), float(r[e]), bool(d[e]), v=float(v[e]), pi=pi[e:e + 1])
+            while tracers[e]:
+                cur[e].add(tracers[e].pop())
+            if d[e]:
+                cur[e].finalize()
+                want[e].append(cur[e])
+                cur[e] = mx.Trajectory()
+                tracers[e].reset()
+        obs = nxt
+    by_env = {e: [] for e in range(len(lengths))}
+    for tr in got:
+        by_env[int(tr[0].obs[0])].append(tr)
+    for e in by_env:
+        assert len(by_env[e]) == len(want[e]) > 0
+        for x, y in zip(by_env[e], want[e]):
+            assert len(x) == len(y)
+            bx, by = x.batched_transitions, y.batched_transitions
+            assert np.array_equal(bx.obs, by.obs) and np.array_equal(bx.a, by.a) and np.array_equal(bx.done, by.done)
+            assert np.array_equal(bx.pi, by.pi) and np.allclose(bx.Rn, by.Rn, rtol=1e-12, atol=0)
+            assert np.allclose(bx.w, by.w, rtol=1e-9, atol=1e-12) and np.array_equal(bx.r, by.r)

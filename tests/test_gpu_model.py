@@ -84,6 +84,24 @@ def test_act_return_conventions():
     assert abs(pi5[0, 0] * 5 - round(pi5[0, 0] * 5)) < 1e-5
 
 
+def test_large_batches_draw_their_root_noise_on_the_device_deterministically():
+    """B*A >= 1024: the Dirichlet root noise is drawn on the GPU from the dirichlet sub-key; the same key
+    must give the same act() and another key another one; the noise mixes into every root's prior."""
+    from muax_amd.model import _dirichlet
+    m = _model()
+    batch = np.random.default_rng(4).uniform(-1, 1, (2048, 4)).astype(F32)
+    a1, p1, v1 = m.act(7, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=20)
+    a2, p2, v2 = m.act(7, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=20)
+    a3, p3, _ = m.act(8, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=20)
+    assert np.array_equal(a1, a2) and np.array_equal(p1, p2) and np.array_equal(v1, v2)
+    assert not np.array_equal(p1, p3)
+    d = _dirichlet((3, 4), 0.3, (2048, 2), "cuda")
+    assert d.is_cuda and d.dtype == torch.float32 and torch.allclose(d.sum(1), torch.ones(2048, device="cuda"), atol=1e-6)
+    assert torch.equal(d, _dirichlet((3, 4), 0.3, (2048, 2), "cuda")) and float(d.min()) >= 0.0
+    # Dir(0.3, 0.3): symmetric, mass near the corners -- mean 1/2, variance 1/(4 (2 alpha + 1)) = 0.15625
+    assert abs(float(d[:, 0].mean()) - 0.5) < 0.03 and abs(float(d[:, 0].var()) - 0.15625) < 0.02
+
+
 def test_act_greedy_and_invalid_actions():
     m = _model(A=4, obs_dim=6)
     batch = np.random.default_rng(2).uniform(-1, 1, (64, 6)).astype(F32)

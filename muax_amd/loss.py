@@ -17,8 +17,6 @@ muax/loss.py:60-61).  Reference quirks handled explicitly:
 """
 from __future__ import annotations
 
-from typing import Any
-
 import torch
 
 from . import utils as mx_utils

@@ -24,7 +24,7 @@ from . import utils as mx_utils
 from .nn import MZNetwork, MZNetworkParams
 from .optimizers import optimizer  # noqa: F401  (the README's `muax.model.optimizer(...)`)
 from .policy import GumbelMuZeroPolicy, MuZeroPolicy, Policy
-from .search import MuZeroSearch, PolicyOutput, SearchConfig
+from .search import MuZeroSearch, PolicyOutput, SearchConfig  # noqa: F401  (PolicyOutput: re-exported type)
 
 
 _DEVICE_GENERATORS = {}

@@ -216,8 +216,18 @@ typedef struct mzs_tower_args {
   float *prior_logits;     /* [B, A] out */
   int32_t support_size;    /* F = 2 * support_size + 1 <= 64 */
   int32_t reserved0;
+  /* Optional pair mode for small batches (2 * batch workgroups must be resident at once: batch <= 128):
+   * two workgroups per root split the pixels of its map and swap boundary pixels + LayerNorm moments
+   * through `pair_scratch` (caller-owned device memory of mzs_tower_pair_scratch_bytes(batch) bytes,
+   * ZEROED once when allocated and then left to the library; one scratch per stream).  NULL: one
+   * workgroup per root.  Word 4 r + 3 of the trailing uint32 region turns non-zero if root r's halves ever
+   * lost each other (bounded spin ran out): results of that launch are then invalid. */
+  void *pair_scratch;
+  int64_t pair_scratch_bytes;
 } mzs_tower_args;
 int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
+/* bytes of pair_scratch for `batch` roots (0 if pair mode cannot run that batch) */
+int64_t mzs_tower_pair_scratch_bytes(int32_t batch);
 
 #ifdef __cplusplus
 }

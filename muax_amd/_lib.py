@@ -67,14 +67,15 @@ class MzsTowerArgs(C.Structure):
     HEAD_FIELDS = ["r_c1", "r_c2", "r_l1", "r_b1", "r_l2", "r_b2", "v_c1", "v_c2", "v_l1", "v_b1", "v_l2", "v_b2",
                    "p_c1", "p_l1", "p_b1", "p_l2", "p_b2"]
     _fields_ += [(n, _vp) for n in HEAD_FIELDS] + [("reward", _vp), ("value", _vp), ("prior_logits", _vp),
-                                                   ("support_size", C.c_int32), ("reserved0", C.c_int32)]
+                                                   ("support_size", C.c_int32), ("reserved0", C.c_int32),
+                                                   ("pair_scratch", _vp), ("pair_scratch_bytes", C.c_int64)]
 
 
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
-                    "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower"]
+                    "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes"]
 
 _lib = None
 
@@ -111,6 +112,8 @@ def load(build_if_missing: bool = True):
         getattr(L, n).restype = C.c_int
     L.mzs_mlp_num_params.restype = C.c_int64
     L.mzs_mlp_train_workspace_bytes.restype = C.c_int64
+    L.mzs_tower_pair_scratch_bytes.argtypes = [C.c_int32]
+    L.mzs_tower_pair_scratch_bytes.restype = C.c_int64
     if L.mzs_abi_version() != 1:
         raise RuntimeError("libmzsearch.so ABI version mismatch")
     _lib = L

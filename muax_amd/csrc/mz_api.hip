@@ -626,9 +626,33 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     tower_attr = true;
   }
+  if (a->pair_scratch) {
+    const int64_t need = mzs_tower_pair_scratch_bytes(a->batch);
+    if (need == 0) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_resnet_tower: pair mode needs batch <= 128");
+    if (a->pair_scratch_bytes < need) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: pair_scratch too small");
+    if (2 * a->blocks + 1 > mz::kPairMsgs) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_resnet_tower: too many blocks for pair mode");
+    p.pair_f = static_cast<float*>(a->pair_scratch);
+    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot);
+    static bool pair_attr = false;
+    if (!pair_attr) {
+      MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_pair_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      pair_attr = true;
+    }
+    const int groups = (a->batch + 7) / 8;  // 16 blocks = 8 roots x 2 halves
+    hipLaunchKernelGGL(mz::mz_resnet_tower_pair_kernel, dim3(16 * groups), dim3(256), lds,
+                       static_cast<hipStream_t>(stream_), p);
+    MZS_HIP(nullptr, hipGetLastError());
+    return MZS_OK;
+  }
   hipLaunchKernelGGL(mz::mz_resnet_tower_kernel, dim3(a->batch), dim3(256), lds, static_cast<hipStream_t>(stream_), p);
   MZS_HIP(nullptr, hipGetLastError());
   return MZS_OK;
+}
+
+int64_t mzs_tower_pair_scratch_bytes(int32_t batch) {
+  if (batch <= 0 || batch > 128) return 0;  // 2 * batch workgroups have to be resident together
+  return (int64_t)batch * (4 * mz::kPairSlot * (int64_t)sizeof(float) + 4 * (int64_t)sizeof(unsigned));
 }
 
 }  // extern "C"

@@ -8,7 +8,7 @@
 // LDS (pixel stride 68 words: 16-byte aligned rows that still spread over the banks).  A 3x3 convolution is
 // an implicit GEMM  out[36 px (padded to 48)][64 co] = sum_{tap, ci} in[px + tap][ci] W[tap][ci][co]  on
 // v_mfma_f32_16x16x4_f32: wave w owns output channels 16 w .. 16 w + 15 for the two full pixel tiles; the
-// last four pixels run on v_mfma_f32_4x4x1 with K split across the waves (see conv3x3_tiles).  K is walked
+// last four pixels run on v_mfma_f32_4x4x1 on the same weight registers (see conv3x3_tiles).  K is walked
 // in 36 groups of 16 input channels; per group a lane issues ONE ds_read_b128 of activations per tile and
 // ONE global_load_dwordx4 of weights (host-packed so that the four k-steps of a lane are contiguous), six
 // groups ahead and across convolution boundaries; the projection and conv_0 of a block share one pass.  LayerNorm over the
@@ -16,6 +16,7 @@
 // projection shortcut stays in registers until the block's final add.  The heads are small: 1x1 convolutions
 // on the same MFMA tiles, flatten -> Linear layers as VALU dot products with the weights streamed from L2.
 // fp32 throughout (the search's parity bar is 1e-5 on values): 65 MFLOP per root and simulation.
+// With <= 128 roots a second kernel gives every root two workgroups ("pair mode", below).
 //
 // Floating-point kernel: checked against the torch modules of muax_amd/nn.py (tests), tolerance there.
 #pragma once
@@ -57,6 +58,9 @@ struct TowerParams {
   float* value;        // [B]
   float* prior_logits; // [B][A]
   int heads, A, F, support;
+  // pair mode (mz_resnet_tower_pair_kernel): exchange slots and flags of the two workgroups of a root
+  float* pair_f;       // [B][2 halves][2 parity][kPairSlot]
+  unsigned* pair_u;    // [B][4]: flag of half 0, flag of half 1, launch epoch, status
 };
 
 constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 68;  // 16-byte aligned pixels
@@ -64,7 +68,7 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
-constexpr int kHeadWords = 8 + 3 * 768 + 2 * 256 + 64 + 64 + 2 * 4 * 4 * 64;  // ... + remainder-row partial sums  // reduction slots + scratch of the heads
+constexpr int kHeadWords = 8 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots + scratch of the heads
 
 template <int NV>
 MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
@@ -89,27 +93,35 @@ MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
 // Weight quads are fetched kConvAhead groups ahead, activation quads one group ahead.
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 constexpr int kConvAhead = 6;
+template <int AH>
 struct ConvPrefetch {
-  f32x4u q[2][kConvAhead];  // weight quads of groups 0 .. kConvAhead-1 of the NEXT call's stream(s)
+  f32x4u q[2][AH];  // weight quads of groups 0 .. AH-1 of the NEXT call's stream(s)
 };
-MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, f32x4u (&q)[kConvAhead]) {
+template <int AH>
+MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, f32x4u (&q)[AH]) {
   const f32x4u* wq = reinterpret_cast<const f32x4u*>(Wp) + wlane;
 #pragma unroll
-  for (int i = 0; i < kConvAhead; ++i) q[i] = wq[i * 256];
+  for (int i = 0; i < AH; ++i) q[i] = wq[i * 256];
 }
 // NW convolutions of the SAME input in one pass over K (the projection and conv_0 of a residual block share
 // their activation reads).  `pf` holds the first weight quads of this call's stream(s), fetched while the
 // previous LayerNorm ran; on return it holds those of the next call's (Wnext[0 .. nnext)), so the L2
 // latency at the head of a convolution is never exposed.
 // Rows 0..31 of the 36-pixel map are two 16x16x4 tiles per wave (its 16 output channels).  The last four
-// rows would waste 3/4 of a third tile, so they run on v_mfma_f32_4x4x1_16b_f32 instead: its 16 blocks are
-// the 16 groups of four output channels (lane = channel), its four rows the four pixels, k = 1 per
-// instruction -- and the four waves SPLIT K: wave w takes the channels 16 c + 4 w + {0..3} of every group, the
-// same packed weight quads [grp][g = w][co = lane], 144 quarter-cost MFMAs per wave.  The partial sums meet
-// in LDS (`part`, NW x 4 waves x 64 lanes x 4 rows) and land in acc[.][2] of the lanes that own those pixels.
-template <int NW>
+// rows would waste 3/4 of a third tile, so they run on v_mfma_f32_4x4x1_16b_f32 instead, on the SAME B
+// registers: lane l = (g = l >> 4, n = l & 15) holds W[4 g + i][16 wave + n] for the k-step i, and in the
+// 4x4x1 layout lane l is (block l >> 2, column l & 3), i.e. block = (g, n >> 2): the 16 blocks are 4 groups
+// of four of the wave's channels x the 4 k-quads of the group.  With A = in[pixel 32 + (l & 3)][16 c + 4 g + i]
+// one instruction adds k = 4 g + i for every block; the four k-quads of a channel sit in lanes 16 apart and
+// meet in two xor-shuffles at the end.  No extra weight load, no LDS, no barrier: 144 quarter-cost MFMAs.
+// TSEL selects the pixel tiles a workgroup computes: 0 = the whole map (tiles 0, 1 and the remainder rows),
+// 1 = tile 0 only (pixels 0..15), 2 = tile 1 + the remainder rows (pixels 16..35): the two halves of a
+// root in pair mode.
+template <int TSEL>
+MZ_DEV constexpr bool tile_on(int mt) { return TSEL == 0 || (TSEL == 1 ? mt == 0 : mt >= 1); }
+template <int NW, int TSEL = 0, int AHEAD = kConvAhead>
 MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const float* const (&Wnext)[2], int nnext,
-                          const int (&abase)[3], int wlane, int lane, int wave, float* part, ConvPrefetch& pf,
+                          const int (&abase)[3], int wlane, int lane, ConvPrefetch<AHEAD>& pf,
                           f32x4 (&acc)[NW][3]) {
 #pragma unroll
   for (int s = 0; s < NW; ++s)
@@ -118,23 +130,23 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
   f32x4 rem[NW];
 #pragma unroll
   for (int s = 0; s < NW; ++s) rem[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  constexpr int G = 36, AHEAD = kConvAhead;
+  constexpr int G = 36;
   f32x4u wbuf[NW][AHEAD + 1];
   f32x4u abuf[2][2];
   auto a_off = [](int grp) { return (((grp >> 2) / 3) * kHalo + ((grp >> 2) % 3)) * kPixStride + 16 * (grp & 3); };
-  // remainder rows: pixel 32 + (lane & 3), input channels 16 c + 4 wave + {0..3}; weights [grp][g = wave][co = lane]
-  const int rbase = ((32 + (lane & 3)) / kTowerHW * kHalo + (32 + (lane & 3)) % kTowerHW) * kPixStride + 4 * wave;
-  const int rlane = wave * kTowerC + lane;
-  f32x4u rw[NW][2], ra[2];
+  // remainder rows: lane reads pixel 32 + (lane & 3), input channels 16 c + 4 (lane >> 4) + {0..3}
+  const int rbase = ((32 + (lane & 3)) / kTowerHW * kHalo + (32 + (lane & 3)) % kTowerHW) * kPixStride + 4 * (lane >> 4);
+  f32x4u ra[2];
+  constexpr bool REM = TSEL != 1;
 #pragma unroll
   for (int s = 0; s < NW; ++s) {
 #pragma unroll
     for (int q = 0; q < AHEAD; ++q) wbuf[s][q] = pf.q[s][q];
-    rw[s][0] = (reinterpret_cast<const f32x4u*>(Wp[s]) + rlane)[0];
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) abuf[0][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(0));
-  ra[0] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(0));
+  for (int mt = 0; mt < 2; ++mt)
+    if (tile_on<TSEL>(mt)) abuf[0][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(0));
+  if constexpr (REM) ra[0] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(0));
   StaticFor<0, G>::run([&](auto gc) {
     constexpr int grp = decltype(gc)::value;
     if constexpr (grp + AHEAD < G) {
@@ -150,10 +162,9 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
     if constexpr (grp + 1 < G) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        abuf[(grp + 1) & 1][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(grp + 1));
-      ra[(grp + 1) & 1] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(grp + 1));
-#pragma unroll
-      for (int s = 0; s < NW; ++s) rw[s][(grp + 1) & 1] = (reinterpret_cast<const f32x4u*>(Wp[s]) + rlane)[(grp + 1) * 256];
+        if (tile_on<TSEL>(mt))
+          abuf[(grp + 1) & 1][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(grp + 1));
+      if constexpr (REM) ra[(grp + 1) & 1] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(grp + 1));
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here: the scheduler otherwise sinks them
 #pragma unroll
@@ -162,26 +173,26 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
       for (int s = 0; s < NW; ++s) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], wbuf[s][grp % (AHEAD + 1)][i],
-                                                            acc[s][mt], 0, 0, 0);
-        rem[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], rw[s][grp & 1][i], rem[s], 0, 0, 0);
+          if (tile_on<TSEL>(mt))
+            acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], wbuf[s][grp % (AHEAD + 1)][i],
+                                                              acc[s][mt], 0, 0, 0);
+        if constexpr (REM)
+          rem[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], wbuf[s][grp % (AHEAD + 1)][i], rem[s], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
   });
-  // partial sums of the remainder rows: [s][wave][row v][channel = lane]
-#pragma unroll
-  for (int s = 0; s < NW; ++s)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) part[((s * 4 + wave) * 4 + v) * 64 + lane] = rem[s][v];
-  __syncthreads();
-  if (lane < 16) {
-    const int ch = 16 * wave + lane;
+  if constexpr (REM) {
+    // the four k-quads of a channel: lanes n, n + 16, n + 32, n + 48 -> every lane gets the sum; the lanes
+    // g = 0 own pixels 32..35 in the tile layout (acc[.][2][v] <-> pixel 32 + 4 g + v), the others are masked
 #pragma unroll
     for (int s = 0; s < NW; ++s)
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        acc[s][2][v] = (part[((s * 4 + 0) * 4 + v) * 64 + ch] + part[((s * 4 + 1) * 4 + v) * 64 + ch]) +
-                       (part[((s * 4 + 2) * 4 + v) * 64 + ch] + part[((s * 4 + 3) * 4 + v) * 64 + ch]);
+      for (int v = 0; v < 4; ++v) {
+        float t = rem[s][v];
+        t = t + __shfl_xor(t, 16);
+        t = t + __shfl_xor(t, 32);
+        acc[s][2][v] = t;
+      }
   }
 }
 template <int NW>
@@ -225,6 +236,7 @@ MZ_DEV void layer_norm_tiles(f32x4 (&acc)[NW][3], const float* const (&so)[NW], 
   }
 }
 
+template <int TSEL = 0>
 MZ_DEV void store_map(const f32x4 (&acc)[3], float* buf, int ch, int lane) {
   const int g = lane >> 4;
 #pragma unroll
@@ -232,7 +244,7 @@ MZ_DEV void store_map(const f32x4 (&acc)[3], float* buf, int ch, int lane) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int p = 16 * mt + 4 * g + v;
-      if (p < kTowerPix) buf[((p / kTowerHW + 1) * kHalo + p % kTowerHW + 1) * kPixStride + ch] = acc[mt][v];
+      if (tile_on<TSEL>(mt) && p < kTowerPix) buf[((p / kTowerHW + 1) * kHalo + p % kTowerHW + 1) * kPixStride + ch] = acc[mt][v];
     }
 }
 
@@ -280,29 +292,295 @@ MZ_DEV float decode_support(const float* logits, int F, int support, int lane) {
   return inv_scaling(t / s);
 }
 
-__global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// ---- pair mode: the two workgroups of one root ---------------------------------------------------------
+// With <= 128 roots a launch of one workgroup per root leaves half of the 256 CUs idle.  Pair mode gives a
+// root TWO workgroups that split the PIXELS of its map: half 0 owns pixels 0..15 (tile 0), half 1 pixels
+// 16..35 (tile 1 + the remainder rows); both keep all 64 channels, so a residual shortcut never leaves its
+// workgroup.  A 3x3 window of an owned pixel reaches at most 7 pixels into the other half (pixels 9..15 /
+// 16..22), and LayerNorm needs the other half's moments: after every convolution pass the halves swap ONE
+// message through L2 -- their local (mean, M2) and the RAW boundary pixels -- and each normalises the
+// partner's boundary pixels itself (Chan's merge of the moments, written so that both halves compute the
+// same bits).  Messages go through two slots per half (message k in slot k & 1: the partner cannot post
+// k + 2 before it has read k) and a monotonic flag per half; a per-root launch epoch in device memory keeps
+// the numbering going across launches, so a captured hipGraph can replay the kernel.  A spin that runs out
+// sets the root's status word instead of hanging.  Needs both workgroups resident at once: the host uses it
+// only while 2 B workgroups fit the chip in one wave of dispatch.
+constexpr int kPairSlot = 1536;   // floats per message slot: 8 header + 128 (min, max) + 1280 or 2 x 448 payload
+constexpr int kPairBnd = 7;       // boundary pixels each half sends
+constexpr int kPairMsgs = 64;     // messages per launch, upper bound (epoch stride)
+constexpr unsigned kPairSpin = 1u << 19;
+template <int TSEL>
+struct PairGeom {
+  static constexpr int first_own = TSEL == 1 ? 0 : 16, n_own = TSEL == 1 ? 16 : 20;
+  static constexpr int send_first = TSEL == 1 ? 9 : 16, recv_first = TSEL == 1 ? 16 : 9;
+};
+struct PairLink {
+  float* mine;                // [2][kPairSlot]
+  const float* theirs;        // [2][kPairSlot]
+  unsigned* my_flag;
+  const unsigned* their_flag;
+  unsigned* status;
+  unsigned seq;               // number of the last message posted
+  unsigned xcc;               // 1 + id of the XCD this workgroup runs on
+};
+MZ_DEV float* pair_out(const PairLink& L) { return L.mine + ((L.seq + 1) & 1) * kPairSlot; }
+// The two halves of a root sit on the SAME XCD (see mz_resnet_tower_pair_kernel) and meet in that XCD's L2:
+// a CU's L1 is write-through, so a message is in L2 once vmcnt has drained (then the barrier, then the
+// flag); the reader drops its L1 (`buffer_inv sc0`, L1 only) before it looks at the flag and at the
+// message.  What did NOT work: agent-scope fences (their L2 write-back / invalidate threw the convolution
+// weights out of L2 for every workgroup of the XCD, 17 times per launch: 725 us at 128 roots), group-scope
+// atomics (sc0 loads may hit L1 when a workgroup is not split over CUs: the flag was never seen), and
+// device-scope atomics for every word (correct, but each message then costs a trip to the memory side:
+// 4 us per message).  Each message carries the sender's XCC id; a half that sees another id than its own
+// reports status 2 -- the L2 rendezvous is only valid inside one XCD.
+MZ_DEV void pair_store(float* q, float v) { *q = v; }
+MZ_DEV float pair_load(const float* q) { return *reinterpret_cast<const volatile float*>(q); }
+MZ_DEV void pair_post(PairLink& L, int tid) {  // every thread has stored its part of the message
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  L.seq += 1;
+  if (tid == 0) *reinterpret_cast<volatile unsigned*>(L.my_flag) = L.seq;
+}
+MZ_DEV const float* pair_wait(PairLink& L, int tid) {  // the partner's message number L.seq
+  const float* in = L.theirs + (L.seq & 1) * kPairSlot;
+  if (tid == 0) {
+    unsigned n = 0;
+    for (;;) {
+      asm volatile("buffer_inv sc0" ::: "memory");
+      if ((int)(*reinterpret_cast<const volatile unsigned*>(L.their_flag) - L.seq) >= 0) break;
+      if (*reinterpret_cast<const volatile unsigned*>(L.status) != 0u) break;  // once lost, never wait again
+      if (++n > kPairSpin) {
+        *reinterpret_cast<volatile unsigned*>(L.status) = 1u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  asm volatile("buffer_inv sc0" ::: "memory");
+  if (tid == 0 && __float_as_uint(pair_load(in + 4)) != L.xcc && *reinterpret_cast<const volatile unsigned*>(L.status) == 0u)
+    *reinterpret_cast<volatile unsigned*>(L.status) = 2u;
+  return in;
+}
+MZ_DEV int map_word(int px) { return ((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride; }
+
+// moments of the OWN pixels of NW maps: mean over n_own * 64 elements and M2 = sum (x - mean)^2
+template <int NW, int TSEL>
+MZ_DEV void own_moments(const f32x4 (&acc)[NW][3], float (&mean)[NW], float (&m2)[NW], int lane, int wave, float* red) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    mean[s] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        mean[s] = mean[s] + ((tile_on<TSEL>(mt) && 16 * mt + 4 * g + v < kTowerPix) ? acc[s][mt][v] : 0.0f);
+  }
+  wg_sum<NW>(mean, red, wave, lane);
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    mean[s] = mean[s] * (1.0f / (PairGeom<TSEL>::n_own * kTowerC));
+    m2[s] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float d = acc[s][mt][v] - mean[s];
+        m2[s] = m2[s] + ((tile_on<TSEL>(mt) && 16 * mt + 4 * g + v < kTowerPix) ? d * d : 0.0f);
+      }
+  }
+  wg_sum<NW>(m2, red, wave, lane);
+}
+// moments of half 0 (16 x 64 elements) and half 1 (20 x 64) -> mean and 1 / sqrt(var + eps) of the whole map
+MZ_DEV void merge_moments(float m0, float q0, float m1, float q1, float& mean, float& rstd) {
+  constexpr float n0 = 16.0f * kTowerC, n1 = 20.0f * kTowerC, n = n0 + n1;
+  const float d = m1 - m0;
+  mean = m0 + d * (n1 / n);
+  const float M2 = (q0 + q1) + (d * d) * (n0 * n1 / n);
+  rstd = 1.0f / __builtin_sqrtf(M2 * (1.0f / n) + 1e-5f);
+}
+template <int TSEL>
+MZ_DEV void put_boundary(const f32x4 (&acc)[3], float* dst, int ch, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int b = 16 * mt + 4 * g + v - PairGeom<TSEL>::send_first;
+      if (tile_on<TSEL>(mt) && b >= 0 && b < kPairBnd) pair_store(dst + b * kTowerC + ch, acc[mt][v]);
+    }
+}
+MZ_DEV void norm_tiles(f32x4 (&acc)[3], float mean, float rstd, const float* so, bool relu, int ch) {
+  const float sc = so[ch], of = so[kTowerC + ch];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float o = (acc[mt][v] - mean) * rstd * sc + of;
+      acc[mt][v] = relu ? fmaxf(o, 0.0f) : o;
+    }
+}
+
+// ---- the heads (muax/nn.py:313-357), on full maps ----
+struct HeadLds {
+  float *hv, *hv2, *hp, *part, *part2, *vec, *lgt;
+};
+// reward head on [s, a / num_actions] held in `in` (haloed map); `tmp` is a second haloed map
+MZ_DEV void reward_head(const TowerParams& p, int r, const float* in, float* tmp, const HeadLds& H,
+                        const int (&rowc)[3], int ch, int tid, int lane, int wave) {
+  const int g4 = lane >> 4;
+  f32x4 acc[3];
+  conv1x1_tiles(in, rowc, p.r_c1, kTowerC, ch, 4, g4, acc);
+  const float pl = (float)p.action[r] * p.inv_num_actions * p.r_c1[kTowerC * kTowerC + ch];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v] + pl, 0.0f);
+  store_map(acc, tmp, ch, lane);
+  __syncthreads();
+  conv1x1_tiles(tmp, rowc, p.r_c2, kTowerC, ch, 4, g4, acc);
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v], 0.0f);
+  __syncthreads();  // every wave has read tmp
+  store_map(acc, tmp, ch, lane);
+  __syncthreads();
+  {
+    // Linear(2304 -> 64): wave = 9 pixels of the map, lane = output unit; weights stream from L2
+    float sacc = 0.0f;
+    for (int px = 9 * wave; px < 9 * wave + 9; ++px) {
+      const float* row = tmp + map_word(px);
+      const float* wr = p.r_l1 + (size_t)px * kTowerC * kTowerC + lane;
+#pragma unroll 8
+      for (int c = 0; c < kTowerC; ++c) sacc = __builtin_fmaf(row[c], wr[c * kTowerC], sacc);
+    }
+    H.part[tid] = sacc;
+  }
+  __syncthreads();
+  if (tid < 64)
+    H.vec[tid] = fmaxf(((H.part[tid] + H.part[64 + tid]) + (H.part[128 + tid] + H.part[192 + tid])) + p.r_b1[tid], 0.0f);
+  __syncthreads();
+  if (tid < p.F) {
+    float a = 0.0f;
+    for (int k = 0; k < 64; ++k) a = __builtin_fmaf(H.vec[k], p.r_l2[k * p.F + tid], a);
+    H.lgt[tid] = a + p.r_b2[tid];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float rw = decode_support(H.lgt, p.F, p.support, lane);
+    if (lane == 0) p.reward[r] = rw;
+  }
+  __syncthreads();
+}
+// prediction heads on the normalised next state held in `cur` (haloed map)
+MZ_DEV void prediction_heads(const TowerParams& p, int r, const float* cur, const HeadLds& H, const int (&rowc)[3],
+                             int tid, int lane, int wave) {
+  const int g4 = lane >> 4, n16 = lane & 15;
+  if (wave < 2) {  // wave 0: value head, wave 1: policy head -- first 1x1 conv (64 -> 16) + relu
+    f32x4 h[3];
+    conv1x1_tiles(cur, rowc, wave == 0 ? p.v_c1 : p.p_c1, 16, n16, 4, g4, h);
+    float* dst = wave == 0 ? H.hv : H.hp;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int px = 16 * mt + 4 * g4 + v;
+        if (px < kTowerPix) dst[px * 16 + n16] = fmaxf(h[mt][v], 0.0f);
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {  // value head: second 1x1 conv (16 -> 16) + relu
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const f32x4 h = conv1x1_k16(H.hv + (16 * mt + n16) * 16 + 4 * g4, p.v_c2, n16, g4);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int px = 16 * mt + 4 * g4 + v;
+        if (px < kTowerPix) H.hv2[px * 16 + n16] = fmaxf(h[v], 0.0f);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // Linear(576 -> 16) of both heads: thread = (output unit n, one of 16 slices of 36 inputs)
+    const int n = tid & 15, sl = tid >> 4;
+    float sv = 0.0f, sp = 0.0f;
+    for (int i = 36 * sl; i < 36 * sl + 36; ++i) {
+      sv = __builtin_fmaf(H.hv2[i], p.v_l1[i * 16 + n], sv);
+      sp = __builtin_fmaf(H.hp[i], p.p_l1[i * 16 + n], sp);
+    }
+    __syncthreads();
+    H.part[tid] = sv;
+    H.part2[tid] = sp;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int n = tid & 15;
+    const float* src = tid < 16 ? H.part : H.part2;
+    float a = 0.0f;
+    for (int sl = 0; sl < 16; ++sl) a = a + src[sl * 16 + n];
+    H.vec[tid] = fmaxf(a + (tid < 16 ? p.v_b1[n] : p.p_b1[n]), 0.0f);
+  }
+  __syncthreads();
+  if (tid < p.F) {
+    float a = 0.0f;
+    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[k], p.v_l2[k * p.F + tid], a);
+    H.lgt[tid] = a + p.v_b2[tid];
+  } else if (tid >= 64 && tid < 64 + p.A) {
+    const int j = tid - 64;
+    float a = 0.0f;
+    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[16 + k], p.p_l2[k * p.A + j], a);
+    p.prior_logits[(size_t)r * p.A + j] = a + p.p_b2[j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float vl = decode_support(H.lgt, p.F, p.support, lane);
+    if (lane == 0) p.value[r] = vl;
+  }
+}
+
+MZ_DEV void load_state(const TowerParams& p, int r, float* buf, int tid) {
+  const float* xin = p.x + (size_t)r * kTowerPix * kTowerC;
+  for (int i = tid; i < kTowerPix * kTowerC; i += 256) buf[map_word(i >> 6) + (i & 63)] = xin[i];
+}
+
+// One root (TSEL = 0) or one half of a root (TSEL = 1: pixels 0..15, TSEL = 2: pixels 16..35).
+template <int TSEL>
+MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
+  constexpr bool PAIR = TSEL != 0;
+  using Geo = PairGeom<TSEL>;
   float* bufA = lds;
   float* bufB = lds + kBufWords;
   float* red = lds + 2 * kBufWords;
-  float* hv = red + 8;            // [48][16] value head map (rows >= 36 stay zero)
-  float* hv2 = hv + 768;          // [48][16]
-  float* hp = hv2 + 768;          // [48][16] policy head map
-  float* part = hp + 768;         // [256] partial sums of the flatten -> Linear layers
-  float* part2 = part + 256;      // [256]
-  float* vec = part2 + 256;       // [64] hidden vectors
-  float* lgt = vec + 64;          // [64] logits
-  float* part3 = lgt + 64;        // [2][4 waves][4 rows][64] partial sums of the 4x4x1 remainder tiles
+  HeadLds H;
+  H.hv = red + 8;             // [48][16] value head map (rows >= 36 stay zero)
+  H.hv2 = H.hv + 768;         // [48][16]
+  H.hp = H.hv2 + 768;         // [48][16] policy head map
+  H.part = H.hp + 768;        // [256] partial sums of the flatten -> Linear layers
+  H.part2 = H.part + 256;     // [256]
+  H.vec = H.part2 + 256;      // [64] hidden vectors
+  H.lgt = H.vec + 64;         // [64] logits
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = blockIdx.x;
   for (int i = tid; i < 2 * kBufWords + kHeadWords; i += 256) lds[i] = 0.0f;
   __syncthreads();
-  const float* xin = p.x + (size_t)r * kTowerPix * kTowerC;
-  for (int i = tid; i < kTowerPix * kTowerC; i += 256) {
-    const int px = i >> 6, c = i & 63;
-    bufA[((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride + c] = xin[i];
-  }
+  load_state(p, r, bufA, tid);
   __syncthreads();
+
+  PairLink L;
+  if constexpr (PAIR) {
+    constexpr int h = TSEL - 1;
+    float* base = p.pair_f + (size_t)r * 4 * kPairSlot;
+    unsigned* u = p.pair_u + (size_t)r * 4;
+    L.mine = base + h * 2 * kPairSlot;
+    L.theirs = base + (1 - h) * 2 * kPairSlot;
+    L.my_flag = u + h;
+    L.their_flag = u + (1 - h);
+    L.status = u + 3;
+    L.seq = u[2] * kPairMsgs;  // the launch epoch: written only at the very end of a launch, by half 0
+    L.xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg(6164);  // hwreg(HW_REG_XCC_ID, 0, 4)
+  }
 
   // A operand: lane (m = lane & 15, kk = lane >> 4) reads pixel 16 mt + m, input channel 4 c4 + kk
   int abase[3];
@@ -315,60 +593,17 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
   const int ch = 16 * wave + (lane & 15);            // this lane's output channel
   const int wcol = (lane >> 4) * kTowerC + ch;       // B operand: quad [g = lane >> 4][co = ch] of a packed group
   f32x4 acc[3];
-
-  const int g4 = lane >> 4, n16 = lane & 15;
   int rowc[3];  // centre-tap rows for 1x1 convolutions on a haloed map
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) rowc[mt] = abase[mt] + (kHalo + 1) * kPixStride;
-  if (p.heads) {
-    // ---- reward head on [s, a / num_actions] (muax/nn.py:347-357): two 1x1 convs, flatten, two Linears ----
-    conv1x1_tiles(bufA, rowc, p.r_c1, kTowerC, ch, 4, g4, acc);
-    const float pl = (float)p.action[r] * p.inv_num_actions * p.r_c1[kTowerC * kTowerC + ch];
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v] + pl, 0.0f);
-    store_map(acc, bufB, ch, lane);
-    __syncthreads();
-    conv1x1_tiles(bufB, rowc, p.r_c2, kTowerC, ch, 4, g4, acc);
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v], 0.0f);
-    __syncthreads();  // every wave has read bufB
-    store_map(acc, bufB, ch, lane);
-    __syncthreads();
-    {
-      // Linear(2304 -> 64): wave = 9 pixels of the map, lane = output unit; weights stream from L2
-      float sacc = 0.0f;
-      for (int px = 9 * wave; px < 9 * wave + 9; ++px) {
-        const float* row = bufB + ((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride;
-        const float* wr = p.r_l1 + (size_t)px * kTowerC * kTowerC + lane;
-#pragma unroll 8
-        for (int c = 0; c < kTowerC; ++c) sacc = __builtin_fmaf(row[c], wr[c * kTowerC], sacc);
-      }
-      part[tid] = sacc;
-    }
-    __syncthreads();
-    if (tid < 64) vec[tid] = fmaxf(((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + p.r_b1[tid], 0.0f);
-    __syncthreads();
-    if (tid < p.F) {
-      float a = 0.0f;
-      for (int k = 0; k < 64; ++k) a = __builtin_fmaf(vec[k], p.r_l2[k * p.F + tid], a);
-      lgt[tid] = a + p.r_b2[tid];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const float rw = decode_support(lgt, p.F, p.support, lane);
-      if (lane == 0) p.reward[r] = rw;
-    }
-    __syncthreads();
-  }
+  if constexpr (!PAIR)
+    if (p.heads) reward_head(p, r, bufA, bufB, H, rowc, ch, tid, lane, wave);
 
   float* cur = bufA;
   float* oth = bufB;
   if (p.stem_w != nullptr) {
-    // conv1x1 on [s, a / num_actions] + relu: the action plane is constant over the map
+    // conv1x1 on [s, a / num_actions] + relu: the action plane is constant over the map (pair mode: both
+    // halves compute the whole stem, it is 1 % of a block)
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int ctr = (kHalo + 1) * kPixStride;  // centre tap
@@ -394,7 +629,8 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
     float* t = cur; cur = oth; oth = t;
   }
 
-  ConvPrefetch pf;
+  constexpr int AH = kConvAhead;  // (10 groups ahead in pair mode measured the same)
+  ConvPrefetch<AH> pf;
   constexpr size_t CW = 9 * kTowerC * kTowerC;
   if (p.blocks > 0) {
     conv_prefetch(p.conv_w, wcol, pf.q[0]);
@@ -409,27 +645,80 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
     {
       const float* const w2[2] = {W, W + CW};
       const float* const nx[2] = {W + 2 * CW, nullptr};
-      conv3x3_tiles<2>(cur, w2, nx, 1, abase, wcol, lane, wave, part3, pf, pr);
+      conv3x3_tiles<2, TSEL, AH>(cur, w2, nx, 1, abase, wcol, lane, pf, pr);
       const float* const so[2] = {LN, LN + 2 * kTowerC};
-      const bool rl[2] = {false, true};
-      layer_norm_tiles<2>(pr, so, rl, ch, lane, wave, red);
+      if constexpr (!PAIR) {
+        const bool rl[2] = {false, true};
+        layer_norm_tiles<2>(pr, so, rl, ch, lane, wave, red);
+      } else {
+        // message A: moments of both maps + the raw boundary pixels of conv_0's map
+        float m[2], q[2];
+        own_moments<2, TSEL>(pr, m, q, lane, wave, red);
+        float* out = pair_out(L);
+        if (tid == 0) {
+          pair_store(out, m[0]); pair_store(out + 1, q[0]); pair_store(out + 2, m[1]); pair_store(out + 3, q[1]);
+          pair_store(out + 4, __uint_as_float(L.xcc));
+        }
+        put_boundary<TSEL>(pr[1], out + 8, ch, lane);
+        pair_post(L, tid);
+        const float* in = pair_wait(L, tid);
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float mo = pair_load(in + 2 * s), qo = pair_load(in + 2 * s + 1);
+          if (TSEL == 1) merge_moments(m[s], q[s], mo, qo, mean[s], rstd[s]);
+          else merge_moments(mo, qo, m[s], q[s], mean[s], rstd[s]);
+        }
+        norm_tiles(pr[0], mean[0], rstd[0], so[0], false, ch);
+        norm_tiles(pr[1], mean[1], rstd[1], so[1], true, ch);
+        for (int i = tid; i < kPairBnd * kTowerC; i += 256) {
+          const int c = i & 63;
+          const float o = (pair_load(in + 8 + i) - mean[1]) * rstd[1] * so[1][c] + so[1][kTowerC + c];
+          oth[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(o, 0.0f);
+        }
+      }
     }
-    store_map(pr[1], oth, ch, lane);
+    store_map<TSEL>(pr[1], oth, ch, lane);
     __syncthreads();
     f32x4 out[1][3];
     {
       const float* const w1[1] = {W + 2 * CW};
       const float* const nx[2] = {W + 3 * CW, W + 4 * CW};
-      conv3x3_tiles<1>(oth, w1, nx, last ? 0 : 2, abase, wcol, lane, wave, part3, pf, out);
+      conv3x3_tiles<1, TSEL, AH>(oth, w1, nx, last ? 0 : 2, abase, wcol, lane, pf, out);
       const float* const so[1] = {LN + 4 * kTowerC};
-      const bool rl[1] = {false};
-      layer_norm_tiles<1>(out, so, rl, ch, lane, wave, red);
+      if constexpr (!PAIR) {
+        const bool rl[1] = {false};
+        layer_norm_tiles<1>(out, so, rl, ch, lane, wave, red);
+      } else {
+        // message B: moments + raw boundary pixels of conv_1's map + the normalised shortcut at those pixels
+        float m[1], q[1];
+        own_moments<1, TSEL>(out, m, q, lane, wave, red);
+        float* msg = pair_out(L);
+        if (tid == 0) {
+          pair_store(msg, m[0]); pair_store(msg + 1, q[0]);
+          pair_store(msg + 4, __uint_as_float(L.xcc));
+        }
+        put_boundary<TSEL>(out[0], msg + 8, ch, lane);
+        put_boundary<TSEL>(pr[0], msg + 8 + kPairBnd * kTowerC, ch, lane);
+        pair_post(L, tid);
+        const float* in = pair_wait(L, tid);
+        float mean, rstd;
+        const float mo = pair_load(in), qo = pair_load(in + 1);
+        if (TSEL == 1) merge_moments(m[0], q[0], mo, qo, mean, rstd);
+        else merge_moments(mo, qo, m[0], q[0], mean, rstd);
+        norm_tiles(out[0], mean, rstd, so[0], false, ch);
+        for (int i = tid; i < kPairBnd * kTowerC; i += 256) {
+          const int c = i & 63;
+          const float o = (pair_load(in + 8 + i) - mean) * rstd * so[0][c] + so[0][kTowerC + c];
+          cur[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(pair_load(in + 8 + kPairBnd * kTowerC + i) + o, 0.0f);
+        }
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(pr[0][mt][v] + out[0][mt][v], 0.0f);
-    store_map(acc, cur, ch, lane);  // every wave is past its reads of `cur` (the LayerNorm barriers)
+    store_map<TSEL>(acc, cur, ch, lane);  // every wave is past its reads of `cur` (the LayerNorm barriers)
     __syncthreads();
   }
   if (p.blocks == 0) {
@@ -440,26 +729,52 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int px = 16 * mt + 4 * g + v;
-        acc[mt][v] = px < kTowerPix ? cur[((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride + ch] : 0.0f;
+        acc[mt][v] = px < kTowerPix ? cur[map_word(px) + ch] : 0.0f;
       }
   }
 
-  if (p.normalize) {
-    // min_max_normalize2d (muax/nn.py:47-56): per channel over the 36 pixels
+  // min_max_normalize2d (muax/nn.py:47-56): per channel over the 36 pixels
+  float mn = INFINITY, mx = -INFINITY;
+  {
     const int g = lane >> 4;
-    float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const bool ok = 16 * mt + 4 * g + v < kTowerPix;
+        const bool ok = tile_on<TSEL>(mt) && 16 * mt + 4 * g + v < kTowerPix;
         mn = ok ? fminf(mn, acc[mt][v]) : mn;
         mx = ok ? fmaxf(mx, acc[mt][v]) : mx;
       }
     mn = fminf(mn, __shfl_xor(mn, 16)); mn = fminf(mn, __shfl_xor(mn, 32));
     mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float scale = mx - mn;
-    scale = scale < 1e-5f ? scale + 1e-5f : scale;
+  }
+  const float* fin = nullptr;
+  if constexpr (PAIR) {
+    // message C: per-channel (min, max) of the own pixels; half 1 adds its 20 raw pixels for the heads
+    float* msg = pair_out(L);
+    if (tid == 0) pair_store(msg + 4, __uint_as_float(L.xcc));
+    if (lane < 16) {
+      pair_store(msg + 8 + ch, mn);
+      pair_store(msg + 8 + kTowerC + ch, mx);
+    }
+    if constexpr (TSEL == 2) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int mt = 1; mt < 3; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int px = 16 * mt + 4 * g + v;
+          if (px < kTowerPix) pair_store(msg + 8 + 2 * kTowerC + (px - 16) * kTowerC + ch, acc[mt][v]);
+        }
+    }
+    pair_post(L, tid);
+    fin = pair_wait(L, tid);
+    mn = fminf(mn, pair_load(fin + 8 + ch));
+    mx = fmaxf(mx, pair_load(fin + 8 + kTowerC + ch));
+  }
+  float scale = mx - mn;
+  scale = scale < 1e-5f ? scale + 1e-5f : scale;
+  if (p.normalize) {
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -473,75 +788,55 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams 
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int px = 16 * mt + 4 * g + v;
-        if (px < kTowerPix) yout[px * kTowerC + ch] = acc[mt][v];
+        if (tile_on<TSEL>(mt) && px < kTowerPix) yout[px * kTowerC + ch] = acc[mt][v];
       }
+  }
+  if constexpr (TSEL == 1) {
+    if (tid == 0) p.pair_u[(size_t)r * 4 + 2] += 1;  // next launch's epoch: half 1 read it before its first message
   }
   if (p.heads) {
-    // ---- prediction heads on the normalised next state (muax/nn.py:313-341) ----
-    store_map(acc, cur, ch, lane);
-    __syncthreads();
-    if (wave < 2) {  // wave 0: value head, wave 1: policy head -- first 1x1 conv (64 -> 16) + relu
-      f32x4 h[3];
-      conv1x1_tiles(cur, rowc, wave == 0 ? p.v_c1 : p.p_c1, 16, n16, 4, g4, h);
-      float* dst = wave == 0 ? hv : hp;
-#pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int px = 16 * mt + 4 * g4 + v;
-          if (px < kTowerPix) dst[px * 16 + n16] = fmaxf(h[mt][v], 0.0f);
+    if constexpr (TSEL == 2) {
+      // half 1: the reward head, on the state reloaded into the (now free) buffers
+      __syncthreads();
+      load_state(p, r, bufA, tid);
+      __syncthreads();
+      reward_head(p, r, bufA, bufB, H, rowc, ch, tid, lane, wave);
+    } else {
+      // ---- prediction heads on the normalised next state ----
+      store_map<TSEL>(acc, cur, ch, lane);
+      if constexpr (TSEL == 1) {
+        // the other 20 pixels arrive raw: normalise them with their channel's (min, scale)
+        __syncthreads();
+        float* cmn = H.part;   // [64] min, [64] scale per channel
+        if (lane < 16) {
+          cmn[ch] = mn;
+          cmn[kTowerC + ch] = scale;
         }
-    }
-    __syncthreads();
-    if (wave == 0) {  // value head: second 1x1 conv (16 -> 16) + relu
-#pragma unroll
-      for (int mt = 0; mt < 3; ++mt) {
-        const f32x4 h = conv1x1_k16(hv + (16 * mt + n16) * 16 + 4 * g4, p.v_c2, n16, g4);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int px = 16 * mt + 4 * g4 + v;
-          if (px < kTowerPix) hv2[px * 16 + n16] = fmaxf(h[v], 0.0f);
+        __syncthreads();
+        for (int i = tid; i < 20 * kTowerC; i += 256) {
+          const int c = i & 63;
+          const float raw = pair_load(fin + 8 + 2 * kTowerC + i);
+          cur[map_word(16 + (i >> 6)) + c] = p.normalize ? (raw - cmn[c]) / cmn[kTowerC + c] : raw;
         }
-      }
-    }
-    __syncthreads();
-    {
-      // Linear(576 -> 16) of both heads: thread = (output unit n, one of 16 slices of 36 inputs)
-      const int n = tid & 15, sl = tid >> 4;
-      float sv = 0.0f, sp = 0.0f;
-      for (int i = 36 * sl; i < 36 * sl + 36; ++i) {
-        sv = __builtin_fmaf(hv2[i], p.v_l1[i * 16 + n], sv);
-        sp = __builtin_fmaf(hp[i], p.p_l1[i * 16 + n], sp);
       }
       __syncthreads();
-      part[tid] = sv;
-      part2[tid] = sp;
-    }
-    __syncthreads();
-    if (tid < 32) {
-      const int n = tid & 15;
-      const float* src = tid < 16 ? part : part2;
-      float a = 0.0f;
-      for (int sl = 0; sl < 16; ++sl) a = a + src[sl * 16 + n];
-      vec[tid] = fmaxf(a + (tid < 16 ? p.v_b1[n] : p.p_b1[n]), 0.0f);
-    }
-    __syncthreads();
-    if (tid < p.F) {
-      float a = 0.0f;
-      for (int k = 0; k < 16; ++k) a = __builtin_fmaf(vec[k], p.v_l2[k * p.F + tid], a);
-      lgt[tid] = a + p.v_b2[tid];
-    } else if (tid >= 64 && tid < 64 + p.A) {
-      const int j = tid - 64;
-      float a = 0.0f;
-      for (int k = 0; k < 16; ++k) a = __builtin_fmaf(vec[16 + k], p.p_l2[k * p.A + j], a);
-      p.prior_logits[(size_t)r * p.A + j] = a + p.p_b2[j];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const float vl = decode_support(lgt, p.F, p.support, lane);
-      if (lane == 0) p.value[r] = vl;
+      prediction_heads(p, r, cur, H, rowc, tid, lane, wave);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  tower_body<0>(p, blockIdx.x, lds);
+}
+// two workgroups per root, 16 blocks = 8 roots x 2 halves laid out so that the halves of a root are 8
+// blocks apart: with the round-robin dispatch over the 8 XCDs they land on the same XCD and share its L2
+__global__ __launch_bounds__(256) void mz_resnet_tower_pair_kernel(const TowerParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int r = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), h = (blockIdx.x >> 3) & 1;
+  if (r >= p.B) return;
+  if (h == 0) tower_body<1>(p, r, lds);
+  else tower_body<2>(p, r, lds);
 }
 
 }  // namespace mz

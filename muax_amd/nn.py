@@ -10,6 +10,7 @@ through the step-wise search path.
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, NamedTuple, Optional
 
 import torch
@@ -373,6 +374,7 @@ class ResNetDynamic(nn.Module):
     def __init__(self, embedding_dim, num_actions: int = None, full_support_size: int = None, output_channels: int = 64,
                  generator=None, name="dynamic"):
         super().__init__()
+        self._pair_scratch = {}
         if full_support_size is None:  # the reference's own signature: (num_actions, full_support_size)
             embedding_dim, num_actions, full_support_size = None, embedding_dim, num_actions
         self.num_actions, self.full_support_size = num_actions, full_support_size
@@ -395,6 +397,7 @@ class ResNetDynamic(nn.Module):
 
     # ---- HIP path of the next-state tower (mzs_resnet_tower, muax_amd/csrc/mz_conv.cuh) ----
     use_hip_tower = True
+    use_pair_tower = True
 
     def _hip_tower_ok(self, s, inference=False):
         return (self.use_hip_tower and s.is_cuda and s.dtype == torch.float32 and tuple(s.shape[1:]) == (6, 6, 64)
@@ -445,9 +448,32 @@ class ResNetDynamic(nn.Module):
                     torch.empty(B, pred.num_actions, device=x.device))
             args.reward, args.value, args.prior_logits = (o.data_ptr() for o in outs)
             args.support_size = support_size
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        first = False
+        if self.use_pair_tower and os.environ.get("MZS_TOWER_PAIR", "1") != "0":
+            # <= 128 roots: two workgroups per root (mz_conv.cuh, pair mode) so that the launch covers the chip
+            nbytes = L.mzs_tower_pair_scratch_bytes(x.shape[0])
+            if nbytes:
+                key = (x.device.index or 0, x.shape[0], stream)
+                first = key not in self._pair_scratch
+                if first:
+                    self._pair_scratch[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
+                args.pair_scratch, args.pair_scratch_bytes = self._pair_scratch[key].data_ptr(), nbytes
         with torch.cuda.device(x.device):
-            _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+            _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(stream)))
+            if args.pair_scratch and first and not torch.cuda.is_current_stream_capturing():
+                # first launch on this scratch: make sure the two halves of every root found each other (they
+                # meet in one XCD's L2; a part or driver that places workgroups differently reports it here)
+                if self.pair_status():
+                    type(self).use_pair_tower = False
+                    del self._pair_scratch[key]
+                    args.pair_scratch, args.pair_scratch_bytes = None, 0
+                    _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(stream)))
         return y if outs is None else (outs[0], outs[1], outs[2], y)
+
+    def pair_status(self):
+        """Roots whose two workgroups lost each other in any pair-mode launch so far (must be 0)."""
+        return sum(int((t.view(-1)[-4 * k[1]:].view(-1, 4)[:, 3] != 0).sum()) for k, t in self._pair_scratch.items())
 
     def hip_recurrent(self, pred, s, a, support_size: int):
         """The whole recurrent_fn of muax/model.py:265-282 for the ResNet nets in ONE HIP launch: reward head,

@@ -105,7 +105,7 @@ MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, f32x4u (&q)[A
 }
 // NW convolutions of the SAME input in one pass over K (the projection and conv_0 of a residual block share
 // their activation reads).  `pf` holds the first weight quads of this call's stream(s), fetched while the
-// previous LayerNorm ran; on return it holds those of the next call's (Wnext[0 .. nnext)), so the L2
+// previous LayerNorm ran; on return it holds those of the next call's (Wnext[0], Wnext[1]), so the L2
 // latency at the head of a convolution is never exposed.
 // Rows 0..31 of the 36-pixel map are two 16x16x4 tiles per wave (its 16 output channels).  The last four
 // rows would waste 3/4 of a third tile, so they run on v_mfma_f32_4x4x1_16b_f32 instead, on the SAME B
@@ -120,7 +120,7 @@ MZ_DEV void conv_prefetch(const float* __restrict__ Wp, int wlane, f32x4u (&q)[A
 template <int TSEL>
 MZ_DEV constexpr bool tile_on(int mt) { return TSEL == 0 || (TSEL == 1 ? mt == 0 : mt >= 1); }
 template <int NW, int TSEL = 0, int AHEAD = kConvAhead>
-MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const float* const (&Wnext)[2], int nnext,
+MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const float* const (&Wnext)[2],
                           const int (&abase)[3], int wlane, int lane, ConvPrefetch<AHEAD>& pf,
                           f32x4 (&acc)[NW][3]) {
 #pragma unroll
@@ -154,10 +154,11 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
       for (int s = 0; s < NW; ++s)
         wbuf[s][(grp + AHEAD) % (AHEAD + 1)] = (reinterpret_cast<const f32x4u*>(Wp[s]) + wlane)[(grp + AHEAD) * 256];
     } else {
+      // unconditional (the caller passes valid pointers even when fewer streams follow): a load under a
+      // branch makes the compiler's vmcnt bookkeeping conservative for every wait that follows it
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        if (s < nnext)
-          pf.q[s][grp + AHEAD - G] = (reinterpret_cast<const f32x4u*>(Wnext[s]) + wlane)[(grp + AHEAD - G) * 256];
+        pf.q[s][grp + AHEAD - G] = (reinterpret_cast<const f32x4u*>(Wnext[s]) + wlane)[(grp + AHEAD - G) * 256];
     }
     if constexpr (grp + 1 < G) {
 #pragma unroll
@@ -644,8 +645,8 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
     f32x4 pr[2][3];
     {
       const float* const w2[2] = {W, W + CW};
-      const float* const nx[2] = {W + 2 * CW, nullptr};
-      conv3x3_tiles<2, TSEL, AH>(cur, w2, nx, 1, abase, wcol, lane, pf, pr);
+      const float* const nx[2] = {W + 2 * CW, W + 2 * CW};  // one stream follows; the second fetch is a dummy
+      conv3x3_tiles<2, TSEL, AH>(cur, w2, nx, abase, wcol, lane, pf, pr);
       const float* const so[2] = {LN, LN + 2 * kTowerC};
       if constexpr (!PAIR) {
         const bool rl[2] = {false, true};
@@ -683,8 +684,8 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
     f32x4 out[1][3];
     {
       const float* const w1[1] = {W + 2 * CW};
-      const float* const nx[2] = {W + 3 * CW, W + 4 * CW};
-      conv3x3_tiles<1, TSEL, AH>(oth, w1, nx, last ? 0 : 2, abase, wcol, lane, pf, out);
+      const float* const nx[2] = {last ? W : W + 3 * CW, last ? W : W + 4 * CW};  // (last block: dummies)
+      conv3x3_tiles<1, TSEL, AH>(oth, w1, nx, abase, wcol, lane, pf, out);
       const float* const so[1] = {LN + 4 * kTowerC};
       if constexpr (!PAIR) {
         const bool rl[1] = {false};

@@ -32,4 +32,12 @@ for B in [int(x) for x in sys.argv[1:]] or [16, 64, 128]:
         e1.record()
         torch.cuda.synchronize()
         row.append(e0.elapsed_time(e1) / 50 * 1e3)
-    print(f"B={B:4d}: one workgroup per root {row[0]:7.1f} us   pair mode {row[1]:7.1f} us   status {d.pair_status()}", flush=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50):
+            out = d._tower_hip(s, a)  # tower only: no reward / prediction heads
+        e1.record()
+        torch.cuda.synchronize()
+        row.append(e0.elapsed_time(e1) / 50 * 1e3)
+    print(f"B={B:4d}: one workgroup per root {row[0]:7.1f} us (tower only {row[1]:6.1f})   pair mode {row[2]:7.1f} us "
+          f"(tower only {row[3]:6.1f})   status {d.pair_status()}", flush=True)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import muax_amd as muax  # noqa: E402
 from muax_amd import nn  # noqa: E402
-from cartpole_env import CartPole, VectorCartPole  # noqa: E402
+from cartpole_env import VectorCartPole  # noqa: E402
 
 
 def main():
@@ -46,7 +46,7 @@ def main():
             super().append(row)
 
     metrics = Timed()
-    muax.fit_vector(model, VectorCartPole(args.envs, seed=args.seed), CartPole(seed=10_000 + args.seed), n_step=10,
+    muax.fit_vector(model, VectorCartPole(args.envs, seed=args.seed), VectorCartPole(16, seed=10_000 + args.seed), n_step=10,
                     gamma=discount, alpha=0.5, buffer=muax.TrajectoryReplayBuffer(args.buffer),
                     iterations=args.iterations, steps_per_iteration=args.steps, k_steps=10, num_trajectory=32,
                     sample_per_trajectory=1, num_update_per_iteration=args.updates, max_training_steps=total,

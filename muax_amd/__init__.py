@@ -14,7 +14,7 @@ from .nn import MZNetwork, MZNetworkParams, create_muzero_network  # noqa: F401
 from .policy import GumbelMuZeroPolicy, MuZeroPolicy, Policy, StochasticMuZeroPolicy  # noqa: F401
 from .search import MuZeroSearch, PolicyOutput, SearchConfig, SearchTree, key_words  # noqa: F401
 from .sharding import allreduce_mean_flat, gather_roots, shard_roots  # noqa: F401
-from .vector import VectorCollector, episode_trajectory, fit_vector, nstep_returns  # noqa: F401
+from .vector import VectorCollector, episode_trajectory, fit_vector, nstep_returns, test_vector  # noqa: F401
 from .train import _temperature_fn, collect_batched, fit, fit_batched, rollout, rollout_batched, test  # noqa: F401
 
 __version__ = "0.1.0"

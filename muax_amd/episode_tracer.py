@@ -25,8 +25,7 @@ class Transition:
     w: Any = 1.
 
     def __iter__(self):
-        for f in dataclasses.fields(self):
-            yield getattr(self, f.name)
+        return iter((self.obs, self.a, self.r, self.done, self.Rn, self.v, self.pi, self.w))
 
     def __getitem__(self, index):
         return Transition(*(x[index] for x in self))

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import random
 from collections import deque
-from itertools import chain
+from itertools import accumulate, chain
 
 import numpy as np
 
@@ -24,7 +24,7 @@ class Trajectory:
         self.trajectory, self._transition_weight = [], []
         self.transition_class = transition_class
         self._batched_transitions = None
-        self._rows, self._length = None, 0
+        self._rows, self._length, self._cum = None, 0, None
 
     @classmethod
     def from_arrays(cls, obs, a, r, done, Rn, v, pi, w, transition_class=Transition, _checked=False):
@@ -75,16 +75,22 @@ class Trajectory:
             self._materialise()
         return self._batched_transitions
 
-    def sample(self, num_samples: int = 1, k_steps: int = 5):
+    def _sample_cols(self, num_samples, k_steps):
+        """sample() as tuples of arrays [1, k, ...] (no Transition objects).  Same draws as
+        random.choices(range(max_idx), weights=w[:max_idx]): the prefix sums it would build are cached."""
         if len(self) <= k_steps:
             return []
-        if self._rows is not None:
-            self._materialise()
-        max_idx = len(self) - k_steps
-        idxes = random.choices(range(max_idx), weights=self._transition_weight[:max_idx], k=num_samples)
         if self._batched_transitions is None:
             self.finalize()
-        return [self._batched_transitions[:, i:i + k_steps] for i in idxes]
+        max_idx = len(self) - k_steps
+        if self._cum is None or len(self._cum) != len(self._transition_weight):
+            self._cum = list(accumulate(self._transition_weight))
+        idxes = random.choices(range(max_idx), cum_weights=self._cum[:max_idx], k=num_samples)
+        cols = tuple(self._batched_transitions)
+        return [tuple(c[:, i:i + k_steps] for c in cols) for i in idxes]
+
+    def sample(self, num_samples: int = 1, k_steps: int = 5):
+        return [self.transition_class(*cols) for cols in self._sample_cols(num_samples, k_steps)]
 
     def __getitem__(self, index):
         if self._rows is not None:
@@ -115,23 +121,25 @@ class TrajectoryReplayBuffer:
     def add(self, trajectory, w=1.):
         self._storage.append(trajectory)
         self._trajectory_weight.append(w)
+        self._view = None
 
     def sample(self, batch_size=32, num_trajectory: int = None, k_steps: int = 5, sample_per_trajectory: int = 1):
         if batch_size is None and num_trajectory is None:
             raise ValueError("Either num_trajectory or batch_size need to be given.")
         elif batch_size is not None and num_trajectory is None:
             num_trajectory, sample_per_trajectory = batch_size, 1
+        if self._view is None:  # list copy (a deque indexes in O(n)) + the prefix sums random.choices would build
+            self._view = (list(self._storage), list(accumulate(self._trajectory_weight)))
         random.setstate(self._random_state)
-        trajectories = random.choices(self._storage, weights=self._trajectory_weight, k=num_trajectory)
-        batch = list(chain.from_iterable(t.sample(num_samples=sample_per_trajectory, k_steps=k_steps)
-                                         for t in trajectories))
+        trajectories = random.choices(self._view[0], cum_weights=self._view[1], k=num_trajectory)
+        batch = list(chain.from_iterable(t._sample_cols(sample_per_trajectory, k_steps) for t in trajectories))
         self._random_state = random.getstate()
-        cols = list(zip(*(tuple(t) for t in batch)))
-        return self.transition_class(*(np.vstack(c) for c in cols))
+        return self.transition_class(*(np.concatenate(c) for c in zip(*batch)))
 
     def clear(self):
         self._storage = deque([], maxlen=self.capacity)
         self._trajectory_weight = deque([], maxlen=self.capacity)
+        self._view = None
 
     def __len__(self):
         return len(self._storage)

@@ -130,6 +130,25 @@ class VectorCollector:
         return out, key, steps * N
 
 
+def test_vector(model, venv, key, num_simulations: int, max_steps=None):
+    """Greedy evaluation (muax/test.py:5-48: temperature 0, mean undiscounted return) on a vector
+    environment: the FIRST episode of each of its N environments, one batched act() per step."""
+    obs = np.asarray(venv.reset())
+    N = obs.shape[0]
+    G, live = np.zeros(N), np.ones(N, bool)
+    steps = max_steps if max_steps is not None else venv.spec.max_episode_steps
+    for _ in range(steps):
+        key, subkey = prng.split(key)
+        a = model.act(subkey, obs, obs_from_batch=True, num_simulations=num_simulations, temperature=0.)
+        obs, r, done = venv.step(a)
+        obs = np.asarray(obs)
+        G += np.where(live, np.asarray(r, np.float64), 0.0)
+        live &= ~np.asarray(done, bool)
+        if not live.any():
+            break
+    return float(G.mean())
+
+
 def fit_vector(model, venv, test_env, n_step: int = 10, gamma: float = 0.997, alpha=0.5, buffer=None,
                iterations: int = 100, steps_per_iteration: int = 64, num_simulations: int = 50, k_steps: int = 10,
                num_trajectory: int = 32, sample_per_trajectory: int = 1, num_update_per_iteration: int = 50,
@@ -171,8 +190,11 @@ def fit_vector(model, venv, test_env, n_step: int = 10, gamma: float = 0.997, al
             row["loss"] = loss / num_update_per_iteration
         row["training_step"] = training_step
         if it % test_interval == 0:
-            row["test_G"] = test(model, test_env, test_key, num_simulations=num_simulations,
-                                 num_test_episodes=num_test_episodes)
+            if hasattr(test_env, "observation_space"):  # a gym-style environment: the reference's test()
+                row["test_G"] = test(model, test_env, test_key, num_simulations=num_simulations,
+                                     num_test_episodes=num_test_episodes)
+            else:  # a vector environment: all its episodes in lock step
+                row["test_G"] = test_vector(model, test_env, test_key, num_simulations)
         if metrics is not None:
             metrics.append(row)
         if training_step >= max_training_steps:

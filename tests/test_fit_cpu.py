@@ -144,7 +144,7 @@ class _FakeModel:
         a = (obs.sum(1) % 2).astype(np.int64)
         pi = np.stack([0.25 + 0.5 * (a == 0), 0.25 + 0.5 * (a == 1)], 1).astype(np.float32)
         v = obs.sum(1).astype(np.float64) * 0.1
-        return a, pi, v
+        return (a, pi, v) if (with_pi and with_value) else a
 
 
 def test_vector_collector_cuts_the_stream_into_the_same_episodes_as_per_env_tracers():
@@ -165,7 +165,7 @@ def test_vector_collector_cuts_the_stream_into_the_same_episodes_as_per_env_trac
     want = {e: [] for e in range(len(lengths))}
     cur = {e: mx.Trajectory() for e in range(len(lengths))}
     for _ in range(5 + 11 + 8 + 17):
-        a, pi, v = model.act(None, obs)
+        a, pi, v = model.act(None, obs, with_pi=True, with_value=True)
         nxt, r, d = env.step(a)
         for e in range(len(lengths)):
             tracers[e].add(obs[e], int(a[e]), float(r[e]), bool(d[e]), v=float(v[e]), pi=pi[e:e + 1])
@@ -188,3 +188,19 @@ def test_vector_collector_cuts_the_stream_into_the_same_episodes_as_per_env_trac
             assert np.array_equal(bx.obs, by.obs) and np.array_equal(bx.a, by.a) and np.array_equal(bx.done, by.done)
             assert np.array_equal(bx.pi, by.pi) and np.allclose(bx.Rn, by.Rn, rtol=1e-12, atol=0)
             assert np.allclose(bx.w, by.w, rtol=1e-9, atol=1e-12) and np.array_equal(bx.r, by.r)
+
+
+def test_vector_greedy_test_counts_the_first_episode_of_every_environment():
+    import muax_amd as mx
+    env = _ScriptedVecEnv([[3, 7], [12], [1, 2, 30], [9, 4]])
+    env.spec = type("S", (), {"max_episode_steps": 50})()
+    got = mx.test_vector(_FakeModel(), env, mx.prng.PRNGKey(0), num_simulations=4)
+    # replay the first episodes by hand
+    ref_env, model = _ScriptedVecEnv([[3, 7], [12], [1, 2, 30], [9, 4]]), _FakeModel()
+    obs, G, live = ref_env.reset(), np.zeros(4), np.ones(4, bool)
+    for _ in range(12):
+        a = model.act(None, obs)
+        obs, r, d = ref_env.step(a)
+        G += np.where(live, r, 0.0)
+        live &= ~d
+    assert not live.any() and abs(got - G.mean()) < 1e-12

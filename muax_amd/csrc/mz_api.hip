@@ -466,7 +466,8 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
   if (h->use_jump)
     // small batches: 16 levels in flight per root; large ones: one wavefront per root keeps the launch small
   {
-    const dim3 blk(c.batch <= 1024 ? 256 : 64);
+    // few roots and long searches (deep paths): 64 levels in flight
+    const dim3 blk(c.batch <= 256 && c.num_simulations >= 64 ? 1024 : (c.batch <= 1024 ? 256 : 64));
     const size_t lds = sizeof(int32_t) * 15 * ((size_t)c.num_simulations + 2);
     if (c.policy == 1)
       hipLaunchKernelGGL(mz::jump_expand_backup_kernel<true>, dim3(c.batch), blk, lds, stream, sa, h->jump, sim, reward,

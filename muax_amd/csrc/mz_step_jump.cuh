@@ -254,13 +254,13 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
 
 // mctx search.expand + search.backward + refresh of the decisions on the path: one workgroup per root
 template <bool GUMBEL>
-__global__ __launch_bounds__(256) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
+__global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
                                                                   const float* discount, const float* prior_logits,
                                                                   const float* value, const float* next_embedding) {
   extern __shared__ int lds_i[];
   const int r = blockIdx.x;
   const int tid = threadIdx.x, j = tid & 15, row = tid >> 4;
-  const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 256 threads (16 levels in flight) or one wavefront (4)
+  const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 1024 / 256 threads (64 / 16 levels in flight) or one wavefront (4)
   const int N = s.N, A = s.A, E = s.E;
   const size_t rb = (size_t)r * N;
   const int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
@@ -381,15 +381,12 @@ __global__ __launch_bounds__(256) void jump_expand_backup_kernel(StepArgs s, Jum
   __syncthreads();
   // -- JUMP records bottom-up: own end point, the off-path child's record, or the next level's new one --
   if (tid == 0) {
+    int jp = 0, jl = 0;  // the record of level e + 1 rides in registers: no LDS round trip inside the chain
     for (int e = depth; e >= 0; --e) {
-      int jp, jl;
       if (flg[e] || chd[e] < 0) {
         jp = pn[e] | (bst[e] << 16) | (flg[e] ? (int)0x80000000 : 0);
         jl = e;
-      } else if (e < depth && chd[e] == pn[e + 1]) {
-        jp = njp[e + 1];
-        jl = njl[e + 1];
-      } else {
+      } else if (!(e < depth && chd[e] == pn[e + 1])) {
         jp = cjp[e];
         jl = cjl[e];
       }

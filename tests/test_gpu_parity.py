@@ -352,6 +352,16 @@ def test_stepwise_many_simulations_and_wide_actions(oracle):
     _stepwise_vs_oracle(oracle, case2, 300, False, max_depth=7)
 
 
+@pytest.mark.gpu
+def test_stepwise_single_deep_line_beyond_64_levels(oracle):
+    """A search that digs one line 100 levels deep on the step-wise kernels: more levels than the 64 rows a
+    1024-thread expand-backup workgroup has in flight (two rounds of decisions, one long JUMP chain)."""
+    case = make_case(oracle, 46, 7, 4, 8, 2, 120)
+    case["w"]["pp_b2"] = np.array([7.0, -7.0], np.float32)
+    _stepwise_vs_oracle(oracle, case, 120, True)
+    _stepwise_vs_oracle(oracle, case, 120, False)
+
+
 def test_model_act_falls_back_to_stepwise_above_fused_limits():
     """num_simulations = 160 has no fused instance for the default trio: act() must still work (step-wise
     kernels + torch nets) and keep the reference's conventions."""

@@ -437,16 +437,21 @@ int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_em
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
-  if (h->use_jump)
-    hipLaunchKernelGGL(mz::jump_select_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, h->jump, sim,
-                       action_out, parent_embedding_out);
+  bool gathered = false;
+  if (h->use_jump && sa.wide) {  // one workgroup per root: selection + the gather of the wide embedding row
+    hipLaunchKernelGGL(mz::jump_select_kernel<true>, dim3(c.batch), dim3(256), 0, stream, sa, h->jump, sim, action_out,
+                       parent_embedding_out);
+    gathered = true;
+  } else if (h->use_jump)
+    hipLaunchKernelGGL(mz::jump_select_kernel<false>, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa,
+                       h->jump, sim, action_out, parent_embedding_out);
   else if (c.policy == 1)
     hipLaunchKernelGGL(mz::step_select_gumbel_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        action_out, parent_embedding_out);
   else
     hipLaunchKernelGGL(mz::step_select_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        action_out, parent_embedding_out);
-  if (sa.wide) emb_xfer(sa, parent_embedding_out, 0, stream);
+  if (sa.wide && !gathered) emb_xfer(sa, parent_embedding_out, 0, stream);
   MZS_HIP(h, hipGetLastError());
   return MZS_OK;
 }

@@ -167,10 +167,18 @@ __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) 
   }
 }
 
-// mctx search.simulate through the JUMP records
+// mctx search.simulate through the JUMP records.  WIDE: one 256-thread workgroup per root -- every row
+// repeats the (O(1)) selection, so every thread knows the parent and the workgroup gathers its wide
+// embedding row in the same launch (a separate transfer kernel costs its own 4.7 us minimum).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g, int sim, int32_t* action_out,
                                                            float* parent_embedding_out) {
-  MZ_JROW_SETUP
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15;
+  const int r = WIDE ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4));
+  if (r >= s.B) return;
+  const int N = s.N, A = s.A, E = s.E;
+  const size_t rb = (size_t)r * N;
   const uint64_t rg = s.root_offset + (uint64_t)r;
   const int NB = (A + 1) / 2;
   uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 0;
@@ -237,17 +245,18 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
     parent = (int)(ent & 0xffffu);
     action = (int)(ent >> 16);
   }
-  if (j == 0) {
+  if (WIDE ? threadIdx.x == 0 : j == 0) {
     s.sel_parent[r] = parent;
     s.sel_action[r] = action;
     s.sel_depth[r] = depth;
     s.depth_sum[r] += depth;
     action_out[r] = action;
+    if (WIDE) s.xfer_node[r] = parent;
   }
-  if (s.wide) {
-    if (j == 0) s.xfer_node[r] = parent;
+  const float* src = s.embeddings + (rb + parent) * E;
+  if (WIDE) {
+    for (int i = threadIdx.x; i < E; i += 256) parent_embedding_out[(size_t)r * E + i] = src[i];
   } else {
-    const float* src = s.embeddings + (rb + parent) * E;
     for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
   }
 }

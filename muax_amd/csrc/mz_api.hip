@@ -656,6 +656,17 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
   return MZS_OK;
 }
 
+#ifdef MZ_PROFILE
+// profiling builds only (tools/profile_tower.py): read and clear the per-workgroup phase counters
+int mzs_debug_tower_profile(uint64_t* host_out, int32_t words) {
+  static unsigned long long zero[1024 * 16];
+  if (words > 1024 * 16) words = 1024 * 16;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mz::g_tower_prof), sizeof(uint64_t) * (size_t)words) != hipSuccess) return MZS_E_RUNTIME;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mz::g_tower_prof), zero, sizeof(zero)) != hipSuccess) return MZS_E_RUNTIME;
+  return MZS_OK;
+}
+#endif
+
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch) {
   if (batch <= 0 || batch > 128) return 0;  // 2 * batch workgroups have to be resident together
   return (int64_t)batch * (4 * mz::kPairSlot * (int64_t)sizeof(float) + 4 * (int64_t)sizeof(unsigned));

@@ -26,6 +26,19 @@
 
 namespace mz {
 
+// opt-in phase timers of the recurrent kernel (tools/profile_tower.py builds with -DMZ_PROFILE); no code otherwise
+#ifdef MZ_PROFILE
+__device__ unsigned long long g_tower_prof[1024 * 16];
+#define MZ_TT(k)                                              \
+  {                                                           \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    pt[k] += t_ - tlast;                                      \
+    tlast = t_;                                               \
+  }
+#else
+#define MZ_TT(k)
+#endif
+
 struct TowerParams {
   const float* x;          // [B][36][64]  NHWC hidden state s
   const int32_t* action;   // [B] (stem only)
@@ -576,10 +589,16 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
   H.vec = H.part2 + 256;      // [64] hidden vectors
   H.lgt = H.vec + 64;         // [64] logits
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MZ_PROFILE
+  unsigned long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = tlast;
+#endif
   for (int i = tid; i < 2 * kBufWords + kHeadWords; i += 256) lds[i] = 0.0f;
   __syncthreads();
   load_state(p, r, bufA, tid);
   __syncthreads();
+  MZ_TT(0)
 
   PairLink L;
   if constexpr (PAIR) {
@@ -611,6 +630,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
   for (int mt = 0; mt < 3; ++mt) rowc[mt] = abase[mt] + (kHalo + 1) * kPixStride;
   if constexpr (!PAIR)
     if (p.heads) reward_head(p, r, bufA, bufB, H, rowc, ch, tid, lane, wave);
+  MZ_TT(1)
 
   float* cur = bufA;
   float* oth = bufB;
@@ -641,6 +661,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
     __syncthreads();
     float* t = cur; cur = oth; oth = t;
   }
+  MZ_TT(2)
 
   constexpr int AH = kConvAhead;  // (10 groups ahead in pair mode measured the same)
   ConvPrefetch<AH> pf;
@@ -659,6 +680,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
       const float* const w2[2] = {W, W + CW};
       const float* const nx[2] = {W + 2 * CW, W + 2 * CW};  // one stream follows; the second fetch is a dummy
       conv3x3_tiles<2, TSEL, AH>(cur, w2, nx, abase, wcol, lane, pf, pr);
+      MZ_TT(3)
       const float* const so[2] = {LN, LN + 2 * kTowerC};
       if constexpr (!PAIR) {
         const bool rl[2] = {false, true};
@@ -667,6 +689,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         // message A: moments of both maps + the raw boundary pixels of conv_0's map
         float m[2], q[2];
         own_moments<2, TSEL>(pr, m, q, lane, wave, red);
+        MZ_TT(4)
         float* out = pair_out(L);
         if (tid == 0) {
           pair_store(out, m[0]); pair_store(out + 1, q[0]); pair_store(out + 2, m[1]); pair_store(out + 3, q[1]);
@@ -674,7 +697,9 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         }
         put_boundary<TSEL>(pr[1], out + 8, ch, lane);
         pair_post(L, tid);
+        MZ_TT(5)
         const float* in = pair_wait(L, tid);
+        MZ_TT(6)
         float mean[2], rstd[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -693,11 +718,13 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
     }
     store_map<TSEL>(pr[1], oth, ch, lane);
     __syncthreads();
+    MZ_TT(7)
     f32x4 out[1][3];
     {
       const float* const w1[1] = {W + 2 * CW};
       const float* const nx[2] = {last ? W : W + 3 * CW, last ? W : W + 4 * CW};  // (last block: dummies)
       conv3x3_tiles<1, TSEL, AH>(oth, w1, nx, abase, wcol, lane, pf, out);
+      MZ_TT(8)
       const float* const so[1] = {LN + 4 * kTowerC};
       if constexpr (!PAIR) {
         const bool rl[1] = {false};
@@ -706,6 +733,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         // message B: moments + raw boundary pixels of conv_1's map + the normalised shortcut at those pixels
         float m[1], q[1];
         own_moments<1, TSEL>(out, m, q, lane, wave, red);
+        MZ_TT(4)
         float* msg = pair_out(L);
         if (tid == 0) {
           pair_store(msg, m[0]); pair_store(msg + 1, q[0]);
@@ -714,7 +742,9 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         put_boundary<TSEL>(out[0], msg + 8, ch, lane);
         put_boundary<TSEL>(pr[0], msg + 8 + kPairBnd * kTowerC, ch, lane);
         pair_post(L, tid);
+        MZ_TT(5)
         const float* in = pair_wait(L, tid);
+        MZ_TT(6)
         float mean, rstd;
         const float mo = pair_load(in), qo = pair_load(in + 1);
         if (TSEL == 1) merge_moments(m[0], q[0], mo, qo, mean, rstd);
@@ -733,6 +763,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
       for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(pr[0][mt][v] + out[0][mt][v], 0.0f);
     store_map<TSEL>(acc, cur, ch, lane);  // every wave is past its reads of `cur` (the LayerNorm barriers)
     __syncthreads();
+    MZ_TT(9)
   }
   if (p.blocks == 0) {
     // (stem only) bring the map back into registers
@@ -804,6 +835,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         if (tile_on<TSEL>(mt) && px < kTowerPix) yout[px * kTowerC + ch] = acc[mt][v];
       }
   }
+  MZ_TT(10)
   if constexpr (TSEL == 1) {
     if (tid == 0) p.pair_u[(size_t)r * 4 + 2] += 1;  // next launch's epoch: half 1 read it before its first message
   }
@@ -836,6 +868,13 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
       prediction_heads(p, r, cur, H, rowc, tid, lane, wave);
     }
   }
+  MZ_TT(11)
+#ifdef MZ_PROFILE
+  if (tid == 0) {
+    pt[15] = tlast - tstart;
+    for (int k = 0; k < 16; ++k) g_tower_prof[(size_t)blockIdx.x * 16 + k] += pt[k];
+  }
+#endif
 }
 
 __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {

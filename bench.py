@@ -117,8 +117,8 @@ def pmc_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cartpole", choices=sorted(WORKLOADS))
     ap.add_argument("--roots", type=int, default=0, help="roots per GPU (default: the workload's)")
     ap.add_argument("--no-tiebreak", action="store_true", help="drop mctx's threefry tie-break noise (NOT the metric)")

@@ -48,10 +48,24 @@ def _flat_mapping(*args, **kwargs):
     return dict(args[0]) if args and isinstance(args[0], dict) else dict(**kwargs)
 
 
+# the only globals a checkpoint of arrays needs; everything else becomes an inert _Stub (builtins.eval,
+# numpy helpers with side effects, ... never resolve)
+_ALLOWED = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "list"),
+    ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "int"), ("builtins", "float"),
+    ("builtins", "bool"), ("builtins", "complex"), ("builtins", "slice"), ("_codecs", "encode"),
+}
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module.split(".")[0] == "numpy" or module in ("builtins", "collections", "copyreg", "_codecs"):
+        if (module, name) in _ALLOWED:
             return super().find_class(module, name)
+        if module.split(".")[0] == "numpy" and module.endswith("dtypes") and name.endswith("DType"):
+            return super().find_class(module, name)  # numpy >= 1.25 pickles dtypes through numpy.dtypes.*DType
         if name == "_reconstruct_array":
             return _reconstruct_array
         if name == "MZNetworkParams":

@@ -60,7 +60,7 @@ struct mzs_handle {
   mzs_mlp_weights w;
   mz::StepState step;  // device buffers of the step-wise path (lazily allocated)
   uint32_t k_sample[2] = {0, 0};
-  uint32_t sim_keys[mz::kMaxSims][2];
+  std::vector<uint32_t> sim_keys;  // [num_simulations][2], sized at create: simulate_key of every simulation
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
   int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
   float* fused_emb = nullptr;      // fused path, embed_dim > 16: [B][S+1][E] embeddings in HBM
@@ -110,10 +110,10 @@ void derive_keys(mzs_handle* h, const uint32_t key[2]) {
   uint32_t rk[2];
   h_split(key, 3, 0, h->k_sample);
   h_split(key, 3, 2, rk);
-  int S = h->cfg.num_simulations;
-  for (int s = 0; s < S && s < mz::kMaxSims; ++s) {
+  const int S = h->cfg.num_simulations;
+  for (int s = 0; s < S; ++s) {  // every simulation: the step-wise path takes up to 65534 of them
     uint32_t nk[2];
-    h_split(rk, 3, 1, h->sim_keys[s]);
+    h_split(rk, 3, 1, &h->sim_keys[2 * (size_t)s]);
     h_split(rk, 3, 0, nk);
     rk[0] = nk[0];
     rk[1] = nk[1];
@@ -206,6 +206,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     return fail(nullptr, MZS_E_INVALID, "mzs_create: root_offset + batch exceeds global_batch");
   }
   memset(&h->w, 0, sizeof h->w);
+  h->sim_keys.assign(2 * (size_t)cfg->num_simulations, 0u);
   *out = h;
   return MZS_OK;
 }
@@ -301,7 +302,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   }
   derive_keys(h, a->key);
   p.k_sample[0] = h->k_sample[0]; p.k_sample[1] = h->k_sample[1];
-  memcpy(p.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)c.num_simulations);
+  memcpy(p.sim_keys, h->sim_keys.data(), sizeof(uint32_t) * 2 * (size_t)c.num_simulations);  // <= kMaxSims (checked above)
 
   const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, N = c.num_simulations + 1;
 #define MZS_INST(A_, E_, F_, NMAX_, WAVES_) \
@@ -387,7 +388,8 @@ int mzs_root(mzs_handle* h, const float* prior_logits, const float* value, const
   uint32_t zero[2] = {0, 0};
   derive_keys(h, key ? key : zero);
   if (c.tiebreak) {
-    MZS_HIP(h, hipMemcpyAsync(h->step.sim_keys, h->sim_keys, sizeof(uint32_t) * 2 * (size_t)c.num_simulations,
+    // pageable source: the runtime stages it before the call returns, so the next act() may rewrite sim_keys
+    MZS_HIP(h, hipMemcpyAsync(h->step.sim_keys, h->sim_keys.data(), sizeof(uint32_t) * 2 * (size_t)c.num_simulations,
                               hipMemcpyHostToDevice, stream));
   }
   mz::StepArgs sa = h->step.args(c);

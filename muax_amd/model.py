@@ -91,6 +91,7 @@ class MuZero:
         self.capture_graph = bool(capture_graph)
         self._params = None
         self._opt_state = None
+        self._loaded_opt_state = None
         self._fused_train = None
         self._disc_const = None
         self._fused = {}
@@ -289,7 +290,8 @@ class MuZero:
             weights = host[1:1 + A].reshape(1, A).copy()
             root_value = float(host[1 + A])
         elif device_outputs:
-            action, weights = plan_output.action, plan_output.action_weights
+            # the search handle's output buffers are reused by the next act(): hand out copies (stream-ordered, no sync)
+            action, weights, root_value = plan_output.action.clone(), plan_output.action_weights.clone(), root_value.clone()
         else:
             action = plan_output.action.cpu().numpy()
             weights = plan_output.action_weights.cpu().numpy()
@@ -319,7 +321,13 @@ class MuZero:
         if self._optimizer is None:
             self._optimizer = mz_opt.create_optimizer()
         if self._optimizer.opt is None:
+            loaded = self._loaded_opt_state
             self._opt_state = self._optimizer.init(params)
+            if loaded is not None:
+                # a checkpoint was loaded before the optimiser was bound to parameters: resume its moments,
+                # step counts and schedule position (the reference restores opt_state, muax/model.py:210-212)
+                self._optimizer.load_state_dict(loaded)
+                self._loaded_opt_state = None
         fused = backend != "torch" and self.loss_fn is None and self.device.type == "cuda" \
             and mz_nn.is_default_mlp_trio(self.network) and (self.repr_func.obs_dim or 99) <= 16 \
             and not kwargs.get("pi_all_pairs", False)
@@ -343,7 +351,7 @@ class MuZero:
             loss.backward()
             allreduce_mean_flat([p.grad for p in params])
         self._optimizer.step()
-        self._opt_state = self._optimizer.opt.state_dict()
+        self._opt_state = self._optimizer.state_dict()
         self._weights_version += 1
         return {"loss": float(loss.item())}
 
@@ -363,6 +371,11 @@ class MuZero:
             for n, m in mods.items():
                 m.load_state_dict(saved["params"][n])
             self._opt_state = saved.get("optimizer_state")
+            if self._opt_state is not None:
+                if self._optimizer is not None and self._optimizer.opt is not None:
+                    self._optimizer.load_state_dict(self._opt_state)
+                else:
+                    self._loaded_opt_state = self._opt_state  # applied when update() binds the optimiser
             self._weights_version += 1
 
     def save(self, file):

@@ -25,7 +25,27 @@ class Optimizer:
             except (RuntimeError, TypeError, ValueError):
                 pass
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, self._lr_lambda) if self._lr_lambda else None
-        return self.opt.state_dict()
+        return self.state_dict()
+
+    def state_dict(self):
+        """Optimiser moments AND the schedule position (optax keeps both in one opt_state; so does this)."""
+        out = {"opt": self.opt.state_dict()}
+        if self.sched is not None:
+            out["sched"] = {"last_epoch": self.sched.last_epoch, "_step_count": getattr(self.sched, "_step_count", 0)}
+        return out
+
+    def load_state_dict(self, state):
+        """Restore what state_dict() saved (after init()): moments, step counts, learning-rate schedule."""
+        opt_state = state["opt"] if "opt" in state else state  # (older checkpoints stored the bare torch dict)
+        self.opt.load_state_dict(opt_state)
+        sched = state.get("sched") if isinstance(state, dict) else None
+        if self.sched is not None and sched is not None:
+            self.sched.last_epoch = int(sched["last_epoch"])
+            self.sched._step_count = int(sched.get("_step_count", self.sched.last_epoch + 1))
+            lrs = [base * lmbda(self.sched.last_epoch) for base, lmbda in zip(self.sched.base_lrs, self.sched.lr_lambdas)]
+            for group, lr in zip(self.opt.param_groups, lrs):
+                group["lr"] = lr
+            self.sched._last_lr = lrs
 
     def step(self):
         if self.clip:

@@ -83,7 +83,12 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class MuZeroSearch:
-    """One handle = one (device, batch shard, search configuration)."""
+    """One handle = one (device, batch shard, search configuration).
+
+    Output aliasing: `action`, `action_weights`, `root_value`, `search_value`, `depth_sum` (and the tensors of an
+    exported tree) are PERSISTENT buffers of the handle -- act_mlp() / finish() return views of them and the next
+    call on the same handle overwrites them in stream order (select() also stages its actions in `action`).
+    Clone what must outlive the next call (MuZero.act(device_outputs=True) does)."""
 
     def __init__(self, batch: int, cfg: SearchConfig, device=None):
         if not torch.cuda.is_available():

@@ -236,6 +236,32 @@ def test_reference_checkpoint_reader_on_a_synthetic_file_of_the_believed_layout(
         checkpoint.load_reference_params(bad, path)
 
 
+def test_reference_checkpoint_reader_resolves_no_global_outside_its_allow_list(tmp_path):
+    """A crafted .npy must not reach builtins.eval / os.system / numpy helpers through the Unpickler: every
+    global that is not on the allow-list becomes an inert stand-in."""
+    import pickle
+
+    from muax_amd import checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            return (eval, ("__import__('os').environ.__setitem__('MUAX_PWNED', '1')",))
+
+    class Evil2:
+        def __reduce__(self):
+            return (np.load, ("/nonexistent",))
+
+    path = str(tmp_path / "evil.npy")
+    for payload in (Evil(), Evil2()):
+        with open(path, "wb") as f:
+            np.lib.format.write_array_header_1_0(f, {"descr": "|O", "fortran_order": False, "shape": ()})
+            pickle.dump({"params": payload}, f, protocol=2)
+        os.environ.pop("MUAX_PWNED", None)
+        saved = checkpoint.read_reference_checkpoint(path)
+        assert "MUAX_PWNED" not in os.environ
+        assert isinstance(saved["params"], checkpoint._Stub)
+
+
 def test_oracle_reproduces_the_gumbel_golden_fixture(oracle):
     """tests/golden/act_gumbel_cartpole_s32.npz freezes the oracle's Gumbel MuZero act (generator beside it)."""
     import importlib.util

@@ -125,3 +125,38 @@ def test_data_parallel_gradient_mean_equals_full_batch_gradient():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_save_load_restores_the_optimiser_state_and_the_schedule(tmp_path):
+    """muax/model.py:203-212 restores opt_state on load; resumed training must continue the Adam moments, the
+    step counts and the learning-rate schedule -- bit for bit the same trajectory as an uninterrupted run."""
+    b = _batch(B=8, L=3, seed=4)
+
+    def fresh():
+        m = _model(3)
+        m2 = mx.MuZero(m.network, optimizer=mx.optimizers.optimizer(warmup_steps=4, transition_steps=6), device="cpu")
+        m2.init(0, np.zeros((1, 4)))
+        return m2
+
+    ref = fresh()
+    ref_losses = [ref.update(b)["loss"] for _ in range(6)]
+    first = fresh()
+    losses = [first.update(b)["loss"] for _ in range(3)]
+    path = str(tmp_path / "ckpt.pt")
+    first.save(path)
+    resumed = fresh()
+    resumed.load(path)  # before the optimiser is bound to parameters: applied at the first update()
+    losses += [resumed.update(b)["loss"] for _ in range(3)]
+    assert losses == ref_losses
+    state = resumed._optimizer.opt.state_dict()["state"]
+    assert all(int(s["step"]) == 6 for s in state.values())
+    assert resumed._optimizer.sched.last_epoch == 6
+    assert resumed._optimizer.opt.param_groups[0]["lr"] == ref._optimizer.opt.param_groups[0]["lr"]
+    for p, q in zip((p for mod in resumed.network for p in mod.parameters()), (p for mod in ref.network for p in mod.parameters())):
+        assert torch.equal(p, q)
+    # loading into a model whose optimiser is already bound applies the state at once
+    again = fresh()
+    again.update(b)
+    again.load(path)
+    assert all(int(s["step"]) == 3 for s in again._optimizer.opt.state_dict()["state"].values())
+    assert again._optimizer.sched.last_epoch == 3

@@ -81,7 +81,7 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
-constexpr int kHeadWords = 8 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots + scratch of the heads
+constexpr int kHeadWords = 16 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots (4 values x 4 waves) + scratch of the heads
 
 template <int NV>
 MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
@@ -209,42 +209,62 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
       }
   }
 }
+// moments of half 0 (16 x 64 elements) and half 1 (20 x 64) -> mean and 1 / sqrt(var + eps) of the whole map
+MZ_DEV void merge_moments(float m0, float q0, float m1, float q1, float& mean, float& rstd) {
+  constexpr float n0 = 16.0f * kTowerC, n1 = 20.0f * kTowerC, n = n0 + n1;
+  const float d = m1 - m0;
+  mean = m0 + d * (n1 / n);
+  const float M2 = (q0 + q1) + (d * d) * (n0 * n1 / n);
+  rstd = 1.0f / __builtin_sqrtf(M2 * (1.0f / n) + 1e-5f);
+}
+// LayerNorm over the whole map (hk.LayerNorm(axis=(-3,-2,-1)), biased variance, eps 1e-5), one workgroup per
+// root.  The moments are taken EXACTLY as the two workgroups of a root take them in pair mode (below): (mean,
+// M2) of pixels 0..15 and of pixels 16..35 separately -- same per-lane order, same butterfly, same wave order --
+// then Chan's merge (merge_moments).  The two launch shapes therefore give the same bits for every element, and
+// a search does not depend on how many roots share a launch (<= 128: pair mode, above: this one; or how a batch
+// is sharded over GPUs).
 template <int NW>
 MZ_DEV void layer_norm_tiles(f32x4 (&acc)[NW][3], const float* const (&so)[NW], const bool (&relu)[NW], int ch, int lane,
                              int wave, float* red) {
   const int g = lane >> 4;
-  float mean[NW], var[NW];
+  float mh[2 * NW], qh[2 * NW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      mh[2 * s + h] = 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          mh[2 * s + h] = mh[2 * s + h] + (((h == 0 ? mt == 0 : mt >= 1) && 16 * mt + 4 * g + v < kTowerPix) ? acc[s][mt][v] : 0.0f);
+    }
+  wg_sum<2 * NW>(mh, red, wave, lane);
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      mh[2 * s + h] = mh[2 * s + h] * (h == 0 ? 1.0f / (16 * kTowerC) : 1.0f / (20 * kTowerC));
+      qh[2 * s + h] = 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float d = acc[s][mt][v] - mh[2 * s + h];
+          qh[2 * s + h] = qh[2 * s + h] + (((h == 0 ? mt == 0 : mt >= 1) && 16 * mt + 4 * g + v < kTowerPix) ? d * d : 0.0f);
+        }
+    }
+  wg_sum<2 * NW>(qh, red, wave, lane);
 #pragma unroll
   for (int s = 0; s < NW; ++s) {
-    mean[s] = 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) mean[s] = mean[s] + ((16 * mt + 4 * g + v < kTowerPix) ? acc[s][mt][v] : 0.0f);
-  }
-  wg_sum<NW>(mean, red, wave, lane);
-#pragma unroll
-  for (int s = 0; s < NW; ++s) {
-    mean[s] = mean[s] * (1.0f / (kTowerPix * kTowerC));
-    var[s] = 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float d = acc[s][mt][v] - mean[s];
-        var[s] = var[s] + ((16 * mt + 4 * g + v < kTowerPix) ? d * d : 0.0f);
-      }
-  }
-  wg_sum<NW>(var, red, wave, lane);
-#pragma unroll
-  for (int s = 0; s < NW; ++s) {
-    const float rstd = 1.0f / __builtin_sqrtf(var[s] * (1.0f / (kTowerPix * kTowerC)) + 1e-5f);
+    float mean, rstd;
+    merge_moments(mh[2 * s], qh[2 * s], mh[2 * s + 1], qh[2 * s + 1], mean, rstd);
     const float sc = so[s][ch], of = so[s][kTowerC + ch];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const float o = (acc[s][mt][v] - mean[s]) * rstd * sc + of;
+        const float o = (acc[s][mt][v] - mean) * rstd * sc + of;
         acc[s][mt][v] = relu[s] ? fmaxf(o, 0.0f) : o;
       }
   }
@@ -405,14 +425,6 @@ MZ_DEV void own_moments(const f32x4 (&acc)[NW][3], float (&mean)[NW], float (&m2
       }
   }
   wg_sum<NW>(m2, red, wave, lane);
-}
-// moments of half 0 (16 x 64 elements) and half 1 (20 x 64) -> mean and 1 / sqrt(var + eps) of the whole map
-MZ_DEV void merge_moments(float m0, float q0, float m1, float q1, float& mean, float& rstd) {
-  constexpr float n0 = 16.0f * kTowerC, n1 = 20.0f * kTowerC, n = n0 + n1;
-  const float d = m1 - m0;
-  mean = m0 + d * (n1 / n);
-  const float M2 = (q0 + q1) + (d * d) * (n0 * n1 / n);
-  rstd = 1.0f / __builtin_sqrtf(M2 * (1.0f / n) + 1e-5f);
 }
 template <int TSEL>
 MZ_DEV void put_boundary(const f32x4 (&acc)[3], float* dst, int ch, int lane) {
@@ -581,7 +593,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
   float* bufB = lds + kBufWords;
   float* red = lds + 2 * kBufWords;
   HeadLds H;
-  H.hv = red + 8;             // [48][16] value head map (rows >= 36 stay zero)
+  H.hv = red + 16;            // [48][16] value head map (rows >= 36 stay zero)
   H.hv2 = H.hv + 768;         // [48][16]
   H.hp = H.hv2 + 768;         // [48][16] policy head map
   H.part = H.hp + 768;        // [256] partial sums of the flatten -> Linear layers

@@ -177,25 +177,31 @@ class MuZero:
 
     # ------------------------------------------------------------------ act
     def _fused_handle(self, B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak, policy="muzero",
-                      qtransform="qtransform_by_parent_and_siblings", max_considered=16, gumbel_scale=1.0):
+                      qtransform="qtransform_by_parent_and_siblings", max_considered=16, gumbel_scale=1.0,
+                      global_batch=None, root_offset=0):
+        """The MuZeroSearch handle of this act() configuration: created once (mzs_create + its device buffers);
+        a new weights version only re-binds the weight pointers (mzs_mlp_set_weights), it does not re-create the
+        handle -- no allocation on the update()-then-act() cycle of fit()."""
         key = (B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak, policy, qtransform, max_considered,
-               gumbel_scale)
+               gumbel_scale, global_batch, root_offset)
         h = self._fused.get(key)
-        if h is None or h[1] != self._weights_version:
+        if h is None:
             s = MuZeroSearch(B, SearchConfig(A, S, E, max_depth=max_depth, tiebreak=tiebreak,
                                              pb_c_init=pb_c_init, pb_c_base=float(pb_c_base), policy=policy,
                                              qtransform=qtransform, max_num_considered_actions=max_considered,
-                                             gumbel_scale=float(gumbel_scale)), self.device)
+                                             gumbel_scale=float(gumbel_scale), global_batch=global_batch,
+                                             root_offset=root_offset), self.device)
+            h = self._fused[key] = [s, None]
+        if h[1] != self._weights_version:
             w = {k: v.detach() for k, v in mz_nn.mlp_trio_weights(self.network).items()}
-            s.set_mlp_weights(w, obs_dim, self._support_size, self._discount, self._recurrent_pred_on)
-            h = (s, self._weights_version)
-            self._fused[key] = h
+            h[0].set_mlp_weights(w, obs_dim, self._support_size, self._discount, self._recurrent_pred_on)
+            h[1] = self._weights_version
         return h[0]
 
     def _plan(self, params, rng_key, obs, num_simulations=5, temperature=1., invalid_actions=None,
               max_depth=None, loop_fn=None, qtransform=None, dirichlet_fraction=0.25, dirichlet_alpha=0.3,
               pb_c_init=1.25, pb_c_base=19652, dirichlet_noise=None, gumbel=None, tiebreak=True,
-              with_tree=False, max_num_considered_actions=16, gumbel_scale=1.0):
+              with_tree=False, max_num_considered_actions=16, gumbel_scale=1.0, global_batch=None, root_offset=0):
         """muax/model.py:222-243 -> (PolicyOutput, root value)."""
         if self._params is None:
             raise ValueError("call init() first")
@@ -214,31 +220,36 @@ class MuZero:
             try:
                 h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
                                        1.25, 19652, False, "gumbel", qtransform, max_num_considered_actions,
-                                       gumbel_scale)
+                                       gumbel_scale, global_batch, root_offset)
                 out = h.act_mlp(obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree)
                 return out, h.root_value
             except ValueError as e:
                 if "no fused kernel instance" not in str(e):
                     raise
+                self._warn_stepwise(A, self.repr_func.embedding_dim, num_simulations, e)
         if gumbel_policy:
             root = self._root_inference(params, key, obs)
-            out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
-                               invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
-                               max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
-                               gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph,
-                               graph_version=self._weights_version)
+            out = self._checked_search(lambda: self._policy(
+                params, key, root, self._recurrent_inference, num_simulations=num_simulations,
+                invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
+                max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
+                gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version,
+                global_batch=global_batch, root_offset=root_offset))
             return out, root[1]
         if dirichlet_noise is None and dirichlet_fraction:
             k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
             if A is None:
                 with torch.no_grad():
                     A = self.pred_func(self.repr_func(obs[:1]))[1].shape[-1]
-            dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (B, A), self.device)
+            # a shard draws the noise of the WHOLE batch and keeps its rows: results do not depend on the split
+            dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (global_batch or B, A), self.device)
+            if global_batch:
+                dirichlet_noise = dirichlet_noise[root_offset:root_offset + B]
         if fused_ok and type(self._policy) is MuZeroPolicy:
             E = self.repr_func.embedding_dim
             try:
                 h = self._fused_handle(B, A, E, obs.shape[1], num_simulations, max_depth, pb_c_init, pb_c_base,
-                                       tiebreak)
+                                       tiebreak, global_batch=global_batch, root_offset=root_offset)
                 out = h.act_mlp(obs, key, dirichlet_noise=dirichlet_noise, dirichlet_fraction=dirichlet_fraction,
                                 invalid_actions=invalid_actions, temperature=temperature, gumbel=gumbel,
                                 with_tree=with_tree)
@@ -246,20 +257,56 @@ class MuZero:
             except ValueError as e:
                 if "no fused kernel instance" not in str(e):
                     raise
+                self._warn_stepwise(A, E, num_simulations, e)
         root = self._root_inference(params, key, obs)
-        out = self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
-                           temperature=temperature, invalid_actions=invalid_actions, max_depth=max_depth,
-                           dirichlet_fraction=dirichlet_fraction, dirichlet_noise=dirichlet_noise,
-                           pb_c_init=pb_c_init, pb_c_base=pb_c_base, gumbel=gumbel, tiebreak=tiebreak,
-                           with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version)
-        return out, root[1]
+
+        def run():
+            return self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
+                                temperature=temperature, invalid_actions=invalid_actions, max_depth=max_depth,
+                                dirichlet_fraction=dirichlet_fraction, dirichlet_noise=dirichlet_noise,
+                                pb_c_init=pb_c_init, pb_c_base=pb_c_base, gumbel=gumbel, tiebreak=tiebreak,
+                                with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version,
+                                global_batch=global_batch, root_offset=root_offset)
+
+        return self._checked_search(run), root[1]
+
+    _warned_stepwise = set()
+
+    def _warn_stepwise(self, A, E, S, err):
+        """Loud, once per shape: the default MLP trio normally runs as ONE fused launch per act(); a shape without
+        a compiled instance drops to the step-wise kernels + torch modules (tens of launches per simulation)."""
+        key = (A, E, self._support_size, S)
+        if key not in MuZero._warned_stepwise:
+            MuZero._warned_stepwise.add(key)
+            import warnings
+            warnings.warn(f"muax_amd: no fused act() kernel for num_actions={A}, embedding_dim={E}, support_size="
+                          f"{self._support_size}, num_simulations={S} ({err}); falling back to the step-wise search "
+                          f"with torch modules, which is far slower (about 70x at 4096 roots x 50 simulations)",
+                          RuntimeWarning, stacklevel=4)
+
+    def _checked_search(self, run):
+        """Run a step-wise search; if the ResNet recurrent kernel went through pair mode (two workgroups per
+        root meeting in L2, mz_conv.cuh) and any rendezvous was lost -- in ANY launch of the search, graph
+        replays included -- drop pair mode and repeat the search with one workgroup per root.  Both launch
+        shapes produce the same bits, so the repeat is what the undisturbed search would have returned."""
+        out = run()
+        dy = self.dy_func
+        if getattr(dy, "_pair_scratch", None) and dy.pair_lost():
+            import warnings
+            warnings.warn("muax_amd: the pair-mode recurrent kernel lost a rendezvous between the two workgroups of a "
+                          "root; pair mode is disabled for this process and the search was repeated with one "
+                          "workgroup per root", RuntimeWarning)
+            dy.disable_pair_mode()
+            self._weights_version += 1  # captured graphs hold pair-mode launches: re-capture
+            out = run()
+        return out
 
     def act(self, rng_key, obs, with_pi: bool = False, with_value: bool = False, obs_from_batch: bool = False,
             num_simulations: int = 5, temperature: float = 1., invalid_actions=None, max_depth: int = None,
             loop_fn=None, qtransform=None, dirichlet_fraction: float = 0.25, dirichlet_alpha: float = 0.3,
             pb_c_init: float = 1.25, pb_c_base: float = 19652, *, dirichlet_noise=None, gumbel=None,
             tiebreak: bool = True, device_outputs: bool = False, max_num_considered_actions: int = 16,
-            gumbel_scale: float = 1.0):
+            gumbel_scale: float = 1.0, global_batch: Optional[int] = None, root_offset: int = 0):
         r"""Acts given environment observations (muax/model.py:82-179, same arguments and defaults).
 
         Returns `action[, action_weights][, root_value]` in the reference's order.  Unbatched: action is a
@@ -269,7 +316,9 @@ class MuZero:
         `device_outputs=True` (no sync).  `root_value` is the NETWORK value of the root, as the reference.
         Keyword-only extras: exact `dirichlet_noise` / `gumbel` arrays, `tiebreak=False` to drop mctx's
         1e-7 tie-break noise; for the Gumbel policy `max_num_considered_actions` and `gumbel_scale`, which
-        the reference documents (muax/model.py:142-147) but never plumbs through.
+        the reference documents (muax/model.py:142-147) but never plumbs through.  Multi-GPU: a rank that holds
+        rows [root_offset, root_offset + B) of a `global_batch`-root batch passes both, and gets exactly the rows
+        the un-sharded call would have produced (per-root PRNG streams are indexed by the global root).
         """
         obs = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs, dtype=torch.float32)
         if not obs_from_batch:
@@ -280,7 +329,8 @@ class MuZero:
             invalid_actions=invalid_actions, max_depth=max_depth, loop_fn=loop_fn, qtransform=qtransform,
             dirichlet_fraction=dirichlet_fraction, dirichlet_alpha=dirichlet_alpha, pb_c_init=pb_c_init,
             pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak,
-            max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale)
+            max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
+            global_batch=global_batch, root_offset=root_offset)
         if not obs_from_batch:
             # one device-to-host copy instead of three (each costs a synchronisation): action, weights, value
             A = plan_output.action_weights.shape[1]

@@ -472,8 +472,20 @@ class ResNetDynamic(nn.Module):
         return y if outs is None else (outs[0], outs[1], outs[2], y)
 
     def pair_status(self):
-        """Roots whose two workgroups lost each other in any pair-mode launch so far (must be 0)."""
+        """Roots whose two workgroups lost each other in any pair-mode launch so far (must be 0).  Reads device
+        memory: synchronises."""
         return sum(int((t.view(-1)[-4 * k[1]:].view(-1, 4)[:, 3] != 0).sum()) for k, t in self._pair_scratch.items())
+
+    def pair_lost(self) -> bool:
+        """True if any pair-mode launch since the scratch was made lost a rendezvous (bounded spin ran out, or
+        the halves of a root were placed on different XCDs): outputs of that launch are invalid.  MuZero checks
+        this after EVERY search that went through pair mode and, when set, drops pair mode for good and repeats
+        the search with one workgroup per root -- which gives the same bits as an undisturbed pair-mode run."""
+        return bool(self._pair_scratch) and self.pair_status() != 0
+
+    def disable_pair_mode(self):
+        type(self).use_pair_tower = False
+        self._pair_scratch.clear()
 
     def hip_recurrent(self, pred, s, a, support_size: int):
         """The whole recurrent_fn of muax/model.py:265-282 for the ResNet nets in ONE HIP launch: reward head,

@@ -40,10 +40,12 @@ class MuZeroPolicy(Policy):
         emb = embedding.reshape(B, -1)
         S = kwargs.get("num_simulations", 5)
         cfg_key = (A, S, emb.shape[1], kwargs.get("max_depth"), kwargs.get("tiebreak", True),
-                   kwargs.get("pb_c_init", 1.25), kwargs.get("pb_c_base", 19652))
+                   kwargs.get("pb_c_init", 1.25), kwargs.get("pb_c_base", 19652), kwargs.get("global_batch"),
+                   kwargs.get("root_offset", 0))
         cfg = SearchConfig(A, S, emb.shape[1], max_depth=kwargs.get("max_depth"),
                            tiebreak=kwargs.get("tiebreak", True), pb_c_init=kwargs.get("pb_c_init", 1.25),
-                           pb_c_base=float(kwargs.get("pb_c_base", 19652)))
+                           pb_c_base=float(kwargs.get("pb_c_base", 19652)), global_batch=kwargs.get("global_batch"),
+                           root_offset=kwargs.get("root_offset", 0))
         h = self._handle(B, cfg_key, cfg, prior_logits.device)
         shape = tuple(embedding.shape[1:])
 
@@ -83,12 +85,14 @@ class GumbelMuZeroPolicy(Policy):
         qt = kwargs.get("qtransform") or "qtransform_completed_by_mix_value"
         qt = getattr(qt, "__name__", qt)
         key = (B, A, S, emb.shape[1], kwargs.get("max_depth"), qt, kwargs.get("max_num_considered_actions", 16),
-               kwargs.get("gumbel_scale", 1), str(prior_logits.device))
+               kwargs.get("gumbel_scale", 1), str(prior_logits.device), kwargs.get("global_batch"),
+               kwargs.get("root_offset", 0))
         if key not in self._handles:
             cfg = SearchConfig(A, S, emb.shape[1], max_depth=kwargs.get("max_depth"), tiebreak=False,
                                policy="gumbel", qtransform=qt,
                                max_num_considered_actions=kwargs.get("max_num_considered_actions", 16),
-                               gumbel_scale=float(kwargs.get("gumbel_scale", 1)))
+                               gumbel_scale=float(kwargs.get("gumbel_scale", 1)), global_batch=kwargs.get("global_batch"),
+                               root_offset=kwargs.get("root_offset", 0))
             self._handles[key] = MuZeroSearch(B, cfg, prior_logits.device)
         h = self._handles[key]
         shape = tuple(embedding.shape[1:])

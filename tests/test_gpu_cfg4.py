@@ -1,0 +1,254 @@
+"""BASELINE config 4 at its real workload, on the GPU: 84x84x4 frames, the reference's ResNet nets
+(muax/nn.py:313-395), A = 18, E = 6*6*64 = 2304, num_simulations = 200, 128 roots = one GPU's shard of the
+1024-root batch.
+
+* the tree kernels against the oracle fed the very same net outputs (every tree array exact), plus the
+  size-independent structural invariants;
+* launch-shape independence: the recurrent kernel has two launch shapes (<= 128 roots: two workgroups per
+  root, above: one) and both must give the same bits, so that rows 0..127 of a 1024-root act equal the
+  128-root shard's act;
+* accuracy of the fp32-MFMA recurrent kernel against an fp64 evaluation of the same torch modules, next to
+  what MIOpen's fp32 gives on the same inputs;
+* the lost-rendezvous branch of pair mode: status word set -> pair mode dropped, search repeated, same bits.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import muax_amd as mx
+from helpers import assert_trees_equal
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+A, S_FULL, SUPPORT = 18, 200, 10
+
+
+def _nets(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, 2 * SUPPORT + 1, generator=g),
+            mx.nn.ResNetDynamic(A, 2 * SUPPORT + 1, generator=g))
+    m = mx.MuZero(*mods)
+    m.init(0, np.zeros((1, 84, 84, 4), F32))
+    with torch.no_grad():  # biases and LayerNorm parameters away from their init values
+        for mod in mods[1:]:
+            for p in mod.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g).to(p.device))
+    m.weights_changed()
+    return m, mods
+
+
+def _frames(B, seed=1):
+    return np.random.default_rng(seed).integers(0, 256, (B, 84, 84, 4)).astype(F32)
+
+
+@pytest.fixture(autouse=True)
+def _pair_mode_on():
+    mx.nn.ResNetDynamic.use_pair_tower = True
+    yield
+    mx.nn.ResNetDynamic.use_pair_tower = True
+
+
+def test_config4_workload_tree_kernels_against_the_oracle(oracle):
+    """128 roots x 200 simulations x 18 actions x 2304-float embeddings, ResNet nets through the one-launch HIP
+    recurrent_fn (pair mode at this batch).  The oracle's tree is driven with the same net outputs."""
+    B, S = 128, S_FULL
+    m, mods = _nets()
+    obs = torch.from_numpy(_frames(B)).cuda()
+    pl, v, emb = m._root_inference(None, None, obs)
+    E = emb[0].numel()
+    assert E == 2304 and pl.shape == (B, A)
+    rng = np.random.default_rng(3)
+    noise = rng.dirichlet([0.3] * A, B).astype(F32)
+    invalid = (rng.uniform(size=(B, A)) < 0.1).astype(np.uint8)
+    invalid[np.arange(B), rng.integers(0, A, B)] = 0
+    key = [7, 11]
+    s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, E, tiebreak=True))
+    s.root(pl, v, emb.reshape(B, -1), key, torch.from_numpy(invalid), torch.from_numpy(noise), 0.25)
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S, tiebreak=1)
+    oracle.tree_init(tree, oracle.root_prior(pl.cpu().numpy(), noise, 0.25, invalid), v.cpu().numpy(),
+                     emb.reshape(B, -1).cpu().numpy(), invalid)
+    k_sample, _, sims = oracle.sim_keys_from_act_key(key, S)
+    for sim in range(S):
+        action, pemb = s.select(sim)
+        p_ref, a_ref, _ = oracle.step_select(tree, cfg, sim, sims[sim])
+        assert np.array_equal(a_ref, action.cpu().numpy()), sim
+        (r, disc, logits, val), ns = m._recurrent_inference(None, None, action, pemb.reshape(B, 6, 6, 64))
+        outs = (r, disc, logits, val, ns.reshape(B, -1))
+        s.expand_backup(sim, *outs)
+        oracle.step_expand_backup(tree, sim, p_ref, a_ref, *[o.cpu().numpy() for o in outs])
+    out = s.finish(1.0, None, with_tree=True)
+    g = oracle.gumbel(k_sample, B * A).reshape(B, A)
+    a_ref, w_ref = oracle.summary_sample(tree, 1.0, g)
+    assert np.array_equal(a_ref, out.action.cpu().numpy())
+    assert np.array_equal(w_ref, out.action_weights.cpu().numpy())
+    assert_trees_equal(tree, out.search_tree, exact_floats=True)
+    assert mods[2]._pair_scratch and not mods[2].pair_lost()  # the recurrent kernel ran in pair mode, undisturbed
+    # size-independent structure (as test_fused_full_size_properties)
+    t = out.search_tree
+    nv, cv, ci, par, afp = (x.cpu().numpy() for x in
+                            (t.node_visits, t.children_visits, t.children_index, t.parents, t.action_from_parent))
+    assert (nv[:, 0] == S + 1).all() and (cv[:, 0].sum(-1) == S).all()
+    assert (cv.sum(-1) == nv - 1)[nv > 0].all()
+    b, n, a = np.nonzero(ci >= 0)
+    c = ci[b, n, a]
+    assert (par[b, c] == n).all() and (afp[b, c] == a).all() and (cv[b, n, a] == nv[b, c]).all()
+    assert (np.sort(c.reshape(B, S), axis=1) == np.arange(1, S + 1)).all()
+    assert (cv[:, 0][invalid.astype(bool)] == 0).all()  # masked root actions are never visited
+    depth = np.zeros_like(par)
+    for k in range(1, S + 1):
+        depth[:, k] = depth[np.arange(B), par[:, k]] + 1
+    assert np.array_equal(depth.sum(1), s.depth_sum.cpu().numpy())
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.1, 5.0])
+@pytest.mark.parametrize("B", [1, 9, 128])
+def test_recurrent_kernel_launch_shapes_give_the_same_bits(B, scale):
+    """Pair mode (two workgroups per root) == one workgroup per root, bit for bit, on every output -- also on
+    ill-conditioned inputs (a channel that is nearly constant over the map: min_max_normalize2d divides by its
+    range), where round 1's two moment orders differed by up to 8.7e-2."""
+    m, mods = _nets(11 + B)
+    d, pred = mods[2], mods[1]
+    g = torch.Generator().manual_seed(5 + B)
+    s = torch.rand(B, 6, 6, 64, generator=g) * scale
+    s[:, :, :, 3] = 0.25 + 1e-6 * torch.rand(B, 6, 6, generator=g)  # nearly constant channel
+    s = s.cuda()
+    a = torch.randint(0, A, (B,), generator=g).cuda()
+    d.use_pair_tower = False
+    ref = d.hip_recurrent(pred, s, a, SUPPORT)
+    assert not d._pair_scratch
+    d.use_pair_tower = True
+    out = None
+    for _ in range(5):
+        out = d.hip_recurrent(pred, s, a, SUPPORT)
+    torch.cuda.synchronize()
+    assert len(d._pair_scratch) == 1 and d.pair_status() == 0
+    for k, (x, y) in enumerate(zip(ref, out)):
+        assert torch.equal(x, y), (k, float((x - y).abs().max()))
+    # two launches deep (the second one on the first one's next state)
+    d.use_pair_tower = False
+    ref2 = d.hip_recurrent(pred, ref[3], a, SUPPORT)
+    d.use_pair_tower = True
+    out2 = d.hip_recurrent(pred, out[3], a, SUPPORT)
+    for x, y in zip(ref2, out2):
+        assert torch.equal(x, y)
+
+
+def test_rows_of_a_1024_root_act_equal_the_128_root_shard_act():
+    """Sharding invariance of config 4: rows 0..127 and 896..1023 of the 1024-root search (one workgroup per
+    root) against the 128-root shards run with (global_batch=1024, root_offset) (pair mode).  Root inference
+    is evaluated once for the whole batch and sliced (the representation net runs on MIOpen, whose algorithm
+    choice may depend on the batch size; the search kernels are what is under test)."""
+    Bg, Bs, S = 1024, 128, S_FULL
+    m, mods = _nets(2)
+    obs = torch.from_numpy(_frames(Bg, seed=4)).cuda()
+    pl, v, emb = [], [], []
+    for i in range(0, Bg, 128):  # (chunks: activation memory of the 84x84 stages)
+        a_, b_, c_ = m._root_inference(None, None, obs[i:i + 128])
+        pl.append(a_); v.append(b_); emb.append(c_)
+    pl, v, emb = torch.cat(pl), torch.cat(v), torch.cat(emb)
+    noise = torch.from_numpy(np.random.default_rng(5).dirichlet([0.3] * A, Bg).astype(F32)).cuda()
+
+    def rec_of(B):
+        def rec(action, flat):
+            (r, disc, logits, val), ns = m._recurrent_inference(None, None, action, flat.reshape(B, 6, 6, 64))
+            return r, disc, logits, val, ns.reshape(B, -1)
+        return rec
+
+    full = mx.MuZeroSearch(Bg, mx.SearchConfig(A, S, 2304, tiebreak=True))
+    o_full = full.search((pl, v, emb.reshape(Bg, -1)), rec_of(Bg), key=[3, 9], dirichlet_noise=noise, with_tree=True)
+    assert not mods[2]._pair_scratch  # 1024 roots: one workgroup per root
+    ints = ("node_visits", "parents", "action_from_parent", "children_index", "children_visits")
+    for off in (0, Bg - Bs):
+        sl = slice(off, off + Bs)
+        shard = mx.MuZeroSearch(Bs, mx.SearchConfig(A, S, 2304, tiebreak=True, global_batch=Bg, root_offset=off))
+        o = shard.search((pl[sl], v[sl], emb.reshape(Bg, -1)[sl]), rec_of(Bs), key=[3, 9], dirichlet_noise=noise[sl],
+                         with_tree=True)
+        assert mods[2]._pair_scratch and not mods[2].pair_lost()  # 128 roots: pair mode
+        assert torch.equal(o.action, o_full.action[sl]) and torch.equal(o.action_weights, o_full.action_weights[sl])
+        for f in o.search_tree._fields:
+            x, y = getattr(o.search_tree, f), getattr(o_full.search_tree, f)[sl]
+            assert torch.equal(x, y), (off, f, int((x != y).sum()))
+        assert all(getattr(o.search_tree, f).dtype == torch.int32 for f in ints)
+        shard.close()
+
+
+def test_recurrent_kernel_accuracy_against_fp64():
+    """mzs_resnet_tower with heads (both launch shapes) against an fp64 CPU evaluation of the SAME torch
+    modules; MIOpen's fp32 evaluation of them is measured beside it.  A floating-point kernel 24 convolutions
+    and LayerNorms deep: the bar is that the HIP kernel is no farther from fp64 than 1.5 x the fp32 library
+    path (+1e-6), and within 5e-5 of fp64 in absolute terms on next state (in [0, 1]), logits, reward and
+    value (|value| up to a few units): the north star's 1e-5 is the bar BETWEEN implementations of one
+    arithmetic spec (the tree kernels meet it with ==); two correct fp32 evaluations of this tower are
+    themselves ~1e-5 apart."""
+    m, mods = _nets(21)
+    d, pred = mods[2], mods[1]
+    g = torch.Generator().manual_seed(9)
+    B = 24
+    s = torch.rand(B, 6, 6, 64, generator=g)
+    a = torch.randint(0, A, (B,), generator=g)
+    d64, p64 = copy.deepcopy(d).cpu().double(), copy.deepcopy(pred).cpu().double()
+    d64.use_hip_tower = False
+    with torch.no_grad():
+        r_l, ns64 = d64(s.double(), a)
+        v_l, lg64 = p64(ns64)
+        r64 = mx.utils.support_to_scalar(torch.softmax(r_l, -1), SUPPORT).flatten()
+        v64 = mx.utils.support_to_scalar(torch.softmax(v_l, -1), SUPPORT).flatten()
+    ref = (r64, v64, lg64, ns64)
+    sc, ac = s.cuda(), a.cuda()
+    d.use_hip_tower = False
+    (r0, _, lg0, v0), ns0 = m._recurrent_inference(None, None, ac, sc)
+    d.use_hip_tower = True
+    lib = (r0, v0, lg0, ns0)
+    names = ("reward", "value", "prior_logits", "next_state")
+    report = {}
+    for pair in (False, True):
+        d.use_pair_tower = pair
+        hip = d.hip_recurrent(pred, sc, ac, SUPPORT)
+        for n, h, l, x in zip(names, hip, lib, ref):
+            eh = float((h.double().cpu() - x).abs().max())
+            el = float((l.double().cpu() - x).abs().max())
+            report[(n, pair)] = (eh, el)
+            assert eh <= 1.5 * el + 1e-6, (n, pair, eh, el)
+            assert eh <= 5e-5, (n, pair, eh)
+    print("max |x - fp64|  (HIP kernel, MIOpen fp32):", {f"{n}{'/pair' if p else ''}": (f"{a_:.2e}", f"{b_:.2e}")
+                                                       for (n, p), (a_, b_) in report.items()})
+
+
+def test_lost_pair_rendezvous_drops_pair_mode_and_repeats_the_search():
+    """include/mzsearch.h: a root whose two workgroups lost each other sets its status word and the launch's
+    results are invalid.  Force it (status word poisoned: 'once lost, never wait again', so the halves read
+    stale messages) and check MuZero.act(): warns, disables pair mode, repeats the search with one workgroup
+    per root and returns exactly what the undisturbed search returns."""
+    B, S = 16, 12
+    m, mods = _nets(31)
+    d = mods[2]
+    obs = _frames(B, seed=8)
+    kw = dict(with_pi=True, with_value=True, obs_from_batch=True, num_simulations=S)
+    a0, pi0, v0 = m.act(5, obs, **kw)  # pair mode, undisturbed
+    assert len(d._pair_scratch) == 1 and not d.pair_lost()
+    scratch = next(iter(d._pair_scratch.values()))
+    scratch.view(-1)[-4 * B:].view(-1, 4)[3, 3] = 1  # root 3: lost
+    assert d.pair_lost()
+    with pytest.warns(RuntimeWarning, match="lost a rendezvous"):
+        a1, pi1, v1 = m.act(5, obs, **kw)
+    assert mx.nn.ResNetDynamic.use_pair_tower is False and not d._pair_scratch
+    assert np.array_equal(a0, a1) and np.array_equal(pi0, pi1) and np.array_equal(v0, v1)
+    a2, pi2, v2 = m.act(5, obs, **kw)  # later acts stay on one workgroup per root, silently
+    assert np.array_equal(a0, a2) and np.array_equal(pi0, pi2)
+    # the same through a captured graph: the graph held pair-mode launches and must be re-captured
+    mx.nn.ResNetDynamic.use_pair_tower = True
+    mg = mx.MuZero(*mods, capture_graph=True)
+    mg.init(0, obs[:1])
+    mg._params = m._params
+    b0 = mg.act(5, obs, **kw)
+    for scratch in d._pair_scratch.values():
+        scratch.view(-1)[-4 * B:].view(-1, 4)[0, 3] = 2  # XCC mismatch code
+    with pytest.warns(RuntimeWarning, match="lost a rendezvous"):
+        b1 = mg.act(5, obs, **kw)
+    for x, y in zip(b0, b1):
+        assert np.array_equal(x, y)
+    assert np.array_equal(b0[1], pi0)

@@ -34,6 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",
+           "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA accumulators in VGPRs: the recurrent kernel's folds need no accvgpr moves
            "-fPIC", "-shared", "-Wno-unused-value",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -85,7 +85,8 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    # MUAX_AMD_LIB: tools only (A/B builds of the same ABI under tools/bin); the product always loads the in-tree library
+    path = os.environ.get("MUAX_AMD_LIB") or _build.LIB_PATH
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError(f"{path} is missing: build it with `python -m muax_amd._build`")

@@ -106,6 +106,10 @@ MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
 // Weight quads are fetched kConvAhead groups ahead, activation quads one group ahead.
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 constexpr int kConvAhead = 6;
+#ifndef MZ_CONV_FOLD_TAPS
+#define MZ_CONV_FOLD_TAPS 1
+#endif
+constexpr int kConvFoldTaps = MZ_CONV_FOLD_TAPS;  // taps per partial sum: 1 = every tap on its own, 3 = per kernel row, 9 = one chain
 template <int AH>
 struct ConvPrefetch {
   f32x4u q[2][AH];  // weight quads of groups 0 .. AH-1 of the NEXT call's stream(s)
@@ -136,13 +140,20 @@ template <int NW, int TSEL = 0, int AHEAD = kConvAhead>
 MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const float* const (&Wnext)[2],
                           const int (&abase)[3], int wlane, int lane, ConvPrefetch<AHEAD>& pf,
                           f32x4 (&acc)[NW][3]) {
+  // Accuracy: one fp32 accumulator over all K = 576 terms is a 576-long sequential sum.  Every TAP (64 terms)
+  // is accumulated on its own, from zero, and the nine tap sums are added in tap order: tap t runs on `acc`
+  // (even t) or `alt` (odd t), and a set is folded into `tot` when it is needed again two taps later (its MFMAs
+  // have long retired: no accumulator-read stall in the loop).  Against an fp64 evaluation of the whole
+  // recurrent_fn the next state's mean error goes from 1.7 x MIOpen fp32's (one chain) to 0.8 x; the folds cost
+  // 3.5-4.5 % of the launch (profiles/r02_tower_accuracy.txt; MZ_CONV_FOLD_TAPS = 3 / 9 rebuild the other orders).
+  f32x4 alt[NW][3], tot[NW][3];
+  f32x4 rem[NW], ralt[NW], rtot[NW];
 #pragma unroll
-  for (int s = 0; s < NW; ++s)
+  for (int s = 0; s < NW; ++s) {
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) acc[s][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  f32x4 rem[NW];
-#pragma unroll
-  for (int s = 0; s < NW; ++s) rem[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mt = 0; mt < 3; ++mt) acc[s][mt] = alt[s][mt] = tot[s][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    rem[s] = ralt[s] = rtot[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  }
   constexpr int G = 36;
   f32x4u wbuf[NW][AHEAD + 1];
   f32x4u abuf[2][2];
@@ -162,6 +173,7 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
   if constexpr (REM) ra[0] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(0));
   StaticFor<0, G>::run([&](auto gc) {
     constexpr int grp = decltype(gc)::value;
+    constexpr int tap = grp >> 2, seg = tap / kConvFoldTaps, P = seg & 1;
     if constexpr (grp + AHEAD < G) {
 #pragma unroll
       for (int s = 0; s < NW; ++s)
@@ -180,6 +192,24 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
           abuf[(grp + 1) & 1][mt] = *reinterpret_cast<const f32x4u*>(in + abase[mt] + a_off(grp + 1));
       if constexpr (REM) ra[(grp + 1) & 1] = *reinterpret_cast<const f32x4u*>(in + rbase + a_off(grp + 1));
     }
+    if constexpr ((grp & 3) == 0 && tap % kConvFoldTaps == 0 && seg >= 2) {
+      // tap t starts: fold the sum of tap t - 2 (this accumulator set) into the total, restart from zero
+#pragma unroll
+      for (int s = 0; s < NW; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          if (tile_on<TSEL>(mt)) {
+            f32x4& cur = P ? alt[s][mt] : acc[s][mt];
+            tot[s][mt] = seg == 2 ? cur : tot[s][mt] + cur;
+            cur = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+          }
+        if constexpr (REM) {
+          f32x4& cur = P ? ralt[s] : rem[s];
+          rtot[s] = seg == 2 ? cur : rtot[s] + cur;
+          cur = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here: the scheduler otherwise sinks them
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -187,26 +217,39 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
       for (int s = 0; s < NW; ++s) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          if (tile_on<TSEL>(mt))
-            acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], wbuf[s][grp % (AHEAD + 1)][i],
-                                                              acc[s][mt], 0, 0, 0);
-        if constexpr (REM)
-          rem[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], wbuf[s][grp % (AHEAD + 1)][i], rem[s], 0, 0, 0);
+          if (tile_on<TSEL>(mt)) {
+            f32x4& cur = P ? alt[s][mt] : acc[s][mt];
+            cur = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[grp & 1][mt][i], wbuf[s][grp % (AHEAD + 1)][i], cur, 0, 0, 0);
+          }
+        if constexpr (REM) {
+          f32x4& cur = P ? ralt[s] : rem[s];
+          cur = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], wbuf[s][grp % (AHEAD + 1)][i], cur, 0, 0, 0);
+        }
       }
     __builtin_amdgcn_sched_barrier(0);
   });
+  // taps 7 (alt) and 8 (acc) are still in their accumulators: total = ((sum of taps 0..6) + tap 7) + tap 8
+  if constexpr (kConvFoldTaps != 9) {
+#pragma unroll
+    for (int s = 0; s < NW; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        if (tile_on<TSEL>(mt)) acc[s][mt] = (tot[s][mt] + alt[s][mt]) + acc[s][mt];
+  }
   if constexpr (REM) {
     // the four k-quads of a channel: lanes n, n + 16, n + 32, n + 48 -> every lane gets the sum; the lanes
     // g = 0 own pixels 32..35 in the tile layout (acc[.][2][v] <-> pixel 32 + 4 g + v), the others are masked
 #pragma unroll
-    for (int s = 0; s < NW; ++s)
+    for (int s = 0; s < NW; ++s) {
+      const f32x4 rsum = kConvFoldTaps == 9 ? rem[s] : (rtot[s] + ralt[s]) + rem[s];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        float t = rem[s][v];
+        float t = rsum[v];
         t = t + __shfl_xor(t, 16);
         t = t + __shfl_xor(t, 32);
         acc[s][2][v] = t;
       }
+    }
   }
 }
 // moments of half 0 (16 x 64 elements) and half 1 (20 x 64) -> mean and 1 / sqrt(var + eps) of the whole map

@@ -224,7 +224,7 @@ class HkConv2D(nn.Module):
         kernel); rebuilt when the parameter changes, differentiable view while training."""
         if torch.is_grad_enabled() and self.w.requires_grad:
             return self.w.permute(3, 2, 0, 1)
-        sig = (self.w.data_ptr(), self.w._version)
+        sig = (self.w.data_ptr(), self.w._version, self.w.dtype, self.w.device)
         if getattr(self, "_oihw_sig", None) != sig:
             self._oihw_cache = self.w.detach().permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
             self._oihw_sig = sig
@@ -406,7 +406,7 @@ class ResNetDynamic(nn.Module):
 
     def _packed(self):
         ps = [self.ns_stem.w] + [p for b in self.ns_blocks for p in b.parameters()]
-        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        sig = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
         if getattr(self, "_pack_sig", None) != sig:
             with torch.no_grad():
                 # kernel layout of a 3x3 conv: Wp[tap][c][g][co][i] = W[tap][16 c + 4 g + i][co]  (mz_conv.cuh)

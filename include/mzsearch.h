@@ -147,6 +147,16 @@ int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
                float *search_value_out, int32_t *depth_sum_out, void *stream);
 int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
 
+/* ---- root exploration noise ----
+ * rows [root_offset, root_offset + batch) of what mctx.muzero_policy draws for a `global_batch`-root act:
+ *   jax.random.dirichlet(split(rng_key, 3)[1], alpha = full([num_actions], dirichlet_alpha), shape = (global_batch,))
+ * (policy call site muax/policy.py:18-30, defaults muax/model.py:92-93), into out [batch, num_actions] on the
+ * device.  `key` is the DIRICHLET sub-key (host values).  Restated from jax's published sampler on the exact
+ * threefry key walk; float bits are spec-to-confirm against a real jax (oracle/mz_oracle.c): inject an array
+ * through mzs_act_args.dirichlet_noise / mzs_root for bit-pinned noise.  errors: mzs_last_error(NULL) */
+int mzs_dirichlet(int32_t device, const uint32_t key[2], float alpha, int32_t batch, int32_t num_actions,
+                  int64_t global_batch, int64_t root_offset, float *out, void *stream);
+
 /* ---- training step of the default MLP trio ----
  * mzs_mlp_loss_grad replaces jax.value_and_grad(loss_fn) at muax/model.py:245-249 with the default
  * loss (muax/loss.py:10-88): for a batch of k-step trajectories it returns the scalar loss and the

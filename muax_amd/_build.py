@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmzsearch.so")
 SOURCES = ["mz_api.hip"]
-HEADERS = ["mz_spec.cuh", "mz_fused.cuh", "mz_step.cuh", "mz_step_jump.cuh", "mz_train.cuh", "mz_conv.cuh",
+HEADERS = ["mz_spec.cuh", "mz_fused.cuh", "mz_step.cuh", "mz_step_jump.cuh", "mz_train.cuh", "mz_conv.cuh", "mz_dirichlet.cuh",
            os.path.join("..", "..", "include", "mzsearch.h")]
 
 

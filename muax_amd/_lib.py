@@ -75,7 +75,8 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
-                    "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes"]
+                    "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
+                    "mzs_dirichlet"]
 
 _lib = None
 
@@ -113,6 +114,8 @@ def load(build_if_missing: bool = True):
         getattr(L, n).restype = C.c_int
     L.mzs_mlp_num_params.restype = C.c_int64
     L.mzs_mlp_train_workspace_bytes.restype = C.c_int64
+    L.mzs_dirichlet.argtypes = [C.c_int32, C.POINTER(C.c_uint32 * 2), C.c_float, C.c_int32, C.c_int32, C.c_int64,
+                                C.c_int64, _vp, _vp]
     L.mzs_tower_pair_scratch_bytes.argtypes = [C.c_int32]
     L.mzs_tower_pair_scratch_bytes.restype = C.c_int64
     if L.mzs_abi_version() != 1:

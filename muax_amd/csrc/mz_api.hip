@@ -15,6 +15,7 @@
 #include "mz_step_jump.cuh"
 #include "mz_train.cuh"
 #include "mz_conv.cuh"
+#include "mz_dirichlet.cuh"
 
 namespace {
 
@@ -668,6 +669,30 @@ int mzs_debug_tower_profile(uint64_t* host_out, int32_t words) {
   return MZS_OK;
 }
 #endif
+
+// ---------------------------------------------------------------------------
+// root exploration noise
+// ---------------------------------------------------------------------------
+int mzs_dirichlet(int32_t device, const uint32_t key[2], float alpha, int32_t batch, int32_t num_actions,
+                  int64_t global_batch, int64_t root_offset, float* out, void* stream_) {
+  if (!key || !out) return fail(nullptr, MZS_E_INVALID, "mzs_dirichlet: null argument");
+  if (batch <= 0 || num_actions <= 0 || num_actions > 64) return fail(nullptr, MZS_E_INVALID, "mzs_dirichlet: batch / num_actions (1..64)");
+  if (!(alpha > 0.0f)) return fail(nullptr, MZS_E_INVALID, "mzs_dirichlet: alpha must be positive");
+  if (global_batch <= 0) global_batch = batch;
+  if (root_offset < 0 || root_offset + batch > global_batch)
+    return fail(nullptr, MZS_E_INVALID, "mzs_dirichlet: root_offset + batch exceeds global_batch");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MZS_E_NODEVICE, "mzs_dirichlet: no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_dirichlet: bad device ordinal");
+  MZS_HIP(nullptr, hipSetDevice(device));
+  const int R = 256 / num_actions;
+  hipLaunchKernelGGL(mz::dirichlet_kernel, dim3((batch + R - 1) / R), dim3(256), sizeof(float) * (size_t)R * num_actions,
+                     static_cast<hipStream_t>(stream_), key[0], key[1], alpha, batch, num_actions, (uint64_t)global_batch,
+                     (uint64_t)root_offset, out);
+  MZS_HIP(nullptr, hipGetLastError());
+  return MZS_OK;
+}
 
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch) {
   if (batch <= 0 || batch > 128) return 0;  // 2 * batch workgroups have to be resident together

@@ -410,7 +410,13 @@ MZ_DEV float* pair_out(const PairLink& L) { return L.mine + ((L.seq + 1) & 1) * 
 // device-scope atomics for every word (correct, but each message then costs a trip to the memory side:
 // 4 us per message).  Each message carries the sender's XCC id; a half that sees another id than its own
 // reports status 2 -- the L2 rendezvous is only valid inside one XCD.
+#ifdef MZ_PAIR_SC1
+// A/B build: payload stores write-through at agent scope (global_store ... sc1): with the sc0 sc1 loads below this
+// is the guide's placement-independent form R1 (valid across XCDs), at the price of one fabric write per dword
+MZ_DEV void pair_store(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
 MZ_DEV void pair_store(float* q, float v) { *q = v; }
+#endif
 MZ_DEV float pair_load(const float* q) { return *reinterpret_cast<const volatile float*>(q); }
 MZ_DEV void pair_post(PairLink& L, int tid) {  // every thread has stored its part of the message
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

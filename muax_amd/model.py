@@ -27,27 +27,26 @@ from .policy import GumbelMuZeroPolicy, MuZeroPolicy, Policy
 from .search import MuZeroSearch, PolicyOutput, SearchConfig  # noqa: F401  (PolicyOutput: re-exported type)
 
 
-_DEVICE_GENERATORS = {}
-_DEVICE_DRAW_MIN = 1024  # elements; below it the CPU draw (no launches) is quicker
+def _dirichlet(key_words, alpha: float, shape, device, global_batch=None, root_offset=0) -> torch.Tensor:
+    """Root exploration noise of mctx.muzero_policy: rows [root_offset, root_offset + B) of
+    jax.random.dirichlet(dirichlet_key, full([A], alpha), (global_batch,)) -- jax's sampler (loggamma by
+    Marsaglia-Tsang rejection on the threefry key walk, softmax) restated on the device, ONE launch
+    (mzs_dirichlet, muax_amd/csrc/mz_dirichlet.cuh).  The key walk is exact; the float bits are spec-to-confirm
+    against a real jax (oracle/mz_oracle.c), so `dirichlet_noise=` stays the way to inject an exact array."""
+    import ctypes as C
 
-
-def _dirichlet(key_words, alpha: float, shape, device) -> torch.Tensor:
-    """Root exploration noise Dir(alpha) drawn with torch from the dirichlet sub-key.  JAX's gamma
-    sampler is not restated: the draw is deterministic in the key but is NOT
-    bit-identical to jax.random.dirichlet; pass `dirichlet_noise=` to inject an exact array.
-    Large batches are drawn on the GPU (a 4096 x 2 draw costs 0.3 ms on the host, twice the search
-    kernel); small ones on the host, where no launch is needed."""
-    seed = (int(key_words[0]) << 32) | int(key_words[1])
+    from . import _lib
     device = torch.device(device)
-    on_device = device.type == "cuda" and int(np.prod(shape)) >= _DEVICE_DRAW_MIN
-    where = device if on_device else torch.device("cpu")
-    g = _DEVICE_GENERATORS.get(where)
-    if g is None:
-        g = _DEVICE_GENERATORS[where] = torch.Generator(device=where)
-    g.manual_seed(seed)
-    conc = torch.full(shape, float(alpha), dtype=torch.float64, device=where)
-    x = torch._standard_gamma(conc, generator=g).clamp_min(1e-300)
-    return (x / x.sum(dim=-1, keepdim=True)).to(torch.float32).to(device)
+    if device.type != "cuda":
+        raise RuntimeError("muax_amd draws the root noise on the GPU (there is no CPU search path)")
+    B, A = shape
+    out = torch.empty(B, A, dtype=torch.float32, device=device)
+    kw = (C.c_uint32 * 2)(int(key_words[0]) & 0xFFFFFFFF, int(key_words[1]) & 0xFFFFFFFF)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().mzs_dirichlet(device.index or 0, C.byref(kw), float(alpha), B, A, global_batch or B,
+                                             root_offset, out.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    return out
 
 
 class MuZero:
@@ -241,10 +240,8 @@ class MuZero:
             if A is None:
                 with torch.no_grad():
                     A = self.pred_func(self.repr_func(obs[:1]))[1].shape[-1]
-            # a shard draws the noise of the WHOLE batch and keeps its rows: results do not depend on the split
-            dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (global_batch or B, A), self.device)
-            if global_batch:
-                dirichlet_noise = dirichlet_noise[root_offset:root_offset + B]
+            # a shard draws exactly its rows of the whole batch's noise: results do not depend on the split
+            dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (B, A), self.device, global_batch, root_offset)
         if fused_ok and type(self._policy) is MuZeroPolicy:
             E = self.repr_func.embedding_dim
             try:

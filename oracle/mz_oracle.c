@@ -211,6 +211,127 @@ float mzo_gumbel_from_bits(uint32_t bits) {
 }
 
 /* ===================================================================== */
+/* jax.random.dirichlet restated                                          */
+/* ===================================================================== */
+/* mctx.muzero_policy draws its root noise with
+ *   jax.random.dirichlet(dirichlet_rng_key, alpha = full([A], dirichlet_alpha), shape = (B,))
+ * (call site of the policy: muax/policy.py:18-30; defaults muax/model.py:92-93).  Restated from the
+ * PUBLISHED algorithm of jax/_src/random.py (jax 0.4.x): _dirichlet = softmax(loggamma(key, alpha, shape + [A])),
+ * _gamma_impl: one key per element = split(key, B * A)[i], _gamma_one(key, alpha, log_space = True):
+ * Marsaglia-Tsang rejection with per-iteration key splits, alpha < 1 boosted to alpha + 1 and corrected in log
+ * space with log1p(-uniform(subkey)) / alpha; normal = sqrt(2) erf_inv(uniform(lo = nextafter(-1, 0), 1)) with
+ * XLA's single-precision erf_inv (Giles' polynomials).
+ * SPEC-TO-CONFIRM: jax is not installable here, so neither the op order nor the last bits (XLA's own log /
+ * log1p / erf_inv polynomials) can be checked against a real jax; the integer key walk is exact threefry.  The
+ * tested, bit-pinned path for "same noise as the reference" remains act(dirichlet_noise = <array from jax>). */
+float mzo_log1p(float x) { /* x > -1: log(1 + x) with the rounding error of (1 + x) compensated */
+  float u = 1.0f + x;
+  if (u == 1.0f) return x;
+  return mzo_log(u) * (x / (u - 1.0f));
+}
+
+float mzo_erf_inv(float x) { /* |x| < 1; M. Giles, "Approximating the erfinv function", single precision */
+  float w = -mzo_log1p(-(x * x));
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = 3.43273939e-07f + p * w;
+    p = -3.5233877e-06f + p * w;
+    p = -4.39150654e-06f + p * w;
+    p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w;
+    p = -0.00417768164f + p * w;
+    p = 0.246640727f + p * w;
+    p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = 0.000100950558f + p * w;
+    p = 0.00134934322f + p * w;
+    p = -0.00367342844f + p * w;
+    p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w;
+    p = 0.00943887047f + p * w;
+    p = 1.00167406f + p * w;
+    p = 2.83297682f + p * w;
+  }
+  return p * x;
+}
+
+/* jax.random.uniform(key, (), float32, minval, maxval): max(minval, floats * (maxval - minval) + minval) */
+static float jax_uniform(const uint32_t key[2], float minval, float maxval) {
+  float f = mzo_uniform_from_bits(mzo_random_bits(key, 1, 0));
+  float u = f * (maxval - minval) + minval;
+  return u > minval ? u : minval;
+}
+/* jax.random.normal(key, ()) */
+static float jax_normal(const uint32_t key[2]) {
+  const float LO = -0.99999994f; /* nextafter(-1, 0) */
+  return 1.41421354f * mzo_erf_inv(jax_uniform(key, LO, 1.0f));
+}
+
+/* jax _gamma_one(key, alpha, log_space = True): log of a Gamma(alpha, 1) draw */
+float mzo_loggamma_one(const uint32_t key_in[2], float alpha_orig) {
+  const float THIRD = 0.333333343f, SQUEEZE = 0.0331f;
+  const int boost_mask = alpha_orig >= 1.0f;
+  const float alpha = boost_mask ? alpha_orig : alpha_orig + 1.0f;
+  const float d = alpha - THIRD;
+  const float c = THIRD / sqrtf(d);
+  uint32_t key[2], subkey[2];
+  mzo_split(key_in, 2, 0, key);
+  mzo_split(key_in, 2, 1, subkey);
+  float X = 0.0f, V = 1.0f, U = 2.0f;
+  for (int guard = 0; guard < 1000; ++guard) {
+    /* _cond_fn: keep looping while the candidate is REJECTED (the initial state always is) */
+    const float logU = U > 0.0f ? mzo_log(U) : -INFINITY;
+    const int cond = (U >= 1.0f - SQUEEZE * (X * X)) && (logU >= X * 0.5f + d * ((1.0f - V) + mzo_log(V)));
+    if (!cond) break;
+    uint32_t nk[2], x_key[2], u_key[2];
+    mzo_split(key, 3, 0, nk);
+    mzo_split(key, 3, 1, x_key);
+    mzo_split(key, 3, 2, u_key);
+    key[0] = nk[0]; key[1] = nk[1];
+    float x = 0.0f, v = -1.0f;
+    for (int g2 = 0; g2 < 1000 && v <= 0.0f; ++g2) {
+      uint32_t k2[2], sub[2];
+      mzo_split(x_key, 2, 0, k2);
+      mzo_split(x_key, 2, 1, sub);
+      x_key[0] = k2[0]; x_key[1] = k2[1];
+      x = jax_normal(sub);
+      v = 1.0f + x * c;
+    }
+    X = x * x;
+    V = (v * v) * v;
+    U = jax_uniform(u_key, 0.0f, 1.0f);
+  }
+  const float log_samples = mzo_log1p(-jax_uniform(subkey, 0.0f, 1.0f)); /* -exponential(subkey) */
+  const float log_boost = (boost_mask || log_samples == 0.0f) ? 0.0f : log_samples * (1.0f / alpha_orig);
+  return (mzo_log(d) + mzo_log(V)) + log_boost;
+}
+
+/* rows [root_offset, root_offset + B) of jax.random.dirichlet(key, full([A], alpha), (global_batch,)) */
+void mzo_dirichlet(const uint32_t key[2], float alpha, int B, int A, int64_t global_batch,
+                   int64_t root_offset, float *out) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    float lg[256], mx = 0.0f, sum = 0.0f;
+    for (int a = 0; a < A; ++a) {
+      uint32_t ek[2];
+      mzo_split(key, global_batch * A, (root_offset + b) * A + a, ek);
+      lg[a] = mzo_loggamma_one(ek, alpha);
+      mx = (a == 0 || lg[a] > mx) ? lg[a] : mx;
+    }
+    /* jax.nn.softmax: exp(x - max) / sum, summed in action order */
+    for (int a = 0; a < A; ++a) {
+      lg[a] = mzo_exp(lg[a] - mx);
+      sum = a == 0 ? lg[a] : sum + lg[a];
+    }
+    for (int a = 0; a < A; ++a) out[(int64_t)b * A + a] = lg[a] / sum;
+  }
+}
+
+/* ===================================================================== */
 /* Default MLP trio (muax/nn.py:59-115)                                   */
 /* ===================================================================== */
 

@@ -93,6 +93,12 @@ void mzo_split(const uint32_t key[2], int64_t n, int64_t row, uint32_t out[2]);
 uint32_t mzo_random_bits(const uint32_t key[2], int64_t size, int64_t i);
 float mzo_uniform_from_bits(uint32_t bits);
 float mzo_gumbel_from_bits(uint32_t bits);
+/* jax.random.dirichlet restated (spec-to-confirm, see mz_oracle.c) */
+float mzo_log1p(float x);
+float mzo_erf_inv(float x);
+float mzo_loggamma_one(const uint32_t key[2], float alpha);
+void mzo_dirichlet(const uint32_t key[2], float alpha, int B, int A, int64_t global_batch,
+                   int64_t root_offset, float *out);
 
 /* ---- nets ---- */
 void mzo_root_inference(const mzo_mlp *m, const float *obs, float *embedding,

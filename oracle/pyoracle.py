@@ -98,6 +98,14 @@ def lib():
         L.mzo_uniform_from_bits.argtypes = [C.c_uint32]
         L.mzo_gumbel_from_bits.restype = C.c_float
         L.mzo_gumbel_from_bits.argtypes = [C.c_uint32]
+        L.mzo_log1p.restype = C.c_float
+        L.mzo_log1p.argtypes = [C.c_float]
+        L.mzo_erf_inv.restype = C.c_float
+        L.mzo_erf_inv.argtypes = [C.c_float]
+        L.mzo_loggamma_one.restype = C.c_float
+        L.mzo_loggamma_one.argtypes = [_u32p, C.c_float]
+        L.mzo_dirichlet.restype = None
+        L.mzo_dirichlet.argtypes = [_u32p, C.c_float, C.c_int, C.c_int, C.c_int64, C.c_int64, _f32p]
         L.mzo_random_bits.restype = C.c_uint32
         L.mzo_random_bits.argtypes = [_u32p, C.c_int64, C.c_int64]
         L.mzo_select_action.restype = C.c_int
@@ -195,6 +203,15 @@ def uniform(key, size):
 def gumbel(key, size):
     return np.array([lib().mzo_gumbel_from_bits(int(b)) for b in random_bits(key, size)],
                     np.float32)
+
+
+def dirichlet(key, alpha, B, A, global_batch=None, root_offset=0):
+    """Rows [root_offset, root_offset + B) of jax.random.dirichlet(key, full([A], alpha), (global_batch,))
+    as restated in mz_oracle.c (spec-to-confirm)."""
+    k = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros((B, A), np.float32)
+    lib().mzo_dirichlet(_p(k, _u32p), C.c_float(alpha), B, A, global_batch or B, root_offset, _p(out, _f32p))
+    return out
 
 
 # --------------------------------------------------------------------------

@@ -84,10 +84,22 @@ def test_act_return_conventions():
     assert abs(pi5[0, 0] * 5 - round(pi5[0, 0] * 5)) < 1e-5
 
 
-def test_large_batches_draw_their_root_noise_on_the_device_deterministically():
-    """B*A >= 1024: the Dirichlet root noise is drawn on the GPU from the dirichlet sub-key; the same key
-    must give the same act() and another key another one; the noise mixes into every root's prior."""
+def test_root_noise_is_jax_dirichlet_restated_on_the_device(oracle):
+    """Default act(key): the Dirichlet root noise is jax.random.dirichlet's sampler restated on the device
+    (mzs_dirichlet) from the dirichlet sub-key: bit-equal to the oracle's restatement (rejection loops on the
+    threefry key walk included), for any batch size, action count and shard; statistics of Dir(0.3)."""
     from muax_amd.model import _dirichlet
+    for B, A, key, alpha in ((1, 2, (0, 42), 0.3), (33, 2, (5, 6), 0.3), (2048, 2, (3, 4), 0.3), (300, 18, (9, 9), 0.3),
+                             (64, 4, (1, 1), 1.5), (1000, 64, (2, 7), 0.03)):
+        d = _dirichlet(key, alpha, (B, A), "cuda")
+        ref = oracle.dirichlet(key, alpha, B, A)
+        assert d.is_cuda and d.dtype == torch.float32 and np.array_equal(ref, d.cpu().numpy()), (B, A)
+        assert torch.allclose(d.sum(1), torch.ones(B, device="cuda"), atol=1e-6) and float(d.min()) >= 0.0
+    full = _dirichlet((3, 4), 0.3, (2048, 2), "cuda")
+    part = _dirichlet((3, 4), 0.3, (100, 2), "cuda", global_batch=2048, root_offset=700)
+    assert torch.equal(part, full[700:800])
+    # Dir(0.3, 0.3): symmetric, mass near the corners -- mean 1/2, variance 1/(4 (2 alpha + 1)) = 0.15625
+    assert abs(float(full[:, 0].mean()) - 0.5) < 0.03 and abs(float(full[:, 0].var()) - 0.15625) < 0.02
     m = _model()
     batch = np.random.default_rng(4).uniform(-1, 1, (2048, 4)).astype(F32)
     a1, p1, v1 = m.act(7, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=20)
@@ -95,11 +107,70 @@ def test_large_batches_draw_their_root_noise_on_the_device_deterministically():
     a3, p3, _ = m.act(8, batch, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=20)
     assert np.array_equal(a1, a2) and np.array_equal(p1, p2) and np.array_equal(v1, v2)
     assert not np.array_equal(p1, p3)
-    d = _dirichlet((3, 4), 0.3, (2048, 2), "cuda")
-    assert d.is_cuda and d.dtype == torch.float32 and torch.allclose(d.sum(1), torch.ones(2048, device="cuda"), atol=1e-6)
-    assert torch.equal(d, _dirichlet((3, 4), 0.3, (2048, 2), "cuda")) and float(d.min()) >= 0.0
-    # Dir(0.3, 0.3): symmetric, mass near the corners -- mean 1/2, variance 1/(4 (2 alpha + 1)) = 0.15625
-    assert abs(float(d[:, 0].mean()) - 0.5) < 0.03 and abs(float(d[:, 0].var()) - 0.15625) < 0.02
+
+
+def _model_with(w, E, A, obs_dim, **kw):
+    """A MuZero on the default MLP trio carrying the oracle-side weight dict `w` (haiku layouts)."""
+    m = _model(E, A, obs_dim, **kw)
+    with torch.no_grad():
+        for k, p in mx.nn.mlp_trio_weights(m.network).items():
+            p.copy_(torch.from_numpy(w[k]))
+    m.weights_changed()
+    return m
+
+
+@pytest.mark.parametrize("B,A,E,obs_dim,S", [(1, 2, 8, 4, 10), (33, 2, 8, 4, 50), (33, 4, 32, 8, 20)])
+def test_muzero_act_equals_the_oracle_for_the_same_key(oracle, B, A, E, obs_dim, S):
+    """MuZero.act() itself (muax/model.py:82-179), default arguments: Dirichlet root noise from split(key, 3)[1],
+    tie-break noise and the categorical's Gumbel from the key -- against the oracle driven with the same key.
+    Batched, unbatched (python int / [1, A] / python float) and with an injected noise array."""
+    w = oracle.random_mlp_weights(40 + B + A, obs_dim, E, A, 21, bias_scale=0.1)
+    m = _model_with(w, E, A, obs_dim)
+    rng = np.random.default_rng(B)
+    obs = rng.uniform(-1, 1, (B, obs_dim)).astype(F32)
+    mlp, cfg = oracle.Mlp(w, obs_dim, E, A, 21), oracle.SearchCfg(S, tiebreak=1)
+    key = mx.prng.PRNGKey(1234 + B)
+    noise = oracle.dirichlet(oracle.split(key, 3)[1], 0.3, B, A)
+    ref = oracle.act_mlp(mlp, cfg, obs, key, noise, 0.25, None, 1.0, None)
+    a, pi, v = m.act(key, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=S)
+    assert a.dtype == np.int32 and np.array_equal(a, ref["action"]) and np.array_equal(pi, ref["action_weights"])
+    assert np.array_equal(v, ref["root_value"])
+    # an injected noise array replaces the draw; temperature and the other act() keywords reach the search
+    inj = rng.dirichlet([0.3] * A, B).astype(F32)
+    ref2 = oracle.act_mlp(mlp, cfg, obs, key, inj, 0.25, None, 0.5, None)
+    a2, pi2 = m.act(key, obs, with_pi=True, obs_from_batch=True, num_simulations=S, temperature=0.5, dirichlet_noise=inj)
+    assert np.array_equal(a2, ref2["action"]) and np.array_equal(pi2, ref2["action_weights"])
+    # unbatched call on the first observation: the batch of one has its own PRNG layout (global batch 1)
+    n1 = oracle.dirichlet(oracle.split(key, 3)[1], 0.3, 1, A)
+    ref1 = oracle.act_mlp(mlp, cfg, obs[:1], key, n1, 0.25, None, 1.0, None)
+    a1, pi1, v1 = m.act(key, obs[0], with_pi=True, with_value=True, num_simulations=S)
+    assert isinstance(a1, int) and isinstance(v1, float) and pi1.shape == (1, A)
+    assert a1 == int(ref1["action"][0]) and np.array_equal(pi1, ref1["action_weights"]) and F32(v1) == ref1["root_value"][0]
+
+
+def test_rollout_reproduces_the_fit_loop_trace_fixture():
+    """muax_amd.rollout() -- the inner loop of muax.fit (muax/train.py:153-170: one key split
+    and one unbatched act() per environment step) -- against the committed oracle trace of 20 CartPole steps at
+    num_simulations=10, batch 1 (tests/golden/rollout_cartpole_s10.npz, generator beside it): every sub-key,
+    observation, action, policy target and value."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from cartpole_env import CartPole
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rollout_cartpole_s10.npz"))
+    seed, env_seed, S, steps, obs_dim, E, A = (int(x) for x in g["meta"])
+    m = _model_with({k[2:]: g[k] for k in g.files if k.startswith("w_")}, E, A, obs_dim)
+    traj, key = mx.rollout(m, CartPole(seed=env_seed), g["key"], num_simulations=S, temperature=1.0, max_steps=steps)
+    assert len(traj) == steps
+    for t, (obs, a, r, done, v, pi) in enumerate(traj):
+        assert np.array_equal(obs, g["obs"][t]) and a == int(g["a"][t]), t
+        assert pi.shape == (1, A) and np.array_equal(pi, g["pi"][t]) and F32(v) == g["v"][t], t
+    k = g["key"]
+    for _ in range(steps):
+        k, _sub = mx.prng.split(k)
+    assert np.array_equal(np.asarray(key, np.uint32), np.asarray(k, np.uint32))  # the advanced key
+    # greedy evaluation (muax/test.py:25-41): temperature 0 picks the most visited action of the same search
+    a0, pi0 = m.act(g["subkey"][0], g["obs"][0], with_pi=True, num_simulations=S, temperature=0.)
+    assert np.array_equal(pi0, g["pi"][0]) and a0 == int(np.argmax(pi0[0]))
 
 
 def test_act_greedy_and_invalid_actions():

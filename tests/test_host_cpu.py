@@ -276,3 +276,27 @@ def test_oracle_reproduces_the_gumbel_golden_fixture(oracle):
     for k, a in out["tree"].arrays().items():
         assert np.array_equal(a, g["tree_" + k]), k
     assert (g["tree_children_visits"][:, 0].sum(-1) == S).all()
+
+
+def test_oracle_reproduces_the_fit_loop_trace_fixture(oracle):
+    """tests/golden/rollout_cartpole_s10.npz (SURVEY.md 8 row a10's pin): 20 CartPole steps of the reference's
+    fit() inner loop at num_simulations=10, batch 1, frozen from the oracle with its generator beside it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_rollout_trace",
+                                                  os.path.join(ROOT, "tests", "golden", "make_rollout_trace.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rollout_cartpole_s10.npz"))
+    seed, env_seed, S, steps = (int(x) for x in g["meta"][:4])
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w_")}
+    rows = mt.oracle_rollout(w, g["key"], mt.CartPole(seed=env_seed), steps, S)
+    assert len(rows) == steps == 20 and S == 10
+    for f in ("subkey", "obs", "noise", "a", "pi", "v"):
+        assert np.array_equal(np.stack([np.asarray(r[f]) for r in rows]), g[f]), f
+    # the sub-keys are the reference loop's `key, subkey = jax.random.split(key)` chain (muax/train.py:154)
+    from muax_amd import prng
+    key = g["key"]
+    for t in range(steps):
+        key, subkey = prng.split(key)
+        assert np.array_equal(np.asarray(subkey, np.uint32), g["subkey"][t])
+    assert g["pi"].shape == (20, 1, 2) and np.allclose(g["pi"].sum(-1), 1)  # pi keeps its leading 1 (muax/model.py:176)

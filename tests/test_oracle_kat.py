@@ -295,3 +295,33 @@ def test_markstein_small_integer_division_equals_true_division():
     from oracle import pyoracle as po
     assert po.markstein_mismatches(300, 0) == 0
     assert po.markstein_mismatches(64, -40) == 0
+
+
+FROZEN_DIRICHLET = [[1061768092, 1046139280], [1026641503, 1064626970], [1065042773, 1016567145]]
+
+
+def test_dirichlet_restatement_statistics_shards_and_frozen_vector(oracle):
+    """oracle/mz_oracle.c restates jax.random.dirichlet (loggamma by Marsaglia-Tsang rejection on the threefry key
+    walk, log-space boost for alpha < 1, softmax).  No jax here to pin the float bits (spec-to-confirm): what CAN be
+    pinned is the distribution (moments of Dir(alpha) and of Gamma(alpha)), the building blocks against scipy, the
+    shard contract, and -- against accidental change -- one frozen vector of this restatement."""
+    import math
+
+    from scipy.special import erfinv
+    L = oracle.lib()
+    xs = np.linspace(-0.9999, 0.9999, 1001)
+    assert max(abs(L.mzo_erf_inv(float(x)) - erfinv(float(np.float32(x)))) / max(1e-3, abs(erfinv(float(x)))) for x in xs) < 1e-5
+    us = np.random.default_rng(0).uniform(1e-7, 0.999, 500).astype(np.float32)
+    assert max(abs(L.mzo_log1p(-float(u)) - math.log1p(-float(u))) / abs(math.log1p(-float(u))) for u in us) < 3e-7
+    d = oracle.dirichlet([0, 42], 0.3, 20000, 2)
+    assert np.allclose(d.sum(1), 1, atol=1e-6) and d.min() >= 0
+    assert abs(d[:, 0].mean() - 0.5) < 0.01 and abs(d[:, 0].var() - 0.25 / 1.6) < 0.005
+    d18 = oracle.dirichlet([1, 2], 0.3, 4000, 18)
+    assert abs(d18.mean() - 1 / 18) < 1e-6 and abs(d18.var(0).mean() - (1 / 18) * (17 / 18) / (18 * 0.3 + 1)) < 5e-4
+    assert np.array_equal(oracle.dirichlet([1, 2], 0.3, 100, 18, global_batch=4000, root_offset=700), d18[700:800])
+    for alpha in (0.3, 1.0, 2.5):  # Gamma(alpha): mean = var = alpha
+        keys = oracle.split([3, 4], 4000)
+        g = np.exp([L.mzo_loggamma_one(oracle._p(np.ascontiguousarray(k, np.uint32), oracle._u32p), alpha) for k in keys])
+        assert abs(g.mean() - alpha) < 0.06 * max(1, alpha) and abs(g.var() - alpha) < 0.2 * max(1, alpha), alpha
+    frozen = oracle.dirichlet([0, 42], 0.3, 3, 2)
+    assert np.array_equal(frozen.view(np.uint32), np.array(FROZEN_DIRICHLET, np.uint32)), frozen.view(np.uint32).tolist()

@@ -114,6 +114,102 @@ def pmc_traffic(workload):
         return None
 
 
+def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl"):
+    """`steps` timed launches of the fused act() kernel on this rank's B roots of the global batch (inputs resident
+    in HBM, launches back to back, one synchronisation at the end; barrier + max over ranks for N > 1)."""
+    from muax_amd import MuZeroSearch, SearchConfig
+    _, obs_dim, E, A, support, S = WORKLOADS[workload]
+    F = 2 * support + 1
+    weights = haiku_style_weights(0, obs_dim, E, A, F)
+    g = torch.Generator().manual_seed(1000 + rank)
+    obs = torch.rand(B, obs_dim, generator=g) * 2 - 1
+    noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)) if A > 1 else torch.ones(B, 1)
+    search = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=tiebreak, global_batch=B * world, root_offset=B * rank), dev)
+    search.set_mlp_weights(weights, obs_dim, support, 0.99)
+    d_obs, d_noise = obs.to(dev), noise.to(dev)
+
+    def step(i):
+        search.act_mlp(d_obs, (0, i), dirichlet_noise=d_noise, dirichlet_fraction=0.25, temperature=1.0)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    # HIP events bracket a SAMPLE of the launches (every 10th step of the timed region): an event pair costs
+    # ~6 us of stream time, 5 % of a 134 us kernel, so bracketing every launch would slow the very loop
+    # that is being timed; unbracketed launches run back to back
+    ev_every = 10 if steps >= 20 else 1
+    sampled = [i for i in range(steps) if i % ev_every == ev_every // 2]
+    for i in range(steps):
+        if i % ev_every == ev_every // 2:
+            evs[i][0].record()
+        step(warmup + i)
+        if i % ev_every == ev_every // 2:
+            evs[i][1].record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in sampled]))
+    depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
+    actions = search.action.cpu()
+    assert int(actions.min()) >= 0 and int(actions.max()) < A
+    search.close()
+    return {"elapsed": elapsed, "kernel_ms": kernel_ms, "depth_total": depth_total, "weights": weights, "obs": obs,
+            "noise": noise}
+
+
+def roofline(workload, B, kernel_ms, depth_total):
+    _, obs_dim, E, A, support, S = WORKLOADS[workload]
+    abytes = algorithmic_bytes(depth_total, B, S, A, E, obs_dim)
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(workload),
+            "kernel": "mz_act_fused_kernel", "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes_per_launch": int(abytes), "mean_selection_depth": round(depth_total / (B * S), 3)}
+
+
+def api_numbers(workload, B, weights, obs, dev, acts=100):
+    """What a caller of the reference's own entry point gets: MuZero.act(rng_key, obs, obs_from_batch=True,
+    num_simulations=50) with default arguments -- Dirichlet root noise drawn from the key on the device, tie-break
+    noise, sampling -- (a) NumPy in / NumPy out: upload, draw, search, ONE download and the host synchronisation of
+    every act (the next act of an RL loop needs this act's actions), (b) device tensors in / out
+    (device_outputs=True): no synchronisation inside act(), acts pipeline on the stream."""
+    import muax_amd as mx
+    _, obs_dim, E, A, support, S = WORKLOADS[workload]
+    net = mx.nn.MZNetwork(mx.nn.Representation(E), mx.nn.Prediction(A, 2 * support + 1), mx.nn.Dynamic(E, A, 2 * support + 1))
+    m = mx.MuZero(net, support_size=support, device=dev)
+    m.init(0, np.zeros((1, obs_dim), np.float32))
+    with torch.no_grad():
+        for k, p in mx.nn.mlp_trio_weights(m.network).items():
+            p.copy_(weights[k].to(dev))
+    m.weights_changed()
+    obs_np, obs_dev = obs.numpy(), obs.to(dev)
+    out = {}
+    for label, kw, x in (("numpy", {}, obs_np), ("device", {"device_outputs": True}, obs_dev)):
+        for i in range(10):
+            m.act(i, x, obs_from_batch=True, num_simulations=S, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(acts):
+            a = m.act(1000 + i, x, obs_from_batch=True, num_simulations=S, **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / acts
+        out[label] = {"value": round(B / dt, 1), "ms_per_act": round(dt * 1e3, 4)}
+    out["unit"] = "env-steps/s"
+    out["call"] = f"MuZero.act(key, obs[{B},{obs_dim}], obs_from_batch=True, num_simulations={S}), defaults otherwise; {acts} acts"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +219,7 @@ def main():
     ap.add_argument("--roots", type=int, default=0, help="roots per GPU (default: the workload's)")
     ap.add_argument("--no-tiebreak", action="store_true", help="drop mctx's threefry tie-break noise (NOT the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the api / config-3 sub-objects of the JSON line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,62 +240,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from muax_amd import MuZeroSearch, SearchConfig
     B, obs_dim, E, A, support, S = WORKLOADS[args.workload]
     if args.roots:
         B = args.roots
     F = 2 * support + 1
-    weights = haiku_style_weights(0, obs_dim, E, A, F)
-    g = torch.Generator().manual_seed(1000 + rank)
-    obs = torch.rand(B, obs_dim, generator=g) * 2 - 1
-    noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)) if A > 1 else torch.ones(B, 1)
     dev = torch.device("cuda", local_rank)
-    search = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=not args.no_tiebreak,
-                                          global_batch=B * world, root_offset=B * rank), dev)
-    search.set_mlp_weights(weights, obs_dim, support, 0.99)
-    d_obs, d_noise = obs.to(dev), noise.to(dev)
-
-    def step(i):
-        search.act_mlp(d_obs, (0, i), dirichlet_noise=d_noise, dirichlet_fraction=0.25, temperature=1.0)
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
-    depth_total = 0
-    t0 = time.perf_counter()
-    # HIP events bracket a SAMPLE of the launches (every 10th step of the timed region): an event pair costs
-    # ~6 us of stream time, 5 % of a 134 us kernel, so bracketing every launch would slow the very loop
-    # that is being timed; unbracketed launches run back to back
-    ev_every = 10 if args.steps >= 20 else 1
-    sampled = [i for i in range(args.steps) if i % ev_every == ev_every // 2]
-    for i in range(args.steps):
-        if i % ev_every == ev_every // 2:
-            evs[i][0].record()
-        step(args.warmup + i)
-        if i % ev_every == ev_every // 2:
-            evs[i][1].record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in sampled]))
-    depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
-    actions = search.action.cpu()
-    assert int(actions.min()) >= 0 and int(actions.max()) < A
+    run = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend)
+    elapsed, kernel_ms, depth_total, weights, obs, noise = (run[k] for k in ("elapsed", "kernel_ms", "depth_total",
+                                                                               "weights", "obs", "noise"))
 
     if rank == 0:
-        abytes = algorithmic_bytes(depth_total, B, S, A, E, obs_dim)
-        achieved = abytes / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "batched act() env-steps/sec at num_simulations=50",
             "value": round(B * world * args.steps / elapsed, 1),
@@ -211,12 +262,21 @@ def main():
                                    f"support {support}, num_simulations={S}, dirichlet 0.25/0.3, "
                                    f"tiebreak={'threefry' if not args.no_tiebreak else 'off'}, temperature 1",
                        "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(args.workload),
-                         "kernel": "mz_act_fused_kernel", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": int(abytes),
-                         "mean_selection_depth": round(depth_total / (B * S), 3)},
+            "roofline": roofline(args.workload, B, kernel_ms, depth_total),
         }
+        if world == 1 and not args.no_extras:
+            # the reference's own entry point on the same workload, and BASELINE configs[2] (the other fused instance)
+            line["api"] = api_numbers(args.workload, B, weights, obs, dev)
+            if args.workload == "cartpole" and not args.roots:
+                B3 = WORKLOADS["lunarlander"][0]
+                r3 = fused_run("lunarlander", B3, 0, 1, dev, max(20, args.steps // 4), max(5, args.warmup // 2),
+                               not args.no_tiebreak)
+                steps3 = max(20, args.steps // 4)
+                line["config3_lunarlander"] = {
+                    "value": round(B3 * steps3 / r3["elapsed"], 1), "unit": "env-steps/s", "steps": steps3,
+                    "ms_per_step": round(r3["elapsed"] / steps3 * 1e3, 4),
+                    "workload": f"lunarlander: {B3} roots, obs 8, MLP embed 32, A=4, support 10, num_simulations=50",
+                    "roofline": roofline("lunarlander", B3, r3["kernel_ms"], r3["depth_total"])}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, obs.numpy(), noise.numpy(), A, E, F, S, support)
         print(json.dumps(line), flush=True)

@@ -1,4 +1,9 @@
-"""Builds the HIP extension in-tree (muax_amd/lib/libmzsearch.so) for gfx950."""
+"""Builds the HIP extension in-tree (muax_amd/lib/libmzsearch.so) for gfx950.
+
+The library is several translation units compiled in parallel (each `hipcc -c`, objects under muax_amd/lib/obj/)
+and linked into one shared object: the C-ABI and the step-wise / training / Dirichlet kernels (mz_api.hip), the
+fused act() kernel instances in three groups (mz_fused_g*.hip, listed in mz_instances.def) and the ResNet
+recurrent kernel (mz_conv.hip).  Only the units whose sources changed are recompiled."""
 from __future__ import annotations
 
 import os
@@ -8,10 +13,23 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libmzsearch.so")
-SOURCES = ["mz_api.hip"]
-HEADERS = ["mz_spec.cuh", "mz_fused.cuh", "mz_step.cuh", "mz_step_jump.cuh", "mz_train.cuh", "mz_conv.cuh", "mz_dirichlet.cuh",
-           os.path.join("..", "..", "include", "mzsearch.h")]
+_ABI = os.path.join("..", "..", "include", "mzsearch.h")
+_FUSED = ["mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_instances.def", _ABI]
+# translation unit -> the headers it is rebuilt for
+UNITS = {
+    "mz_api.hip": ["mz_host.h", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_step.cuh", "mz_step_jump.cuh",
+                   "mz_train.cuh", "mz_dirichlet.cuh", _ABI],
+    "mz_fused_g0.hip": _FUSED,
+    "mz_fused_g1.hip": _FUSED,
+    "mz_fused_g2.hip": _FUSED,
+    "mz_conv.hip": ["mz_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
+}
+SOURCES = list(UNITS)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",
+         "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA accumulators in VGPRs: the recurrent kernel's folds need no accvgpr moves
+         "-fPIC", "-Wno-unused-value"]
 
 
 def hipcc() -> str:
@@ -21,26 +39,54 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (needed to build muax_amd's gfx950 kernels)")
 
 
+def _obj(unit: str, tag: str = "") -> str:
+    return os.path.join(OBJ_DIR, os.path.splitext(unit)[0] + tag + ".o")
+
+
+def _unit_stale(unit: str, tag: str = "") -> bool:
+    o = _obj(unit, tag)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [unit] + UNITS[unit])
+
+
 def stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for u in UNITS for f in [u] + UNITS[u])
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 ... -> muax_amd/lib/libmzsearch.so"""
-    if not force and not stale():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """hipcc --offload-arch=gfx950 -c <unit> (in parallel) ... ; hipcc -shared -> muax_amd/lib/libmzsearch.so.
+    `extra_flags` / `out`: variant builds of the same ABI for the tools (-DMZ_PROFILE, A/B defines)."""
+    out = out or LIB_PATH
+    variant = bool(extra_flags) or out != LIB_PATH
+    if not force and not variant and not stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",
-           "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA accumulators in VGPRs: the recurrent kernel's folds need no accvgpr moves
-           "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    tag = "" if not variant else "_" + os.path.splitext(os.path.basename(out))[0]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cc = hipcc()
+    jobs = []
+    for unit in UNITS:
+        if force or variant or _unit_stale(unit, tag):
+            cmd = [cc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit, tag)]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [_obj(u, tag) for u in UNITS]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+        print(" ".join(link))
+    subprocess.check_call(link)
+    if variant:
+        for u in UNITS:
+            os.remove(_obj(u, tag))
+    return out
 
 
 if __name__ == "__main__":

@@ -10,16 +10,20 @@
 #include <vector>
 
 #include "../../include/mzsearch.h"
-#include "mz_fused.cuh"
+#include "mz_host.h"
+#include "mz_fused_launch.h"
 #include "mz_step.cuh"
 #include "mz_step_jump.cuh"
 #include "mz_train.cuh"
-#include "mz_conv.cuh"
 #include "mz_dirichlet.cuh"
+
+namespace mzh {
+thread_local std::string g_create_error;
+}
 
 namespace {
 
-thread_local std::string g_create_error;
+using mzh::g_create_error;
 
 // ---- host-side JAX threefry (key bookkeeping only: 3 blocks per simulation) ----
 inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -119,34 +123,6 @@ void derive_keys(mzs_handle* h, const uint32_t key[2]) {
     rk[0] = nk[0];
     rk[1] = nk[1];
   }
-}
-
-template <class C>
-int launch_fused(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
-  static std::once_flag once[16];
-  int dev = h->cfg.device;
-  hipError_t attr_err = hipSuccess;
-  std::call_once(once[dev & 15], [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mz::mz_act_fused_kernel<C>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-  });
-  if (attr_err != hipSuccess)
-    return fail(h, MZS_E_RUNTIME, "hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-  int grid = (p.B + C::ROOTS_PER_WG - 1) / C::ROOTS_PER_WG;
-  hipLaunchKernelGGL(mz::mz_act_fused_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, p);
-  MZS_HIP(h, hipGetLastError());
-  return MZS_OK;
-}
-
-template <int A, int E, int F, int NMAX, int WAVES>
-int dispatch_mode(mzs_handle* h, mz::FusedParams& p, hipStream_t stream) {
-  const mzs_config& c = h->cfg;
-  if (c.policy == 1) {
-    if (c.qtransform == 1) return launch_fused<mz::FusedCfg<A, E, F, NMAX, 3, WAVES>>(h, p, stream);
-    return launch_fused<mz::FusedCfg<A, E, F, NMAX, 2, WAVES>>(h, p, stream);
-  }
-  if (c.tiebreak) return launch_fused<mz::FusedCfg<A, E, F, NMAX, 1, WAVES>>(h, p, stream);
-  return launch_fused<mz::FusedCfg<A, E, F, NMAX, 0, WAVES>>(h, p, stream);
 }
 
 }  // namespace
@@ -306,20 +282,18 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   memcpy(p.sim_keys, h->sim_keys.data(), sizeof(uint32_t) * 2 * (size_t)c.num_simulations);  // <= kMaxSims (checked above)
 
   const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, N = c.num_simulations + 1;
-#define MZS_INST(A_, E_, F_, NMAX_, WAVES_) \
-  if (A == A_ && E == E_ && F == F_ && N <= NMAX_) return dispatch_mode<A_, E_, F_, NMAX_, WAVES_>(h, p, stream);
-  MZS_INST(2, 8, 21, 51, 4)    // CartPole   (BASELINE cfg1/cfg2; README.md:102-132)
-  MZS_INST(4, 32, 21, 51, 4)   // LunarLander (BASELINE cfg3)
-  MZS_INST(4, 32, 21, 101, 1)  // ... up to 100 simulations (4 roots per workgroup)
-  MZS_INST(3, 8, 21, 51, 4)    // three actions (Acrobot / MountainCar shapes)
-  MZS_INST(4, 8, 21, 51, 3)    // four actions, small embedding: 12 roots per workgroup
-  MZS_INST(2, 8, 21, 64, 3)    // CartPole up to 63 simulations (12 roots per workgroup)
-  MZS_INST(2, 8, 21, 128, 1)   // ... up to 127 (4 roots per workgroup)
-  MZS_INST(2, 16, 21, 51, 4)   // wider embeddings / more actions of the same default trio
-  MZS_INST(4, 16, 21, 51, 3)
-#undef MZS_INST
+  p.F = F;
+  const int mode = c.policy == 1 ? (c.qtransform == 1 ? 3 : 2) : (c.tiebreak ? 1 : 0);
+  const mz::FusedDispatch groups[] = {mz::fused_dispatch_g0, mz::fused_dispatch_g1, mz::fused_dispatch_g2};
+  for (mz::FusedDispatch g : groups) {
+    std::string err;
+    const int rc = g(mode, c.device, p, stream, A, E, F, N, &err);
+    if (rc == mz::kNoFusedInstance) continue;
+    if (rc != MZS_OK) return fail(h, rc, "mzs_act_mlp: %s", err.c_str());
+    return MZS_OK;
+  }
   return fail(h, MZS_E_UNSUPPORTED,
-              "mzs_act_mlp: no fused kernel instance for this (A, E, F, S); use the step-wise path");
+              "mzs_act_mlp: no fused kernel instance for this (A, E, F, S) (muax_amd/csrc/mz_instances.def); use the step-wise path");
 }
 
 #ifdef MZ_PROFILE
@@ -594,83 +568,6 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
 }
 
 // ---------------------------------------------------------------------------
-// ResNet dynamics: next-state tower
-// ---------------------------------------------------------------------------
-int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
-  if (!a || a->struct_size != (int32_t)sizeof(mzs_tower_args))
-    return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: null arguments or size mismatch (ABI)");
-  if (a->batch <= 0 || a->blocks < 0) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: batch / blocks");
-  if (!a->x || !a->y || (a->blocks > 0 && (!a->conv_w || !a->ln)))
-    return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: null tensor pointer");
-  if (a->stem_w && (!a->action || a->num_actions <= 0))
-    return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: the stem needs actions and num_actions");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(nullptr, MZS_E_NODEVICE, "mzs_resnet_tower: no HIP device (this library has no CPU fallback)");
-  if (a->device < 0 || a->device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: bad device ordinal");
-  MZS_HIP(nullptr, hipSetDevice(a->device));
-  mz::TowerParams p;
-  memset(&p, 0, sizeof p);
-  if (a->r_c1) {
-    const float* const* hp = &a->r_c1;
-    for (int i = 0; i < 17; ++i)
-      if (!hp[i]) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: heads need all 17 weight arrays");
-    if (!a->reward || !a->value || !a->prior_logits || !a->stem_w || !a->normalize)
-      return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: heads need the stem, normalisation and the three outputs");
-    if (a->support_size <= 0 || 2 * a->support_size + 1 > 64 || a->num_actions > 64)
-      return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_resnet_tower: support / action count above 64");
-    p.heads = 1; p.A = a->num_actions; p.support = a->support_size; p.F = 2 * a->support_size + 1;
-    p.r_c1 = a->r_c1; p.r_c2 = a->r_c2; p.r_l1 = a->r_l1; p.r_b1 = a->r_b1; p.r_l2 = a->r_l2; p.r_b2 = a->r_b2;
-    p.v_c1 = a->v_c1; p.v_c2 = a->v_c2; p.v_l1 = a->v_l1; p.v_b1 = a->v_b1; p.v_l2 = a->v_l2; p.v_b2 = a->v_b2;
-    p.p_c1 = a->p_c1; p.p_l1 = a->p_l1; p.p_b1 = a->p_b1; p.p_l2 = a->p_l2; p.p_b2 = a->p_b2;
-    p.reward = a->reward; p.value = a->value; p.prior_logits = a->prior_logits;
-  }
-  p.x = a->x; p.action = a->action; p.stem_w = a->stem_w; p.conv_w = a->conv_w; p.ln = a->ln; p.y = a->y;
-  p.inv_num_actions = a->stem_w ? 1.0f / (float)a->num_actions : 0.0f;
-  p.B = a->batch; p.blocks = a->blocks; p.normalize = a->normalize;
-  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords);
-  static bool tower_attr = false;
-  if (!tower_attr) {
-    MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    tower_attr = true;
-  }
-  if (a->pair_scratch) {
-    const int64_t need = mzs_tower_pair_scratch_bytes(a->batch);
-    if (need == 0) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_resnet_tower: pair mode needs batch <= 128");
-    if (a->pair_scratch_bytes < need) return fail(nullptr, MZS_E_INVALID, "mzs_resnet_tower: pair_scratch too small");
-    if (2 * a->blocks + 1 > mz::kPairMsgs) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_resnet_tower: too many blocks for pair mode");
-    p.pair_f = static_cast<float*>(a->pair_scratch);
-    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot);
-    static bool pair_attr = false;
-    if (!pair_attr) {
-      MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_pair_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      pair_attr = true;
-    }
-    const int groups = (a->batch + 7) / 8;  // 16 blocks = 8 roots x 2 halves
-    hipLaunchKernelGGL(mz::mz_resnet_tower_pair_kernel, dim3(16 * groups), dim3(256), lds,
-                       static_cast<hipStream_t>(stream_), p);
-    MZS_HIP(nullptr, hipGetLastError());
-    return MZS_OK;
-  }
-  hipLaunchKernelGGL(mz::mz_resnet_tower_kernel, dim3(a->batch), dim3(256), lds, static_cast<hipStream_t>(stream_), p);
-  MZS_HIP(nullptr, hipGetLastError());
-  return MZS_OK;
-}
-
-#ifdef MZ_PROFILE
-// profiling builds only (tools/profile_tower.py): read and clear the per-workgroup phase counters
-int mzs_debug_tower_profile(uint64_t* host_out, int32_t words) {
-  static unsigned long long zero[1024 * 16];
-  if (words > 1024 * 16) words = 1024 * 16;
-  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mz::g_tower_prof), sizeof(uint64_t) * (size_t)words) != hipSuccess) return MZS_E_RUNTIME;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(mz::g_tower_prof), zero, sizeof(zero)) != hipSuccess) return MZS_E_RUNTIME;
-  return MZS_OK;
-}
-#endif
-
-// ---------------------------------------------------------------------------
 // root exploration noise
 // ---------------------------------------------------------------------------
 int mzs_dirichlet(int32_t device, const uint32_t key[2], float alpha, int32_t batch, int32_t num_actions,
@@ -692,11 +589,6 @@ int mzs_dirichlet(int32_t device, const uint32_t key[2], float alpha, int32_t ba
                      (uint64_t)root_offset, out);
   MZS_HIP(nullptr, hipGetLastError());
   return MZS_OK;
-}
-
-int64_t mzs_tower_pair_scratch_bytes(int32_t batch) {
-  if (batch <= 0 || batch > 128) return 0;  // 2 * batch workgroups have to be resident together
-  return (int64_t)batch * (4 * mz::kPairSlot * (int64_t)sizeof(float) + 4 * (int64_t)sizeof(unsigned));
 }
 
 }  // extern "C"

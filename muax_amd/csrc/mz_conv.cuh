@@ -20,7 +20,7 @@
 //
 // Floating-point kernel: checked against the torch modules of muax_amd/nn.py (tests), tolerance there.
 #pragma once
-#include "mz_train.cuh"  // f32x4
+#include "mz_spec.cuh"
 
 #pragma clang fp contract(off)
 

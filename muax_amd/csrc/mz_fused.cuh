@@ -90,7 +90,7 @@ struct FusedParams {
   float* t_embeddings;
   float* emb_scratch;  // [B][S+1][E], instances with the embeddings out of LDS and no export
   // scalars
-  int32_t B, obs_dim, S, max_depth, support, pred_on_parent, export_tree;
+  int32_t B, obs_dim, S, max_depth, support, F, pred_on_parent, export_tree;  // F = 2 support + 1
   float pb_c_init, pb_c_base, dirichlet_fraction, discount, temperature;
   uint64_t global_batch, root_offset;
   uint32_t k_sample[2];
@@ -105,15 +105,18 @@ struct FusedParams {
 
 // MODE: 0 muzero policy without tie-break noise, 1 muzero policy with mctx's tie-break noise,
 //       2 gumbel policy + qtransform_by_parent_and_siblings, 3 gumbel policy + completed_by_mix_value
-template <int A_, int E_, int F_, int NMAX_, int MODE_, int WAVES_ = 4>
+// FS_: 16-lane slots of the support logits (2: F = 2 support + 1 in 17..32, 4: 33..64); F itself is a run-time
+// parameter (support_size is a constructor argument of the reference, muax/model.py:48-49)
+template <int A_, int E_, int FS_, int NMAX_, int MODE_, int WAVES_ = 4>
 struct FusedCfg {
   static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_;
-  static constexpr int A = A_, E = E_, F = F_, NMAX = NMAX_, MODE = MODE_;
+  static constexpr int A = A_, E = E_, FS = FS_, NMAX = NMAX_, MODE = MODE_;
+  static_assert(FS_ == 2 || FS_ == 4, "support logits are handled as one or two packed pairs of lane slots");
   static constexpr bool TB = MODE_ == 1;
   static constexpr bool GUMBEL = MODE_ >= 2;
   static constexpr int QT = MODE_ == 3 ? 1 : 0;
   static constexpr int H = kHidden;
-  static constexpr int ES = (E + 15) / 16, FS = (F + 15) / 16;
+  static constexpr int ES = (E + 15) / 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
   //   [SEL0  ..) A x {child index, cached pUCT score}   (4-byte aligned only: the stride is odd)
   //   [HDR0  ..) visits, value, JUMP word, raw value
@@ -155,7 +158,7 @@ struct FusedCfg {
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
   static_assert(LDS_BYTES <= 160 * 1024, "tree does not fit the 160 KiB LDS of a CU: lower WAVES");
   static_assert(A <= 8, "selection keeps all A scores in registers");
-  static_assert(F <= 32 && E <= 32 * 16, "row-distributed vectors");
+  static_assert(E <= 32 * 16, "row-distributed vectors");
 };
 
 // y = x . W + b for row-distributed vectors; W column(s) of this lane in VGPRs.
@@ -185,6 +188,22 @@ struct RowLinear {
     });
 #pragma unroll
     for (int t = 0; t < OS; ++t) y[t] = y[t] + b[t];
+  }
+};
+
+// the same with a run-time number of outputs (the support logits): OS lane slots of capacity
+template <int NIN, int OS>
+struct RowLinearRT {
+  float w[NIN][OS];
+  float b[OS];
+  MZ_DEV void load(const float* __restrict__ W, const float* __restrict__ Bv, int j, int nout) {
+#pragma unroll
+    for (int t = 0; t < OS; ++t) {
+      int k = j + 16 * t;
+      b[t] = k < nout ? Bv[k] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) w[i][t] = k < nout ? W[i * nout + k] : 0.0f;
+    }
   }
 };
 
@@ -250,20 +269,32 @@ MZ_DEV void row_softmax(const float (&x)[(N + 15) / 16], int j, float (&p)[(N + 
   for (int t = 0; t < NSLOT; ++t) p[t] = e[t] / s;
 }
 
-// support_to_scalar(softmax(logits)) (muax/utils.py:94-102, muax/model.py:254,273-274)
-template <int F>
-MZ_DEV float row_decode(const float (&logits)[(F + 15) / 16], int j, int support) {
-  constexpr int NSLOT = (F + 15) / 16;
-  float p[NSLOT];
-  row_softmax<F>(logits, j, p);
+// support_to_scalar(softmax(logits)) (muax/utils.py:94-102, muax/model.py:254,273-274), F = 2 support + 1 > 16
+// logits in FS lane slots
+template <int FS>
+MZ_DEV float row_decode(const float (&logits)[FS], int j, int support, int F) {
+  bool ok[FS];
+#pragma unroll
+  for (int t = 0; t < FS; ++t) ok[t] = j + 16 * t < F;
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < FS; ++t) m = ok[t] ? fmaxf(m, logits[t]) : m;
+  m = row_max<4>(m);
+  float e[FS];
   float part = 0.0f;
 #pragma unroll
-  for (int t = 0; t < NSLOT; ++t) {
-    bool ok = j + 16 * t < F;
-    float term = (float)(j + 16 * t - support) * p[t];
-    part = (t == 0) ? (ok ? term : 0.0f) : (ok ? part + term : part);
+  for (int t = 0; t < FS; ++t) {
+    e[t] = ok[t] ? exp_neg(logits[t] - m) : 0.0f;
+    part = (t == 0) ? e[0] : (ok[t] ? part + e[t] : part);
   }
-  return inv_scaling(row_sum(part));
+  const float s = row_sum(part);
+  float tpart = 0.0f;
+#pragma unroll
+  for (int t = 0; t < FS; ++t) {
+    const float term = (float)(j + 16 * t - support) * (e[t] / s);
+    tpart = (t == 0) ? (ok[0] ? term : 0.0f) : (ok[t] ? tpart + term : tpart);
+  }
+  return inv_scaling(row_sum(tpart));
 }
 
 // muax/nn.py:37-44 over a row-distributed vector
@@ -290,52 +321,60 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
 template <class C>
 struct Nets {
   RowLinearPair<C::E> p1;  // (pv1, pp1)
-  RowLinear<kHidden, C::F> pv2;
+  RowLinearRT<kHidden, C::FS> pv2;
   RowLinear<kHidden, C::A> pp2;
   RowLinearOneHot2<C::E, C::A> d1;  // (dr1, dn1)
-  RowLinear<kHidden, C::F> dr2;
+  RowLinearRT<kHidden, C::FS> dr2;
   RowLinear<kHidden, C::E> dn2;
 
   MZ_DEV void load(const FusedParams& p, int j) {
     p1.load(p.pv_w1, p.pv_b1, p.pp_w1, p.pp_b1, j);
-    pv2.load(p.pv_w2, p.pv_b2, j); pp2.load(p.pp_w2, p.pp_b2, j);
+    pv2.load(p.pv_w2, p.pv_b2, j, p.F); pp2.load(p.pp_w2, p.pp_b2, j);
     d1.load(p.dr_w1, p.dr_b1, p.dn_w1, p.dn_b1, j);
-    dr2.load(p.dr_w2, p.dr_b2, j); dn2.load(p.dn_w2, p.dn_b2, j);
+    dr2.load(p.dr_w2, p.dr_b2, j, p.F); dn2.load(p.dn_w2, p.dn_b2, j);
   }
   // Prediction (muax/nn.py:73-90) + value decode
-  MZ_DEV void predict(const float (&s)[C::ES], int j, int support, float& value,
+  MZ_DEV void predict(const float (&s)[C::ES], int j, int support, int F, float& value,
                       float& pi_logit) const {
     // same packed chains as forward() below: every weight register then has ONE pairing in the whole
     // kernel (a second, scalar use made the compiler re-pair them through scratch memory)
-    static_assert(C::FS == 2, "support logits are handled as two lane slots");
+    constexpr int NP = C::FS / 2;
     f32x2 g = splat2(0.0f);
     StaticFor<0, C::E>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       g = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), p1.w[i], g);
     });
     g = elu2(g + p1.b);
-    f32x2 vl = splat2(0.0f);
+    f32x2 vl[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) vl[q] = splat2(0.0f);
     float pl = 0.0f;
     StaticFor<0, kHidden>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      vl = fma2(splat2(bcast<i>(g.x)), (f32x2){pv2.w[i][0], pv2.w[i][1]}, vl);
+      const f32x2 gv = splat2(bcast<i>(g.x));
+#pragma unroll
+      for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
       pl = __builtin_fmaf(bcast<i>(g.y), pp2.w[i][0], pl);
     });
-    vl = vl + (f32x2){pv2.b[0], pv2.b[1]};
     pi_logit = pl + pp2.b[0];
-    float v_logits[C::FS] = {vl.x, vl.y};
-    value = row_decode<C::F>(v_logits, j, support);
+    float v_logits[C::FS];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      vl[q] = vl[q] + (f32x2){pv2.b[2 * q], pv2.b[2 * q + 1]};
+      v_logits[2 * q] = vl[q].x;
+      v_logits[2 * q + 1] = vl[q].y;
+    }
+    value = row_decode<C::FS>(v_logits, j, support, F);
   }
   // ---- the per-simulation pass: Dynamic (muax/nn.py:93-115) on (s, action), Prediction
   // (muax/nn.py:73-90) on the child (or parent) embedding, both support decodes.  Same arithmetic
   // as predict() above (and a plain layer-by-layer Dynamic), organised for the machine: the two hidden layers that share an
   // input run as ONE packed chain ((reward-net, state-net), (value-net, policy-net)), 2-slot logits
   // are packed, and the reward and value decodes advance together as (reward, value) pairs. ----
-  MZ_DEV void forward(const float (&s)[C::ES], int action, int j, int support, bool pred_on_parent,
+  MZ_DEV void forward(const float (&s)[C::ES], int action, int j, int support, int F, bool pred_on_parent,
                       float& reward, float& value, float& pi_logit, float& pi_prob,
                       float (&ns)[C::ES]) const {
-    static_assert(C::FS == 2, "support logits are handled as two lane slots");
-    constexpr int E = C::E, A = C::A;
+    constexpr int E = C::E, A = C::A, FS = C::FS, NP = C::FS / 2;
     // Dynamic, first layer: [s, onehot(a)] -> 16 hidden units of the reward net and of the state net
     f32x2 h = splat2(0.0f);
     StaticFor<0, E>::run([&](auto ic) {
@@ -351,18 +390,23 @@ struct Nets {
       h = (h + wsel) + d1.b;
     }
     h = elu2(h);
-    // second layer: reward logits (two slots, packed) and next state
-    f32x2 rl = splat2(0.0f);
+    // second layer: reward logits (FS slots, packed in pairs) and next state
+    f32x2 rl[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) rl[q] = splat2(0.0f);
 #pragma unroll
     for (int t = 0; t < C::ES; ++t) ns[t] = 0.0f;
     StaticFor<0, kHidden>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      rl = fma2(splat2(bcast<i>(h.x)), (f32x2){dr2.w[i][0], dr2.w[i][1]}, rl);
+      const f32x2 hr = splat2(bcast<i>(h.x));
+#pragma unroll
+      for (int q = 0; q < NP; ++q) rl[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl[q]);
       const float hb = bcast<i>(h.y);
 #pragma unroll
       for (int t = 0; t < C::ES; ++t) ns[t] = __builtin_fmaf(hb, dn2.w[i][t], ns[t]);
     });
-    rl = rl + (f32x2){dr2.b[0], dr2.b[1]};
+#pragma unroll
+    for (int q = 0; q < NP; ++q) rl[q] = rl[q] + (f32x2){dr2.b[2 * q], dr2.b[2 * q + 1]};
 #pragma unroll
     for (int t = 0; t < C::ES; ++t) ns[t] = ns[t] + dn2.b[t];
     row_min_max_normalize<E>(ns, j);
@@ -376,14 +420,19 @@ struct Nets {
       g = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), p1.w[i], g);
     });
     g = elu2(g + p1.b);
-    f32x2 vl = splat2(0.0f);
+    f32x2 vl[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) vl[q] = splat2(0.0f);
     float pl = 0.0f;
     StaticFor<0, kHidden>::run([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      vl = fma2(splat2(bcast<i>(g.x)), (f32x2){pv2.w[i][0], pv2.w[i][1]}, vl);
+      const f32x2 gv = splat2(bcast<i>(g.x));
+#pragma unroll
+      for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
       pl = __builtin_fmaf(bcast<i>(g.y), pp2.w[i][0], pl);
     });
-    vl = vl + (f32x2){pv2.b[0], pv2.b[1]};
+#pragma unroll
+    for (int q = 0; q < NP; ++q) vl[q] = vl[q] + (f32x2){pv2.b[2 * q], pv2.b[2 * q + 1]};
     pi_logit = pl + pp2.b[0];
     {
       // children_prior of the new node: softmax over the A policy logits (an independent chain the
@@ -392,22 +441,38 @@ struct Nets {
       row_softmax<A>(px, j, pp);
       pi_prob = pp[0];
     }
-    // support_to_scalar(softmax(.)) of the reward logits and the value logits, as (reward, value) pairs
-    const bool ok1 = j + 16 < C::F;  // slot 0 is always inside the support (F > 16)
-    f32x2 m = (f32x2){ok1 ? fmaxf(rl.x, rl.y) : rl.x, ok1 ? fmaxf(vl.x, vl.y) : vl.x};
+    // support_to_scalar(softmax(.)) of the reward logits and the value logits, as (reward, value) pairs per
+    // lane slot; slot 0 is always inside the support (F > 16), the others are masked by ok[t]
+    f32x2 xs[FS];
+    bool ok[FS];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      xs[2 * q] = (f32x2){rl[q].x, vl[q].x};
+      xs[2 * q + 1] = (f32x2){rl[q].y, vl[q].y};
+    }
+#pragma unroll
+    for (int t = 0; t < FS; ++t) ok[t] = t == 0 || j + 16 * t < F;
+    f32x2 m = xs[0];
+#pragma unroll
+    for (int t = 1; t < FS; ++t) m = ok[t] ? (f32x2){fmaxf(m.x, xs[t].x), fmaxf(m.y, xs[t].y)} : m;
     m = (f32x2){row_max<4>(m.x), row_max<4>(m.y)};
-    f32x2 e0 = exp_neg2((f32x2){rl.x, vl.x} - m);
-    f32x2 e1 = exp_neg2((f32x2){rl.y, vl.y} - m);
-    e1 = ok1 ? e1 : splat2(0.0f);
-    f32x2 part = ok1 ? e0 + e1 : e0;
-    f32x2 sum = (f32x2){row_sum(part.x), row_sum(part.y)};
-    f32x2 p0 = (f32x2){e0.x / sum.x, e0.y / sum.y};
-    f32x2 p1 = (f32x2){e1.x / sum.x, e1.y / sum.y};
-    f32x2 t0 = splat2((float)(j - support)) * p0;
-    f32x2 t1 = splat2((float)(j + 16 - support)) * p1;
-    f32x2 tp = ok1 ? t0 + t1 : t0;
-    f32x2 xs = (f32x2){row_sum(tp.x), row_sum(tp.y)};
-    f32x2 dec = inv_scaling2(xs);
+    f32x2 e[FS];
+    e[0] = exp_neg2(xs[0] - m);
+    f32x2 part = e[0];
+#pragma unroll
+    for (int t = 1; t < FS; ++t) {
+      e[t] = exp_neg2(xs[t] - m);
+      e[t] = ok[t] ? e[t] : splat2(0.0f);
+      part = ok[t] ? part + e[t] : part;
+    }
+    const f32x2 sum = (f32x2){row_sum(part.x), row_sum(part.y)};
+    f32x2 tp = splat2((float)(j - support)) * (f32x2){e[0].x / sum.x, e[0].y / sum.y};
+#pragma unroll
+    for (int t = 1; t < FS; ++t) {
+      const f32x2 tt = splat2((float)(j + 16 * t - support)) * (f32x2){e[t].x / sum.x, e[t].y / sum.y};
+      tp = ok[t] ? tp + tt : tp;
+    }
+    const f32x2 dec = inv_scaling2((f32x2){row_sum(tp.x), row_sum(tp.y)});
     reward = dec.x;
     value = dec.y;
   }
@@ -658,7 +723,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     row_min_max_normalize<E>(s, j);
   }
   float v0, pl0;
-  nets.predict(s, j, support, v0, pl0);
+  nets.predict(s, j, support, p.F, v0, pl0);
   uint32_t inv_bits = 0;  // root_invalid_actions as a bit mask (row uniform)
   if (p.invalid != nullptr) {
 #pragma unroll
@@ -879,7 +944,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     for (int t = 0; t < C::PATHS; ++t) ppw[t] = itree[po + C::PATH0 + (j + 16 * t < C::PATHW ? j + 16 * t : 0)];
     float reward, value, pil, pprob;
     float ns[C::ES];
-    nets.forward(sp, action, j, support, p.pred_on_parent != 0, reward, value, pil, pprob, ns);
+    nets.forward(sp, action, j, support, p.F, p.pred_on_parent != 0, reward, value, pil, pprob, ns);
     MZ_TICK(2);  // network pass (+ parent embedding gather)
     {
       const int vis = vis_old + 1;

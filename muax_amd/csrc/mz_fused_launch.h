@@ -1,0 +1,17 @@
+// mz_fused_launch.h -- the fused act() kernel is compiled as several translation units (groups of instances, built
+// in parallel); each group exports one dispatcher.  Instances are listed in mz_instances.def.
+#pragma once
+#include <string>
+
+#include "mz_fused.cuh"
+
+namespace mz {
+constexpr int kNoFusedInstance = 1;  // dispatcher result: this group has no instance for the shape
+// mode: FusedCfg::MODE (0 muzero, 1 muzero + tie-break noise, 2 gumbel / parent-and-siblings, 3 gumbel / mix value).
+// Returns MZS_OK after the launch, kNoFusedInstance, or a negative MZS_E_* with *err set.
+using FusedDispatch = int (*)(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F,
+                              int N, std::string* err);
+int fused_dispatch_g0(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, std::string* err);
+int fused_dispatch_g1(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, std::string* err);
+int fused_dispatch_g2(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, std::string* err);
+}  // namespace mz

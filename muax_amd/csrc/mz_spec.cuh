@@ -212,6 +212,7 @@ MZ_DEV float inv_scaling(float x) {  // muax/utils.py:70-76, eps = 1e-3
 // ---- packed pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): component-wise the very same
 // operation sequences as the scalar routines above, two independent values per instruction ----
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator tile (mz_train.cuh, mz_conv.cuh)
 MZ_DEV f32x2 splat2(float x) { return (f32x2){x, x}; }
 MZ_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 MZ_DEV f32x2 exp_core2(f32x2 x, int& k0, int& k1) {

@@ -26,7 +26,6 @@
 
 namespace mz {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TrainParams {
   const float* obs;     // [B][obs_dim]   (batch.obs[:, 0])

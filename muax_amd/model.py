@@ -214,20 +214,26 @@ class MuZero:
         key = prng.as_key(rng_key)
         B = obs.shape[0]
         A = self.pred_func.num_actions if hasattr(self.pred_func, "num_actions") else None
-        fused_ok = mz_nn.is_default_mlp_trio(self.network) and obs.dim() == 2
+        fused_ok = mz_nn.is_default_mlp_trio(self.network) and obs.ndim == 2
+        self._last_fused = None  # the fused handle of this act(), if any (its outputs come back in one copy)
         if gumbel_policy and fused_ok and type(self._policy) is GumbelMuZeroPolicy:
             try:
                 h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
                                        1.25, 19652, False, "gumbel", qtransform, max_num_considered_actions,
                                        gumbel_scale, global_batch, root_offset)
                 out = h.act_mlp(obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree)
+                self._last_fused = h
                 return out, h.root_value
             except ValueError as e:
                 if "no fused kernel instance" not in str(e):
                     raise
                 self._warn_stepwise(A, self.repr_func.embedding_dim, num_simulations, e)
+        def device_obs():  # plugin nets (and the step-wise fall-back) run on device tensors
+            return obs if isinstance(obs, torch.Tensor) and obs.device == self.device \
+                else torch.as_tensor(obs, dtype=torch.float32).to(self.device)
+
         if gumbel_policy:
-            root = self._root_inference(params, key, obs)
+            root = self._root_inference(params, key, device_obs())
             out = self._checked_search(lambda: self._policy(
                 params, key, root, self._recurrent_inference, num_simulations=num_simulations,
                 invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
@@ -239,7 +245,7 @@ class MuZero:
             k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
             if A is None:
                 with torch.no_grad():
-                    A = self.pred_func(self.repr_func(obs[:1]))[1].shape[-1]
+                    A = self.pred_func(self.repr_func(torch.as_tensor(obs[:1], dtype=torch.float32).to(self.device)))[1].shape[-1]
             # a shard draws exactly its rows of the whole batch's noise: results do not depend on the split
             dirichlet_noise = _dirichlet(k_dir, dirichlet_alpha, (B, A), self.device, global_batch, root_offset)
         if fused_ok and type(self._policy) is MuZeroPolicy:
@@ -250,12 +256,13 @@ class MuZero:
                 out = h.act_mlp(obs, key, dirichlet_noise=dirichlet_noise, dirichlet_fraction=dirichlet_fraction,
                                 invalid_actions=invalid_actions, temperature=temperature, gumbel=gumbel,
                                 with_tree=with_tree)
+                self._last_fused = h
                 return out, h.root_value
             except ValueError as e:
                 if "no fused kernel instance" not in str(e):
                     raise
                 self._warn_stepwise(A, E, num_simulations, e)
-        root = self._root_inference(params, key, obs)
+        root = self._root_inference(params, key, device_obs())
 
         def run():
             return self._policy(params, key, root, self._recurrent_inference, num_simulations=num_simulations,
@@ -317,10 +324,14 @@ class MuZero:
         rows [root_offset, root_offset + B) of a `global_batch`-root batch passes both, and gets exactly the rows
         the un-sharded call would have produced (per-root PRNG streams are indexed by the global root).
         """
-        obs = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs, dtype=torch.float32)
-        if not obs_from_batch:
-            obs = obs.unsqueeze(0)
-        obs = obs.to(self.device)
+        if isinstance(obs, torch.Tensor):
+            obs = obs.to(torch.float32)
+            if not obs_from_batch:
+                obs = obs.unsqueeze(0)
+        else:  # host observations stay NumPy: the search handle stages them through pinned memory
+            obs = np.asarray(obs, dtype=np.float32)
+            if not obs_from_batch:
+                obs = obs[None]
         plan_output, root_value = self._plan(
             self.params, rng_key, obs, num_simulations=num_simulations, temperature=temperature,
             invalid_actions=invalid_actions, max_depth=max_depth, loop_fn=loop_fn, qtransform=qtransform,
@@ -328,21 +339,24 @@ class MuZero:
             pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak,
             max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
             global_batch=global_batch, root_offset=root_offset)
-        if not obs_from_batch:
-            # one device-to-host copy instead of three (each costs a synchronisation): action, weights, value
-            A = plan_output.action_weights.shape[1]
-            host = torch.cat([plan_output.action.to(torch.float32), plan_output.action_weights.reshape(-1),
-                              root_value.reshape(-1).to(torch.float32)]).cpu().numpy()
-            action = int(host[0])
-            weights = host[1:1 + A].reshape(1, A).copy()
-            root_value = float(host[1 + A])
-        elif device_outputs:
+        if device_outputs and obs_from_batch:
             # the search handle's output buffers are reused by the next act(): hand out copies (stream-ordered, no sync)
             action, weights, root_value = plan_output.action.clone(), plan_output.action_weights.clone(), root_value.clone()
         else:
-            action = plan_output.action.cpu().numpy()
-            weights = plan_output.action_weights.cpu().numpy()
-            root_value = root_value.cpu().numpy()
+            if self._last_fused is not None:
+                # fused path: the three outputs share one allocation -> one device-to-host copy, one sync
+                action, weights, root_value = self._last_fused.outputs_to_host()
+            else:
+                # one device-to-host copy instead of three (each costs a synchronisation): action, weights, value
+                A = plan_output.action_weights.shape[1]
+                B = plan_output.action.shape[0]
+                host = torch.cat([plan_output.action.to(torch.float32), plan_output.action_weights.reshape(-1),
+                                  root_value.reshape(-1).to(torch.float32)]).cpu().numpy()
+                action = host[:B].astype(np.int32)
+                weights = host[B:B + B * A].reshape(B, A).copy()
+                root_value = host[B + B * A:].copy()
+            if not obs_from_batch:
+                action, root_value = int(action[0]), float(root_value[0])  # weights keep their leading 1 (muax/model.py:176)
         if with_pi and with_value:
             return action, weights, root_value
         elif not with_pi and with_value:

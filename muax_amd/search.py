@@ -120,11 +120,15 @@ class MuZeroSearch:
         self._weights = None
         B, A = self.batch, cfg.num_actions
         with torch.cuda.device(self.device):
-            self.action = torch.empty(B, dtype=torch.int32, device=self.device)
-            self.action_weights = torch.empty(B, A, dtype=torch.float32, device=self.device)
-            self.root_value = torch.empty(B, dtype=torch.float32, device=self.device)
+            # action | action_weights | root_value in ONE allocation: a NumPy caller gets them with one copy
+            self._out = torch.empty(B * (2 + A), dtype=torch.float32, device=self.device)
+            self.action = self._out[:B].view(torch.int32)
+            self.action_weights = self._out[B:B + B * A].view(B, A)
+            self.root_value = self._out[B + B * A:]
             self.search_value = torch.empty(B, dtype=torch.float32, device=self.device)
             self.depth_sum = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._out_host = None   # pinned mirror of _out (outputs_to_host)
+        self._obs_stage = None  # (pinned host [B, obs_dim], its NumPy view, device twin, copy-done event)
         self._tree = None
         self._parent_emb = None
         self._graphs = {}  # (recurrent_fn) -> captured simulation loop
@@ -179,6 +183,41 @@ class MuZeroSearch:
             setattr(v, f, getattr(tree, f).data_ptr())
         return v
 
+    def outputs_to_host(self):
+        """(action int32 [B], action_weights f32 [B, A], root_value f32 [B]) as fresh NumPy arrays: ONE
+        device-to-host copy into pinned memory and one stream synchronisation (the reference's np.asarray /
+        .item() sync, muax/model.py:173-174)."""
+        B, A = self.batch, self.cfg.num_actions
+        if self._out_host is None:
+            self._out_host = torch.empty(B * (2 + A), dtype=torch.float32).pin_memory()
+            self._out_host_np = self._out_host.numpy()
+        self._out_host.copy_(self._out, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        h = self._out_host_np
+        return h[:B].view(np.int32).copy(), h[B:B + B * A].reshape(B, A).copy(), h[B + B * A:].copy()
+
+    def _stage_obs(self, obs, obs_dim):
+        """Host observations (NumPy / CPU tensor) -> device through a pinned staging buffer, asynchronously."""
+        B = self.batch
+        if isinstance(obs, torch.Tensor):
+            if obs.is_cuda:
+                return self._f32(obs, (B, obs_dim), "obs")
+            obs = obs.detach().numpy()
+        obs = np.asarray(obs)
+        if obs.shape != (B, obs_dim):
+            raise ValueError(f"obs: expected shape {(B, obs_dim)}, got {obs.shape}")
+        if self._obs_stage is None or self._obs_stage[0].shape[1] != obs_dim:
+            host = torch.empty(B, obs_dim, dtype=torch.float32).pin_memory()
+            self._obs_stage = (host, host.numpy(), torch.empty(B, obs_dim, dtype=torch.float32, device=self.device),
+                               torch.cuda.Event())
+        host, host_np, dev, ev = self._obs_stage
+        ev.synchronize()  # the previous upload has left the staging buffer (no-op when it has, or never ran)
+        np.copyto(host_np, obs, casting="same_kind")
+        with torch.cuda.device(self.device):
+            dev.copy_(host, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.device))
+        return dev
+
     # ------------------------------------------------------------------ fused path
     def set_mlp_weights(self, weights: dict, obs_dim: int, support_size: int = 10,
                         discount: float = 0.99, recurrent_pred_on: str = "child"):
@@ -209,7 +248,7 @@ class MuZeroSearch:
         if self._weights is None:
             raise ValueError("set_mlp_weights() first")
         B, A = self.batch, self.cfg.num_actions
-        obs = self._f32(obs, (B, self._weights[1]), "obs")
+        obs = self._stage_obs(obs, self._weights[1])
         noise = self._f32(dirichlet_noise, (B, A), "dirichlet_noise")
         inv = self._u8(invalid_actions, (B, A), "invalid_actions")
         gum = self._f32(gumbel, (B, A), "gumbel")

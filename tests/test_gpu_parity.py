@@ -54,7 +54,7 @@ def _compare(ref, s, out):
 
 
 @pytest.mark.parametrize("tiebreak", [False, True])
-@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100), (2, 8, 63, 150), (3, 8, 50, 90), (2, 16, 50, 70), (4, 16, 40, 50), (2, 8, 100, 60), (2, 8, 127, 30), (4, 32, 100, 24)])
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100), (2, 8, 63, 150), (3, 8, 50, 90), (2, 16, 50, 70), (4, 16, 40, 50), (2, 8, 100, 60), (2, 8, 127, 30), (4, 32, 100, 24), (2, 10, 50, 100), (4, 10, 50, 60), (6, 8, 50, 45)])
 def test_fused_matches_oracle(oracle, A, E, S, B, tiebreak):
     case = make_case(oracle, 10 * A + E, B, 4 if E == 8 else 8, E, A, S)
     key = [123, 456 + A]
@@ -116,6 +116,20 @@ def test_fused_small_margins(oracle):
     case["w"] = {k: (v * 1e-4).astype(np.float32) for k, v in case["w"].items()}
     s, out = _fused(case, True, [5, 5], use_noise=False)
     _compare(_oracle(oracle, case, True, [5, 5], use_noise=False), s, out)
+
+
+@pytest.mark.parametrize("A,E,support,S,B", [(2, 8, 8, 30, 40), (2, 8, 15, 50, 40), (2, 8, 16, 50, 70), (2, 8, 31, 20, 33),
+                                             (6, 8, 20, 50, 45), (4, 32, 20, 50, 50), (6, 8, 12, 30, 20)])
+def test_fused_support_sizes(oracle, A, E, support, S, B):
+    """support_size is a constructor argument of the reference (muax/model.py:48-49): F = 2 support + 1 is a
+    run-time parameter of the fused kernel, 17..32 logits in two lane slots, 33..63 in four -- e.g. the
+    (A = 6, E = 8, support = 20) shape through mzs_act_mlp."""
+    case = make_case(oracle, 100 * A + support, B, 4 if E == 8 else 8, E, A, S, support=support)
+    key = [support, A]
+    s, out = _fused(case, True, key)
+    _compare(_oracle(oracle, case, True, key), s, out)
+    s, out = _fused(case, False, key, temperature=0.25, use_noise=False)
+    _compare(_oracle(oracle, case, False, key, temperature=0.25, use_noise=False), s, out)
 
 
 def test_fused_sharding_invariance(oracle):

@@ -17,11 +17,8 @@ PHASES = ["loop top", "select (jump words)", "network pass", "-", "expand stores
 
 
 def build():
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                           "-fPIC", "-shared", "-Wno-unused-value", "-DMZ_PROFILE", "-o", LIB,
-                           os.path.join(ROOT, "muax_amd", "csrc", "mz_api.hip")])
-    print(LIB)
+    from muax_amd import _build
+    print(_build.build(extra_flags=["-DMZ_PROFILE"], out=LIB))
 
 
 def run():

@@ -28,8 +28,8 @@
 #pragma clang fp contract(off)
 
 using namespace mz;
-using Cfg = FusedCfg<2, 8, 21, 51, 1, 4>;  // CartPole shapes (BASELINE configs[1])
-constexpr int A = Cfg::A, E = Cfg::E, F = Cfg::F, H = kHidden, SUPPORT = 10;
+using Cfg = FusedCfg<2, 8, 2, 51, 1, 4>;  // CartPole shapes (BASELINE configs[1])
+constexpr int A = Cfg::A, E = Cfg::E, F = 21, H = kHidden, SUPPORT = 10;
 
 struct Out {
   float reward, value, pil[A], pprob[A], ns[E];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void netpass_rows(const BenchParams p) {
   __syncthreads();
   const uint64_t t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < p.iters; ++it) {
-    nets.forward(s, action, j, SUPPORT, false, reward, value, pil, pprob, ns);
+    nets.forward(s, action, j, SUPPORT, F, false, reward, value, pil, pprob, ns);
     chk = (chk << 1 | chk >> 31) ^ f2u(reward) ^ (f2u(value) * 3u) ^ f2u(bcast<0>(pil)) ^ (f2u(bcast<1>(pprob)) * 5u);
     s[0] = ns[0];
     action = (action + 1 + (it & 1)) % A;
@@ -335,6 +335,7 @@ int main(int argc, char** argv) {
   BenchParams p;
   memset(&p, 0, sizeof p);
   FusedParams& f = p.fp;
+  f.F = F;
   const float se = 1.0f / sqrtf((float)E), sx = 1.0f / sqrtf((float)(E + A)), sh = 0.25f;
   f.pv_w1 = dev(E * H, se, 0); f.pv_b1 = dev(H, 1, 1); f.pv_w2 = dev(H * F, sh, 0); f.pv_b2 = dev(F, 1, 1);
   f.pp_w1 = dev(E * H, se, 0); f.pp_b1 = dev(H, 1, 1); f.pp_w2 = dev(H * A, sh, 0); f.pp_b2 = dev(A, 1, 1);

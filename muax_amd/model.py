@@ -94,6 +94,7 @@ class MuZero:
         self._fused_train = None
         self._disc_const = None
         self._fused = {}
+        self._root_graphs = {}
         self._weights_version = 0
 
     # ------------------------------------------------------------------ init / params
@@ -150,7 +151,34 @@ class MuZero:
 
     # ------------------------------------------------------------------ inference glue
     def _root_inference(self, params, rng_key, obs):
-        """muax/model.py:251-263 -> (prior_logits [B,A], value [B], embedding [B,...])."""
+        """muax/model.py:251-263 -> (prior_logits [B,A], value [B], embedding [B,...]).  With
+        capture_graph=True the plugin nets' root inference (dozens of small torch kernels for a convolutional
+        representation net: launch-bound, 8 of config 4's 39 ms per act were gaps between them) is captured once
+        per (shape, weights version) into a hipGraph and replayed on a static input buffer; the returned tensors
+        are the graph's static outputs (consumed by mzs_root in stream order before the next replay)."""
+        if self.capture_graph and obs.is_cuda and not torch.cuda.is_current_stream_capturing():
+            key = (tuple(obs.shape), obs.dtype, obs.device, self._weights_version)
+            ent = self._root_graphs.get(key)
+            if ent is None:
+                self._root_graphs.clear()  # older weight versions / shapes: drop their graphs and buffers
+                static_in = obs.clone()
+                cur = torch.cuda.current_stream(obs.device)
+                side = torch.cuda.Stream(device=obs.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):  # lazy layer creation and MIOpen's solver search stay out of the capture
+                    for _ in range(2):
+                        self._root_inference_eager(static_in)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._root_inference_eager(static_in)
+                ent = self._root_graphs[key] = (g, static_in, out)
+            ent[1].copy_(obs)
+            ent[0].replay()
+            return ent[2]
+        return self._root_inference_eager(obs)
+
+    def _root_inference_eager(self, obs):
         with torch.no_grad():
             s = self.repr_func(obs)
             v, logits = self.pred_func(s)

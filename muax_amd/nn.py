@@ -135,6 +135,36 @@ def _init_dynamic_func(dynamic_module, embedding_dim, num_actions, full_support_
     return dynamic_module(embedding_dim, num_actions, full_support_size)
 
 
+def _init_resnet_representation_func(representation_module, input_channels):
+    """muax/nn.py:435-439."""
+    return representation_module(input_channels=input_channels)
+
+
+def _init_resnet_prediction_func(prediction_module, num_actions, full_support_size, output_channels):
+    """muax/nn.py:441-445."""
+    return prediction_module(num_actions, full_support_size, output_channels)
+
+
+def _init_resnet_dynamic_func(dynamic_module, num_actions, full_support_size, output_channels):
+    """muax/nn.py:447-451."""
+    return dynamic_module(num_actions, full_support_size, output_channels)
+
+
+def _init_ez_representation_func(representation_module, embedding_dim):
+    """muax/nn.py:398-402."""
+    return representation_module(embedding_dim)
+
+
+def _init_ez_prediction_func(prediction_module, num_actions, full_support_size, output_init_scale):
+    """muax/nn.py:404-408."""
+    return prediction_module(num_actions, full_support_size, output_init_scale)
+
+
+def _init_ez_dynamic_func(dynamic_module, embedding_dim, num_actions, full_support_size, output_init_scale):
+    """muax/nn.py:410-414."""
+    return dynamic_module(embedding_dim, num_actions, full_support_size, output_init_scale)
+
+
 def create_muzero_network(representation_module, prediction_module, dynamic_module, embedding_dim: int,
                           num_actions: int, full_support_size: int) -> MZNetwork:
     """muax/nn.py:23-34."""
@@ -324,6 +354,114 @@ def _head(conv_channels, n_convs, hidden, out, gen):
     for _ in range(n_convs):
         layers += [HkConv2D(conv_channels, 1, 1, generator=gen), nn.ReLU()]
     return _Seq(*layers, nn.Flatten(1), LazyHkLinear(hidden, generator=gen), nn.ReLU(), LazyHkLinear(out, generator=gen))
+
+
+class _LNReluHead(nn.Module):
+    """The head EZPrediction and EZDynamic share (muax/nn.py:232-243,246-257,277-288): LayerNorm - relu -
+    conv1x1(16) - LayerNorm - relu - flatten - Linear(32, no bias) - LayerNorm over the vector - relu - Linear(out)
+    with hk.initializers.VarianceScaling(output_init_scale) (fan_in, truncated normal) on the last layer."""
+
+    def __init__(self, out_features: int, output_init_scale: float, generator=None):
+        super().__init__()
+        self.ln_in, self.conv, self.ln_mid = HkLayerNorm(), HkConv2D(16, 1, 1, generator=generator), HkLayerNorm()
+        self.fc, self.ln_vec = LazyHkLinear(32, with_bias=False, generator=generator), HkLayerNorm(axis=(-1,))
+        self.out = LazyHkLinear(out_features, generator=generator)
+        self._scale = float(output_init_scale)
+
+    def forward(self, x):
+        h = torch.relu(self.ln_mid(self.conv(torch.relu(self.ln_in(x)))))
+        h = torch.relu(self.ln_vec(self.fc(h.flatten(1))))
+        fresh = self.out.w is None
+        y = self.out(h)
+        if fresh:  # VarianceScaling(scale): stddev sqrt(scale / fan_in) of the truncated normal (haiku divides by .8796)
+            with torch.no_grad():
+                self.out.w.mul_(math.sqrt(self._scale) / 0.87962566103423978)
+            y = self.out(h)
+        return y
+
+
+class EZStateEncoder(nn.Module):
+    """muax/nn.py:180-207: EfficientZero encoder, 84x84 frames -> 6x6 x channels (strides 2, 2, pool, pool)."""
+
+    def __init__(self, channels: int, use_v2: bool = True, generator=None):
+        super().__init__()
+        Block = ResidualConvBlockV2 if use_v2 else ResidualConvBlockV1
+        g = generator
+        self.use_v2 = use_v2
+        self.stem = HkConv2D(channels // 2, 3, 2, generator=g)
+        self.stem_ln = None if use_v2 else HkLayerNorm()
+        self.block0 = Block(channels // 2, 1, False, g)
+        self.block1 = Block(channels, 2, True, g)
+        self.block2, self.block3, self.block4 = Block(channels, 1, False, g), Block(channels, 1, False, g), Block(channels, 1, False, g)
+
+    def forward(self, observations):
+        x = self.stem(observations.to(torch.float32) / 255.)
+        if not self.use_v2:
+            x = torch.relu(self.stem_ln(x))
+        x = self.block2(self.block1(self.block0(x)))
+        x = self.block3(avg_pool_same(x))
+        return self.block4(avg_pool_same(x))
+
+
+class EZRepresentation(nn.Module):
+    """muax/nn.py:210-218 (no min-max normalisation: the reference's EZ variant returns the encoder output)."""
+
+    def __init__(self, embedding_dim: int, generator=None, name="representation"):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.repr_func = EZStateEncoder(embedding_dim, generator=generator)
+
+    def forward(self, obs):
+        return self.repr_func(obs)
+
+
+class EZPrediction(nn.Module):
+    """muax/nn.py:221-264: one residual block, then the value head and the policy head."""
+
+    def __init__(self, num_actions: int, full_support_size: int, output_init_scale: float, use_v2: bool = True,
+                 generator=None, name="prediction"):
+        super().__init__()
+        self.num_actions, self.full_support_size = num_actions, full_support_size
+        self._block_cls, self._gen = (ResidualConvBlockV2 if use_v2 else ResidualConvBlockV1), generator
+        self.block = None
+        self.v_func = _LNReluHead(full_support_size, output_init_scale, generator)
+        self.pi_func = _LNReluHead(num_actions, output_init_scale, generator)
+
+    def forward(self, s):
+        if self.block is None:  # channel count follows the embedding (muax/nn.py:260)
+            self.block = self._block_cls(s.shape[-1], 1, False, self._gen).to(s.device)
+        o = self.block(s)
+        return self.v_func(o), self.pi_func(o)
+
+
+class EZDynamic(nn.Module):
+    """muax/nn.py:267-309: the RAW action index enters as one extra plane (no / num_actions here, unlike
+    ResNetDynamic), one 3x3 convolution with a residual connection, one residual block, the reward head."""
+
+    def __init__(self, embedding_dim: int, num_actions: int, full_support_size: int, output_init_scale: float,
+                 use_v2: bool = True, generator=None, name="dynamic"):
+        super().__init__()
+        self.embedding_dim, self.num_actions, self.full_support_size = embedding_dim, num_actions, full_support_size
+        self.use_v2, self._gen = use_v2, generator
+        self._block_cls = ResidualConvBlockV2 if use_v2 else ResidualConvBlockV1
+        self.ln_in = HkLayerNorm()
+        self.conv = self.block = None
+        self.ln_out = None if use_v2 else HkLayerNorm()
+        self.r_func = _LNReluHead(full_support_size, output_init_scale, generator)
+
+    def forward(self, s, a):
+        n, h, w, c = s.shape
+        if self.conv is None:
+            self.conv = HkConv2D(c, 3, 1, generator=self._gen).to(s.device)
+            self.block = self._block_cls(c, 1, False, self._gen).to(s.device)
+        shortcut = s
+        if self.use_v2:
+            s = torch.relu(self.ln_in(s))
+        sa = torch.cat([s, a.to(s.dtype).reshape(n, 1, 1, 1).expand(n, h, w, 1)], dim=-1)
+        out = self.conv(sa)
+        out = out + shortcut if self.use_v2 else torch.relu(self.ln_out(out) + shortcut)
+        out = self.block(out)
+        return self.r_func(out), out
 
 
 class ResNetRepresentation(nn.Module):

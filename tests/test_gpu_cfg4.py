@@ -256,3 +256,24 @@ def test_lost_pair_rendezvous_drops_pair_mode_and_repeats_the_search():
     for x, y in zip(b0, b1):
         assert np.array_equal(x, y)
     assert np.array_equal(b0[1], pi0)
+
+
+def test_ez_nets_drive_the_stepwise_search_eager_and_captured():
+    """The reference's EfficientZero-style nets (muax/nn.py:180-309) as plugin nets: step-wise search with torch
+    modules between the tree kernels; with capture_graph=True both the root inference and the simulation loop are
+    hipGraphs and give the same search."""
+    g = torch.Generator().manual_seed(6)
+    mods = (mx.nn.EZRepresentation(32, generator=g), mx.nn.EZPrediction(A, 21, 1.0, generator=g),
+            mx.nn.EZDynamic(32, A, 21, 1.0, generator=g))
+    obs = _frames(6, seed=12)
+    eager, graph = mx.MuZero(*mods), mx.MuZero(*mods, capture_graph=True)
+    eager.init(0, obs[:1])
+    graph.init(0, obs[:1])
+    kw = dict(with_pi=True, with_value=True, obs_from_batch=True, num_simulations=10)
+    a1, pi1, v1 = eager.act(3, obs, **kw)
+    for _ in range(2):  # second call: pure replay of both graphs
+        a2, pi2, v2 = graph.act(3, obs, **kw)
+        assert np.array_equal(a1, a2) and np.array_equal(pi1, pi2) and np.allclose(v1, v2, rtol=1e-5, atol=1e-6)
+    assert pi1.shape == (6, A) and np.allclose(pi1.sum(1), 1) and len(graph._root_graphs) == 1
+    a3, _, _ = eager.act(4, _frames(6, seed=13), **kw)
+    assert a3.shape == (6,) and a3.dtype == np.int32

@@ -74,3 +74,43 @@ def test_resnet_trio_contract_atari_shape():
         y = ln(torch.randn(3, 4, 4, 5) * 3 + 2)
     assert torch.allclose(y.mean((1, 2, 3)), torch.zeros(3), atol=1e-5) and torch.allclose(
         y.var((1, 2, 3), unbiased=False), torch.ones(3), atol=1e-3)
+
+
+def test_ez_trio_contract_and_factories():
+    """muax/nn.py:180-309 (EfficientZero-style nets) and the factory functions muax/nn.py:398-451: geometry of the
+    encoder (84 -> 42 -> 21 -> 11 -> 6), both residual-block flavours, the raw-action plane of EZDynamic, the
+    LayerNorm heads and the VarianceScaling init of their last layer."""
+    g = torch.Generator().manual_seed(0)
+    nn_ = mx.nn
+    rep = nn_._init_ez_representation_func(lambda e: nn_.EZRepresentation(e, generator=g), 16)
+    pred = nn_._init_ez_prediction_func(lambda a, f, sc: nn_.EZPrediction(a, f, sc, generator=g), 18, 21, 0.1)
+    dyn = nn_._init_ez_dynamic_func(lambda e, a, f, sc: nn_.EZDynamic(e, a, f, sc, generator=g), 16, 18, 21, 0.1)
+    obs = torch.randint(0, 256, (2, 84, 84, 4)).float()
+    with torch.no_grad():
+        s = rep(obs)
+        v, lg = pred(s)
+        r, ns = dyn(s, torch.tensor([0, 17]))
+        r2, ns2 = dyn(s, torch.tensor([5, 17]))
+    assert s.shape == ns.shape == (2, 6, 6, 16) and v.shape == r.shape == (2, 21) and lg.shape == (2, 18)
+    assert not torch.equal(ns[0], ns2[0]) and torch.equal(ns[1], ns2[1])  # the action plane matters, per sample
+    w = pred.v_func.out.w
+    assert abs(float(w.std()) - np.sqrt(0.1 / 32)) < 0.4 * np.sqrt(0.1 / 32) and float(pred.v_func.out.b.abs().max()) == 0.0
+    assert pred.v_func.fc.b is None and tuple(pred.v_func.fc.w.shape) == (6 * 6 * 16, 32)
+    v1 = nn_.EZStateEncoder(8, use_v2=False, generator=g)
+    with torch.no_grad():
+        assert v1(obs).shape == (2, 6, 6, 8) and float(v1(obs).min()) >= 0.0  # v1 blocks end in a relu
+        d1 = nn_.EZDynamic(8, 4, 21, 1.0, use_v2=False, generator=g)
+        r1, n1 = d1(v1(obs), torch.tensor([1, 2]))
+    assert n1.shape == (2, 6, 6, 8) and r1.shape == (2, 21)
+    # the ResNet factories (muax/nn.py:435-451) build the modules config 4 uses
+    net = mx.MZNetwork(nn_._init_resnet_representation_func(lambda input_channels: nn_.ResNetRepresentation(input_channels, generator=g), 8),
+                       nn_._init_resnet_prediction_func(lambda a, f, c: nn_.ResNetPrediction(a, f, c, generator=g), 18, 21, 16),
+                       nn_._init_resnet_dynamic_func(lambda a, f, c: nn_.ResNetDynamic(a, f, output_channels=c, generator=g), 18, 21, 16))
+    with torch.no_grad():
+        s = net.representation_fn(obs)
+        assert s.shape == (2, 6, 6, 16) and net.prediction_fn(s)[1].shape == (2, 18)
+        assert net.dynamic_fn(s, torch.tensor([3, 4]))[1].shape == (2, 6, 6, 16)
+    # a MuZero on the EZ nets initialises and exposes its sub-networks (the search itself needs the GPU)
+    m = mx.MuZero(rep, pred, dyn, device="cpu")
+    m.init(0, np.zeros((1, 84, 84, 4), np.float32))
+    assert m.representation(obs.numpy()).shape == (2, 6, 6, 16)

@@ -122,6 +122,28 @@ int mzs_destroy(mzs_handle *h);
 int mzs_mlp_set_weights(mzs_handle *h, const mzs_mlp_weights *w);
 int mzs_act_mlp(mzs_handle *h, const mzs_act_args *args, void *stream);
 
+/* ---- the same from HOST memory: what the reference's act() does around its jitted _plan ----
+ * muax.MuZero.act takes NumPy observations and returns NumPy / Python values, synchronising on the way out
+ * (np.asarray / .item(), muax/model.py:160-179).  mzs_act_mlp_host is that whole round trip in one call: the
+ * observations (and optional masks / noise) are staged through pinned memory owned by the handle, the root noise is
+ * drawn on the device from split(key, 3)[1] unless given (mctx.muzero_policy's jax.random.dirichlet, see
+ * mzs_dirichlet), mzs_act_mlp runs, the three outputs come back with ONE copy, and the call returns after
+ * synchronising `stream`.  All pointers here are HOST pointers.  (The handle allocates its staging buffers at the
+ * first call; this is the only entry point that synchronises.) */
+typedef struct {
+  int32_t struct_size;
+  int32_t draw_dirichlet;              /* muzero policy: 1 = draw the root noise from `key` with dirichlet_alpha */
+  const float *obs;                    /* [B, obs_dim] */
+  const float *dirichlet_noise;        /* [B, A] or NULL (NULL and draw_dirichlet == 0: no noise, fraction forced to 0) */
+  const uint8_t *invalid_actions;      /* [B, A] or NULL */
+  uint32_t key[2];
+  float dirichlet_fraction, dirichlet_alpha, temperature, reserved0;
+  int32_t *action;                     /* out [B] */
+  float *action_weights;               /* out [B, A] */
+  float *root_value;                   /* out [B] */
+} mzs_act_host_args;
+int mzs_act_mlp_host(mzs_handle *h, const mzs_act_host_args *args, void *stream);
+
 /* ---- step-wise path: any repr/pred/dyn plugin nets run by the caller ----
  * mzs_root        <- RootFnOutput(prior_logits, value, embedding)  (muax/model.py:258-262)
  * mzs_select      -> (parent embedding, action) for recurrent_fn   (mctx simulate + expand gather)

@@ -52,6 +52,13 @@ class MzsActArgs(C.Structure):
                 ("depth_sum", _vp), ("tree", C.POINTER(MzsTreeView))]
 
 
+class MzsActHostArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("draw_dirichlet", C.c_int32), ("obs", _vp), ("dirichlet_noise", _vp),
+                ("invalid_actions", _vp), ("key", C.c_uint32 * 2), ("dirichlet_fraction", C.c_float),
+                ("dirichlet_alpha", C.c_float), ("temperature", C.c_float), ("reserved0", C.c_float),
+                ("action", _vp), ("action_weights", _vp), ("root_value", _vp)]
+
+
 class MzsTrainArgs(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32),
                 ("unroll_steps", C.c_int32), ("num_actions", C.c_int32), ("embed_dim", C.c_int32),
@@ -76,7 +83,7 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_expand_backup",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
-                    "mzs_dirichlet"]
+                    "mzs_dirichlet", "mzs_act_mlp_host"]
 
 _lib = None
 
@@ -100,6 +107,7 @@ def load(build_if_missing: bool = True):
     L.mzs_destroy.argtypes = [_vp]
     L.mzs_mlp_set_weights.argtypes = [_vp, C.POINTER(MzsMlpWeights)]
     L.mzs_act_mlp.argtypes = [_vp, C.POINTER(MzsActArgs), _vp]
+    L.mzs_act_mlp_host.argtypes = [_vp, C.POINTER(MzsActHostArgs), _vp]
     L.mzs_root.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.POINTER(C.c_uint32 * 2), _vp]
     L.mzs_root_gumbel.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32 * 2), _vp]
     L.mzs_select.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]

@@ -69,6 +69,9 @@ struct mzs_handle {
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
   int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
   float* fused_emb = nullptr;      // fused path, embed_dim > 16: [B][S+1][E] embeddings in HBM
+  // mzs_act_mlp_host: pinned staging (in: obs | noise | invalid, out: action | weights | value) and their device twins
+  void* host_in = nullptr; void* host_out = nullptr; void* dev_in = nullptr; void* dev_out = nullptr;
+  size_t host_in_bytes = 0;
   mz::JumpArgs jump = {nullptr, nullptr, nullptr, nullptr};  // step-wise path with cached decisions
   void* jump_slab = nullptr;
   bool use_jump = false;
@@ -195,6 +198,10 @@ int mzs_destroy(mzs_handle* h) {
   if (h->fused_table) hipFree(h->fused_table);
   if (h->fused_emb) hipFree(h->fused_emb);
   if (h->jump_slab) hipFree(h->jump_slab);
+  if (h->host_in) hipHostFree(h->host_in);
+  if (h->host_out) hipHostFree(h->host_out);
+  if (h->dev_in) hipFree(h->dev_in);
+  if (h->dev_out) hipFree(h->dev_out);
   delete h;
   return MZS_OK;
 }
@@ -294,6 +301,71 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   }
   return fail(h, MZS_E_UNSUPPORTED,
               "mzs_act_mlp: no fused kernel instance for this (A, E, F, S) (muax_amd/csrc/mz_instances.def); use the step-wise path");
+}
+
+int mzs_act_mlp_host(mzs_handle* h, const mzs_act_host_args* a, void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_act_host_args))
+    return fail(h, MZS_E_INVALID, "mzs_act_mlp_host: null or size mismatch (ABI)");
+  if (!h->have_weights) return fail(h, MZS_E_INVALID, "mzs_act_mlp_host: call mzs_mlp_set_weights first");
+  if (!a->obs || !a->action || !a->action_weights || !a->root_value)
+    return fail(h, MZS_E_INVALID, "mzs_act_mlp_host: obs/action/action_weights/root_value must be set");
+  const mzs_config& c = h->cfg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));
+  const size_t B = (size_t)c.batch, A = (size_t)c.num_actions, OD = (size_t)h->w.obs_dim;
+  // staging layout (4-byte words): obs [B, OD] | noise [B, A] | invalid [B, A] bytes
+  const size_t obs_b = B * OD * 4, noise_b = B * A * 4, inv_b = (B * A + 3) / 4 * 4, in_b = obs_b + noise_b + inv_b;
+  const size_t out_b = B * (2 + A) * 4;
+  if (h->host_in_bytes < in_b) {
+    if (h->host_in) { hipHostFree(h->host_in); hipFree(h->dev_in); h->host_in = h->dev_in = nullptr; }
+    MZS_HIP(h, hipHostMalloc(&h->host_in, in_b, hipHostMallocDefault));
+    MZS_HIP(h, hipMalloc(&h->dev_in, in_b));
+    h->host_in_bytes = in_b;
+  }
+  if (!h->host_out) {
+    MZS_HIP(h, hipHostMalloc(&h->host_out, out_b, hipHostMallocDefault));
+    MZS_HIP(h, hipMalloc(&h->dev_out, out_b));
+  }
+  char* hin = static_cast<char*>(h->host_in);
+  char* din = static_cast<char*>(h->dev_in);
+  memcpy(hin, a->obs, obs_b);
+  size_t up = obs_b;  // bytes to upload: the obs, and the optional blocks behind it only when they are used
+  const bool muzero = c.policy == 0;
+  const bool given = muzero && a->dirichlet_noise != nullptr;
+  const bool draw = muzero && !given && a->draw_dirichlet != 0 && a->dirichlet_fraction != 0.0f;
+  if (given) { memcpy(hin + obs_b, a->dirichlet_noise, noise_b); up = obs_b + noise_b; }
+  if (a->invalid_actions) { memcpy(hin + obs_b + noise_b, a->invalid_actions, B * A); up = in_b; }
+  MZS_HIP(h, hipMemcpyAsync(din, hin, up, hipMemcpyHostToDevice, stream));
+  float* d_noise = reinterpret_cast<float*>(din + obs_b);
+  if (draw) {
+    uint32_t kd[2];
+    h_split(a->key, 3, 1, kd);  // mctx: rng_key, dirichlet_rng_key, search_rng_key = split(rng_key, 3)
+    if (int rc = mzs_dirichlet(c.device, kd, a->dirichlet_alpha, c.batch, c.num_actions, c.global_batch, c.root_offset,
+                               d_noise, stream_))
+      return fail(h, rc, "mzs_act_mlp_host: %s", mzs_last_error(nullptr));
+  }
+  float* dout = static_cast<float*>(h->dev_out);
+  mzs_act_args args;
+  memset(&args, 0, sizeof args);
+  args.struct_size = (int32_t)sizeof args;
+  args.obs = reinterpret_cast<const float*>(din);
+  args.dirichlet_noise = (given || draw) ? d_noise : nullptr;
+  args.invalid_actions = a->invalid_actions ? reinterpret_cast<const uint8_t*>(din + obs_b + noise_b) : nullptr;
+  args.key[0] = a->key[0]; args.key[1] = a->key[1];
+  args.dirichlet_fraction = (given || draw) ? a->dirichlet_fraction : 0.0f;
+  args.temperature = a->temperature;
+  args.action = reinterpret_cast<int32_t*>(dout);
+  args.action_weights = dout + B;
+  args.root_value = dout + B + B * A;
+  if (int rc = mzs_act_mlp(h, &args, stream_)) return rc;
+  MZS_HIP(h, hipMemcpyAsync(h->host_out, dout, out_b, hipMemcpyDeviceToHost, stream));
+  MZS_HIP(h, hipStreamSynchronize(stream));
+  const char* hout = static_cast<const char*>(h->host_out);
+  memcpy(a->action, hout, B * 4);
+  memcpy(a->action_weights, hout + B * 4, B * A * 4);
+  memcpy(a->root_value, hout + B * 4 + B * A * 4, B * 4);
+  return MZS_OK;
 }
 
 #ifdef MZ_PROFILE

@@ -228,8 +228,11 @@ class MuZero:
     def _plan(self, params, rng_key, obs, num_simulations=5, temperature=1., invalid_actions=None,
               max_depth=None, loop_fn=None, qtransform=None, dirichlet_fraction=0.25, dirichlet_alpha=0.3,
               pb_c_init=1.25, pb_c_base=19652, dirichlet_noise=None, gumbel=None, tiebreak=True,
-              with_tree=False, max_num_considered_actions=16, gumbel_scale=1.0, global_batch=None, root_offset=0):
-        """muax/model.py:222-243 -> (PolicyOutput, root value)."""
+              with_tree=False, max_num_considered_actions=16, gumbel_scale=1.0, global_batch=None, root_offset=0,
+              host_io=False):
+        """muax/model.py:222-243 -> (PolicyOutput, root value).  `host_io`: the caller gave host observations and
+        wants host results; the fused path then makes the whole round trip in one C call (mzs_act_mlp_host) and the
+        PolicyOutput holds NumPy arrays."""
         if self._params is None:
             raise ValueError("call init() first")
         gumbel_policy = isinstance(self._policy, GumbelMuZeroPolicy)
@@ -244,11 +247,16 @@ class MuZero:
         A = self.pred_func.num_actions if hasattr(self.pred_func, "num_actions") else None
         fused_ok = mz_nn.is_default_mlp_trio(self.network) and obs.ndim == 2
         self._last_fused = None  # the fused handle of this act(), if any (its outputs come back in one copy)
+        host_io = (host_io and fused_ok and not with_tree and gumbel is None and not isinstance(obs, torch.Tensor)
+                   and not isinstance(dirichlet_noise, torch.Tensor) and not isinstance(invalid_actions, torch.Tensor))
         if gumbel_policy and fused_ok and type(self._policy) is GumbelMuZeroPolicy:
             try:
                 h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
                                        1.25, 19652, False, "gumbel", qtransform, max_num_considered_actions,
                                        gumbel_scale, global_batch, root_offset)
+                if host_io:
+                    a_, w_, v_ = h.act_mlp_host(obs, key, dirichlet_fraction=0.0, invalid_actions=invalid_actions)
+                    return PolicyOutput(a_, w_, None), v_
                 out = h.act_mlp(obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree)
                 self._last_fused = h
                 return out, h.root_value
@@ -269,6 +277,17 @@ class MuZero:
                 gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version,
                 global_batch=global_batch, root_offset=root_offset))
             return out, root[1]
+        if host_io and type(self._policy) is MuZeroPolicy:
+            try:  # NumPy in, NumPy out: one C call (staging, root-noise draw from the key, search, one download, sync)
+                h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
+                                       pb_c_init, pb_c_base, tiebreak, global_batch=global_batch, root_offset=root_offset)
+                a_, w_, v_ = h.act_mlp_host(obs, key, dirichlet_noise=dirichlet_noise,
+                                            dirichlet_fraction=dirichlet_fraction, dirichlet_alpha=dirichlet_alpha,
+                                            invalid_actions=invalid_actions, temperature=temperature)
+                return PolicyOutput(a_, w_, None), v_
+            except ValueError as e:
+                if "no fused kernel instance" not in str(e):
+                    raise
         if dirichlet_noise is None and dirichlet_fraction:
             k_dir = prng.split(key, 3)[1]  # mctx: rng_key, dirichlet_rng_key, search_rng_key = split(key, 3)
             if A is None:
@@ -366,13 +385,17 @@ class MuZero:
             dirichlet_fraction=dirichlet_fraction, dirichlet_alpha=dirichlet_alpha, pb_c_init=pb_c_init,
             pb_c_base=pb_c_base, dirichlet_noise=dirichlet_noise, gumbel=gumbel, tiebreak=tiebreak,
             max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
-            global_batch=global_batch, root_offset=root_offset)
-        if device_outputs and obs_from_batch:
+            global_batch=global_batch, root_offset=root_offset, host_io=not (device_outputs and obs_from_batch))
+        if isinstance(plan_output.action, np.ndarray):  # the fused path's host round trip: results are already NumPy
+            action, weights = plan_output.action, plan_output.action_weights
+            if not obs_from_batch:
+                action, root_value = int(action[0]), float(root_value[0])
+        elif device_outputs and obs_from_batch:
             # the search handle's output buffers are reused by the next act(): hand out copies (stream-ordered, no sync)
             action, weights, root_value = plan_output.action.clone(), plan_output.action_weights.clone(), root_value.clone()
         else:
             if self._last_fused is not None:
-                # fused path: the three outputs share one allocation -> one device-to-host copy, one sync
+                # fused path, device inputs: the three outputs share one allocation -> one device-to-host copy, one sync
                 action, weights, root_value = self._last_fused.outputs_to_host()
             else:
                 # one device-to-host copy instead of three (each costs a synchronisation): action, weights, value

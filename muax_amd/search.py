@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (MLP_WEIGHT_NAMES, TREE_FIELDS, TREE_INT_FIELDS, MzsActArgs, MzsConfig,
+from ._lib import (MLP_WEIGHT_NAMES, TREE_FIELDS, TREE_INT_FIELDS, MzsActArgs, MzsActHostArgs, MzsConfig,
                    MzsMlpWeights, MzsTreeView)
 
 
@@ -272,6 +272,44 @@ class MuZeroSearch:
         _lib.check(self._L.mzs_act_mlp(self._h, C.byref(a), self._stream()), self._h)
         self._keep = (obs, noise, inv, gum)  # alive until the stream has consumed them
         return PolicyOutput(self.action, self.action_weights, tree)
+
+    def act_mlp_host(self, obs: np.ndarray, key, dirichlet_noise=None, dirichlet_fraction: float = 0.25,
+                     dirichlet_alpha: float = 0.3, invalid_actions=None, temperature: float = 1.0):
+        """The reference's act() round trip in ONE C call (mzs_act_mlp_host): NumPy observations in, (action int32
+        [B], action_weights f32 [B, A], root_value f32 [B]) NumPy out, synchronised.  Root noise: `dirichlet_noise`
+        if given, else drawn on the device from split(key, 3)[1] (muzero policy, dirichlet_fraction != 0)."""
+        if self._weights is None:
+            raise ValueError("set_mlp_weights() first")
+        B, A, od = self.batch, self.cfg.num_actions, self._weights[1]
+        obs = np.ascontiguousarray(obs, np.float32)
+        if obs.shape != (B, od):
+            raise ValueError(f"obs: expected shape {(B, od)}, got {obs.shape}")
+        a = MzsActHostArgs()
+        a.struct_size = C.sizeof(MzsActHostArgs)
+        a.obs = obs.ctypes.data
+        keep = [obs]
+        if dirichlet_noise is not None:
+            nz = np.ascontiguousarray(dirichlet_noise, np.float32)
+            if nz.shape != (B, A):
+                raise ValueError(f"dirichlet_noise: expected shape {(B, A)}, got {nz.shape}")
+            a.dirichlet_noise = nz.ctypes.data
+            keep.append(nz)
+        if invalid_actions is not None:
+            iv = np.ascontiguousarray(np.asarray(invalid_actions) != 0, np.uint8)
+            if iv.shape != (B, A):
+                raise ValueError(f"invalid_actions: expected shape {(B, A)}, got {iv.shape}")
+            a.invalid_actions = iv.ctypes.data
+            keep.append(iv)
+        a.draw_dirichlet = 1
+        k = key_words(key)
+        a.key[0], a.key[1] = k
+        a.dirichlet_fraction, a.dirichlet_alpha, a.temperature = dirichlet_fraction, dirichlet_alpha, temperature
+        action = np.empty(B, np.int32)
+        weights = np.empty((B, A), np.float32)
+        value = np.empty(B, np.float32)
+        a.action, a.action_weights, a.root_value = action.ctypes.data, weights.ctypes.data, value.ctypes.data
+        _lib.check(self._L.mzs_act_mlp_host(self._h, C.byref(a), self._stream()), self._h)
+        return action, weights, value
 
     # ------------------------------------------------------------------ step-wise path
     def root(self, prior_logits, value, embedding, key=0, invalid_actions=None,

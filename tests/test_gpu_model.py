@@ -135,6 +135,16 @@ def test_muzero_act_equals_the_oracle_for_the_same_key(oracle, B, A, E, obs_dim,
     a, pi, v = m.act(key, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=S)
     assert a.dtype == np.int32 and np.array_equal(a, ref["action"]) and np.array_equal(pi, ref["action_weights"])
     assert np.array_equal(v, ref["root_value"])
+    # (NumPy observations take the one-call host round trip mzs_act_mlp_host; device tensors the launch-only path)
+    ad, pid, vd = m.act(key, torch.from_numpy(obs).cuda(), with_pi=True, with_value=True, obs_from_batch=True,
+                        num_simulations=S, device_outputs=True)
+    assert ad.is_cuda and np.array_equal(ad.cpu().numpy(), a) and np.array_equal(pid.cpu().numpy(), pi)
+    assert np.array_equal(vd.cpu().numpy(), v)
+    inv = np.zeros((B, A), np.uint8)
+    inv[::2, 0] = 1
+    ref_m = oracle.act_mlp(mlp, cfg, obs, key, noise, 0.25, inv, 1.0, None)
+    am, pim = m.act(key, obs, with_pi=True, obs_from_batch=True, num_simulations=S, invalid_actions=inv)
+    assert np.array_equal(am, ref_m["action"]) and np.array_equal(pim, ref_m["action_weights"]) and (pim[::2, 0] == 0).all()
     # an injected noise array replaces the draw; temperature and the other act() keywords reach the search
     inj = rng.dirichlet([0.3] * A, B).astype(F32)
     ref2 = oracle.act_mlp(mlp, cfg, obs, key, inj, 0.25, None, 0.5, None)

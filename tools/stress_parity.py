@@ -16,7 +16,8 @@ import test_gpu_parity as tp  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
 rng = np.random.default_rng(seed)
-shapes = [(2, 8, 4), (3, 8, 6), (4, 8, 5), (2, 16, 4), (4, 16, 8), (4, 32, 8)]
+shapes = [(2, 8, 4), (3, 8, 6), (4, 8, 5), (2, 16, 4), (4, 16, 8), (4, 32, 8), (2, 10, 4), (4, 10, 8), (6, 8, 6)]
+wide_support = {(2, 8), (4, 32), (6, 8)}  # instances with four support slots (support_size 16..31)
 bad = 0
 for c in range(n):
     A, E, obs_dim = shapes[rng.integers(len(shapes))]
@@ -24,7 +25,9 @@ for c in range(n):
     B = int(rng.integers(1, 200))
     tiebreak = bool(rng.integers(2))
     max_depth = None if rng.random() < 0.6 else int(rng.integers(1, S + 1))
-    case = make_case(oracle, 1000 + c + 100003 * abs(seed - 2024), B, obs_dim, E, A, S, invalid_frac=0.3 if (A > 2 and rng.random() < 0.4) else 0.0)
+    support = int(rng.integers(8, 32 if (A, E) in wide_support else 16)) if rng.random() < 0.5 else 10
+    case = make_case(oracle, 1000 + c + 100003 * abs(seed - 2024), B, obs_dim, E, A, S, support=support,
+                     invalid_frac=0.3 if (A > 2 and rng.random() < 0.4) else 0.0)
     scale = float(rng.choice([0.3, 1.0, 3.0]))  # sharper / flatter heads: other depths and tie patterns
     case["w"] = {k: (v * scale).astype(np.float32) if k.endswith(("w1", "w2")) else v for k, v in case["w"].items()}
     temperature = float(rng.choice([0.0, 0.5, 1.0]))
@@ -35,5 +38,5 @@ for c in range(n):
         tp._compare(ref, s, out)
     except AssertionError as e:
         bad += 1
-        print(f"MISMATCH case {c}: A={A} E={E} S={S} B={B} tb={tiebreak} md={max_depth} scale={scale} T={temperature}: {str(e)[:200]}")
+        print(f"MISMATCH case {c}: A={A} E={E} support={support} S={S} B={B} tb={tiebreak} md={max_depth} scale={scale} T={temperature}: {str(e)[:200]}")
 print(f"seed {seed}: {n} cases, {bad} mismatches; mean depth of the last case {float(s.depth_sum.float().mean()) / S:.2f}")

@@ -69,6 +69,8 @@ struct mzs_handle {
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
   int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
   float* fused_emb = nullptr;      // fused path, embed_dim > 16: [B][S+1][E] embeddings in HBM
+  int32_t* fused_path = nullptr;   // fused path, compact instances: [B][S+1][kCompactPathWords] root paths in HBM
+  int cu_count = 0;
   // mzs_act_mlp_host: pinned staging (in: obs | noise | invalid, out: action | weights | value) and their device twins
   void* host_in = nullptr; void* host_out = nullptr; void* dev_in = nullptr; void* dev_out = nullptr;
   size_t host_in_bytes = 0;
@@ -180,6 +182,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     return fail(nullptr, MZS_E_NODEVICE, "mzs_create: device is %s, kernels are built for gfx950 only", prop.gcnArchName);
   mzs_handle* h = new mzs_handle();
   h->cfg = *cfg;
+  h->cu_count = prop.multiProcessorCount;
   if (h->cfg.global_batch <= 0) h->cfg.global_batch = cfg->batch;
   if (h->cfg.root_offset < 0 || h->cfg.root_offset + cfg->batch > h->cfg.global_batch) {
     delete h;
@@ -197,6 +200,7 @@ int mzs_destroy(mzs_handle* h) {
   h->step.release();
   if (h->fused_table) hipFree(h->fused_table);
   if (h->fused_emb) hipFree(h->fused_emb);
+  if (h->fused_path) hipFree(h->fused_path);
   if (h->jump_slab) hipFree(h->jump_slab);
   if (h->host_in) hipHostFree(h->host_in);
   if (h->host_out) hipHostFree(h->host_out);
@@ -292,12 +296,22 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.F = F;
   const int mode = c.policy == 1 ? (c.qtransform == 1 ? 3 : 2) : (c.tiebreak ? 1 : 0);
   const mz::FusedDispatch groups[] = {mz::fused_dispatch_g0, mz::fused_dispatch_g1, mz::fused_dispatch_g2};
-  for (mz::FusedDispatch g : groups) {
-    std::string err;
-    const int rc = g(mode, c.device, p, stream, A, E, F, N, &err);
-    if (rc == mz::kNoFusedInstance) continue;
-    if (rc != MZS_OK) return fail(h, rc, "mzs_act_mlp: %s", err.c_str());
-    return MZS_OK;
+  // more 16-root workgroups than CUs: prefer a compact-record instance (two workgroups per CU), if the shape has one
+  for (int compact = (c.batch > 16 * h->cu_count) ? 1 : 0; compact >= 0; --compact) {
+    p.path_scratch = compact ? h->fused_path : nullptr;
+    for (size_t gi = 0; gi < sizeof groups / sizeof groups[0]; ++gi) {
+      std::string err;
+      int rc = groups[gi](mode, c.device, p, stream, A, E, F, N, compact != 0, &err);
+      if (rc == mz::kNeedPathScratch) {  // first compact launch of this handle: the HBM array of the root paths
+        MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_path),
+                             (size_t)c.batch * N * mz::kCompactPathWords * sizeof(int32_t)));
+        p.path_scratch = h->fused_path;
+        rc = groups[gi](mode, c.device, p, stream, A, E, F, N, true, &err);
+      }
+      if (rc == mz::kNoFusedInstance) continue;
+      if (rc != MZS_OK) return fail(h, rc, "mzs_act_mlp: %s", err.c_str());
+      return MZS_OK;
+    }
   }
   return fail(h, MZS_E_UNSUPPORTED,
               "mzs_act_mlp: no fused kernel instance for this (A, E, F, S) (muax_amd/csrc/mz_instances.def); use the step-wise path");

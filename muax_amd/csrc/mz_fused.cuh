@@ -89,6 +89,7 @@ struct FusedParams {
   int32_t* t_children_visits; float* t_children_rewards; float* t_children_discounts;
   float* t_embeddings;
   float* emb_scratch;  // [B][S+1][E], instances with the embeddings out of LDS and no export
+  int32_t* path_scratch;  // [B][S+1][PATHW], instances with the root paths out of LDS (FusedCfg::PH)
   // scalars
   int32_t B, obs_dim, S, max_depth, support, F, pred_on_parent, export_tree;  // F = 2 support + 1
   float pb_c_init, pb_c_base, dirichlet_fraction, discount, temperature;
@@ -107,8 +108,14 @@ struct FusedParams {
 //       2 gumbel policy + qtransform_by_parent_and_siblings, 3 gumbel policy + completed_by_mix_value
 // FS_: 16-lane slots of the support logits (2: F = 2 support + 1 in 17..32, 4: 33..64); F itself is a run-time
 // parameter (support_size is a constructor argument of the reference, muax/model.py:48-49)
-template <int A_, int E_, int FS_, int NMAX_, int MODE_, int WAVES_ = 4>
+// PH_ ("paths in HBM"): the compact record for launches with MORE workgroups than CUs.  A node's root path -- a
+// third of the record -- moves to global memory ([root][node][PATHW] words: read once per simulation, of the parent,
+// which is known when the simulation starts, so the load runs behind the network pass; written once per node) and the
+// raw value leaves the header where no decision reads it: 16 roots then need < 80 KiB of LDS, TWO workgroups share a
+// CU and every SIMD has two wavefronts whose issue latencies and LDS round trips overlap.
+template <int A_, int E_, int FS_, int NMAX_, int MODE_, int WAVES_ = 4, bool PH_ = false>
 struct FusedCfg {
+  static constexpr bool PH = PH_;
   static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_;
   static constexpr int A = A_, E = E_, FS = FS_, NMAX = NMAX_, MODE = MODE_;
   static_assert(FS_ == 2 || FS_ == 4, "support logits are handled as one or two packed pairs of lane slots");
@@ -128,7 +135,11 @@ struct FusedCfg {
   //   parent[0:12) | action[12:16) | depth of parent[16:24) | bit 31: the end point is a near tie
   static constexpr int SEL0 = 0, SELW = ((2 * A + 3) / 4) * 4;
   static constexpr int HDR0 = SELW, JUMP = HDR0 + 2;
-  static constexpr int ST0 = HDR0 + 4, STW = MODE_ >= 2 ? 5 : 4, ST_LOGIT = 4;
+  // raw_values are read inside the kernel only by qtransform_completed_by_mix_value (MODE 3); the compact record
+  // drops the word elsewhere (an export writes raw values straight to the caller's array)
+  static constexpr bool RAW_OK = !(PH_ && MODE_ != 3);
+  static constexpr int HDRW = RAW_OK ? 4 : 3;
+  static constexpr int ST0 = HDR0 + HDRW, STW = MODE_ >= 2 ? 5 : 4, ST_LOGIT = 4;
   // embeddings: in the LDS record while 16 roots per workgroup still fit the CU's LDS with them, else in
   // HBM ([root][node][E], one coalesced E*4-byte row per access, L2-resident while the root is active)
   static constexpr bool EMB_LDS = E_ <= 16;
@@ -141,12 +152,14 @@ struct FusedCfg {
   static constexpr int PATHW = (NMAX * ENTRY_BITS + 31) / 32;
   // odd record stride: lane e of the backup reads node(e)'s record, and with an odd stride the 16 records
   // of a row start in 16 different LDS banks (a stride of 40 words put them in 4)
-  static constexpr int NS = (PATH0 + PATHW) | 1;
+  static constexpr int NS = (PATH0 + (PH_ ? 0 : PATHW)) | 1;
   static constexpr int TREE_WORDS = ((NS * NMAX + 3) / 4) * 4;
   static constexpr int PATH_WORDS = 0;
-  static constexpr int NOISE_WORDS = 0;
+  // root Gumbel noise (gumbel policy): in the root's own, empty, path slot -- or behind the tree when paths are in HBM
+  static constexpr int NOISE_WORDS = (PH_ && MODE_ >= 2) ? ((A + 3) / 4) * 4 : 0;
+  static constexpr int GUM0 = PH_ ? TREE_WORDS : PATH0;
   static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
-  static_assert(A <= PATHW, "the root's (empty) path slot holds its Gumbel noise");
+  static_assert(PH_ || A <= PATHW, "the root's (empty) path slot holds its Gumbel noise");
   static constexpr int PATHS = (PATHW + 15) / 16;  // path words per lane when a node's path is copied
   static_assert(PATHS <= 4, "a node's path is copied by the 16 lanes of its row");
   // the four roots of a wave start 8 banks apart: row-uniform reads of the same field of four trees
@@ -157,6 +170,8 @@ struct FusedCfg {
   static constexpr int TBL_WORDS = 2 * (((NMAX + 2 + 3) / 4) * 4);  // {sqrt(n) pb_c(n), 1/n} pairs
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
   static_assert(LDS_BYTES <= 160 * 1024, "tree does not fit the 160 KiB LDS of a CU: lower WAVES");
+  static_assert(!PH_ || (2 * LDS_BYTES <= 160 * 1024 && WAVES_ == 4 && (PATHW + 15) / 16 == 1),
+                "compact record: two 16-root workgroups per CU, one path word per lane");
   static_assert(A <= 8, "selection keeps all A scores in registers");
   static_assert(E <= 32 * 16, "row-distributed vectors");
 };
@@ -640,7 +655,7 @@ MZ_DEV void gumbel_scores(bool is_root, float nval, float raw, const float (&log
 }
 
 template <class C>
-__global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const FusedParams p) {
+__global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel(const FusedParams p) {
   constexpr int A = C::A, E = C::E, NS = C::NS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // One wavefront per SIMD owns the whole 512-entry unified register file.  LLVM infers "no AGPRs"
@@ -679,6 +694,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
   // embeddings of this root in HBM (instances that keep them out of LDS): the caller's export buffer when
   // a tree export is requested, else the handle's scratch
   float* gemb = C::EMB_LDS ? nullptr : (ex ? p.t_embeddings : p.emb_scratch) + (size_t)r * N * E;
+
+  // root paths of this root's nodes in HBM (compact record)
+  int32_t* gpath = C::PH ? p.path_scratch + (size_t)r * N * C::PATHW : nullptr;
 
   Nets<C> nets;
   nets.load(p, j);
@@ -765,7 +783,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         g = p.gumbel_scale * gumbel_from_bits(second ? x1 : x0);
       }
       if (j < A) {
-        tree[C::PATH0 + j] = g;  // the root's own path is empty: its slot keeps root_gumbel
+        tree[C::GUM0 + j] = g;  // root_gumbel: in the root's own (empty) path slot, or behind the tree
         tree[C::ST0 + C::STW * j + C::ST_LOGIT] = lg;
       }
       ncons = min(p.max_considered, A - __builtin_popcount(inv_bits));
@@ -775,7 +793,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     if (j == 0) {
       itree[C::HDR0] = 1;
       tree[C::HDR0 + 1] = v0;
-      tree[C::HDR0 + 3] = v0;
+      if constexpr (C::RAW_OK) tree[C::HDR0 + 3] = v0;
       p.root_value[r] = v0;
       if (ex) p.t_raw_values[(size_t)r * N] = v0;
     }
@@ -805,7 +823,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         logit[a] = tree[C::ST0 + C::STW * a + C::ST_LOGIT];
-        gum[a] = tree[C::PATH0 + a];
+        gum[a] = tree[C::GUM0 + a];
       }
       gumbel_scores<A, C::QT>(true, v0, v0, logit, val, vis, rew, dis, gum, p.visit_table[(size_t)ncons * S],
                               inv_bits, sc);
@@ -909,7 +927,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     if (depth > max_depth) {
       // the cached descent overshoots max_depth: stop at level max_depth - 1 of the same path
       depth = max_depth;
-      const int* pb = itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
+      const int* pb = C::PH ? gpath + (size_t)parent * C::PATHW : itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
       const int e = depth - 1;
       const int ent = (pb[(e * C::ENTRY_BITS) >> 5] >> ((e * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
       parent = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
@@ -941,7 +959,11 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
     const int vis_old = nni[C::HDR0];
     int ppw[C::PATHS];
 #pragma unroll
-    for (int t = 0; t < C::PATHS; ++t) ppw[t] = itree[po + C::PATH0 + (j + 16 * t < C::PATHW ? j + 16 * t : 0)];
+    for (int t = 0; t < C::PATHS; ++t) {
+      const int wi = j + 16 * t < C::PATHW ? j + 16 * t : 0;
+      if constexpr (C::PH) ppw[t] = gpath[(size_t)parent * C::PATHW + wi];  // (consumed after the network pass)
+      else ppw[t] = itree[po + C::PATH0 + wi];
+    }
     float reward, value, pil, pprob;
     float ns[C::ES];
     nets.forward(sp, action, j, support, p.F, p.pred_on_parent != 0, reward, value, pil, pprob, ns);
@@ -961,7 +983,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       if (j == 0) {
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
-        nn[C::HDR0 + 3] = value;  // raw_values[new] (mctx update_tree_node)
+        if constexpr (C::RAW_OK) nn[C::HDR0 + 3] = value;  // raw_values[new] (mctx update_tree_node)
         itree[po + C::SEL0 + 2 * action] = newn;
         tree[po + C::ST0 + C::STW * action + 3] = reward;
       }
@@ -977,7 +999,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
           w = (wi == ((e * C::ENTRY_BITS) >> 5))
                   ? (int)(((unsigned)w & ~(((1u << C::ENTRY_BITS) - 1u) << sh)) | ((unsigned)ent << sh))
                   : w;
-          if (wi < C::PATHW) nni[C::PATH0 + wi] = w;
+          if (wi < C::PATHW) {
+            if constexpr (C::PH) gpath[(size_t)newn * C::PATHW + wi] = w;
+            else nni[C::PATH0 + wi] = w;
+          }
         }
       }
       if (ex) {
@@ -1013,7 +1038,12 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
         int pn, pa;
         {
           const int ec = e < depth - 1 ? e : 0;
-          const int ent = (ppath[(ec * C::ENTRY_BITS) >> 5] >> ((ec * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
+          int pword;
+          if constexpr (C::PH)  // word (ec * ENTRY_BITS) / 32 of the parent's path sits in that lane of this row's ppw
+            pword = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + ((ec * C::ENTRY_BITS) >> 5)), ppw[0]);
+          else
+            pword = ppath[(ec * C::ENTRY_BITS) >> 5];
+          const int ent = (pword >> ((ec * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
           pn = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
           pa = ent >> C::ENTRY_ACT_SHIFT;
           pn = e == depth - 1 ? parent : pn;
@@ -1102,9 +1132,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
 #pragma unroll
           for (int a = 0; a < A; ++a) {
             logit[a] = nd[C::ST0 + C::STW * a + C::ST_LOGIT];
-            gum[a] = tree[C::PATH0 + a];
+            gum[a] = tree[C::GUM0 + a];
           }
-          gumbel_scores<A, C::QT>(pn == 0, nval, nd[C::HDR0 + 3], logit, val, vis, rew, dis, gum, cv_next,
+          gumbel_scores<A, C::QT>(pn == 0, nval, C::RAW_OK ? nd[C::HDR0 + C::HDRW - 1] : 0.0f, logit, val, vis, rew, dis, gum, cv_next,
                                   pn == 0 ? inv_bits : 0u, sc);
         }
         MZ_TICKW(10);  // scores
@@ -1171,10 +1201,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void mz_act_fused_kernel(const Fused
       rew[a] = tree[C::ST0 + C::STW * a + 3];
       dis[a] = p.discount;
       logit[a] = tree[C::ST0 + C::STW * a + C::ST_LOGIT];
-      gum[a] = tree[C::PATH0 + a];
+      gum[a] = tree[C::GUM0 + a];
       cv = max(cv, vis[a]);
     }
-    const float nval = tree[C::HDR0 + 1], raw = tree[C::HDR0 + 3];
+    const float nval = tree[C::HDR0 + 1], raw = C::RAW_OK ? tree[C::HDR0 + C::HDRW - 1] : 0.0f;
     gumbel_scores<A, C::QT>(true, nval, raw, logit, val, vis, rew, dis, gum, cv, inv_bits, sc);
     qtransform_inlane<A, C::QT>(nval, raw, logit, val, vis, rew, dis, qv, sumv);
     int best = 0;

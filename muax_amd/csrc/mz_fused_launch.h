@@ -7,11 +7,15 @@
 
 namespace mz {
 constexpr int kNoFusedInstance = 1;  // dispatcher result: this group has no instance for the shape
+constexpr int kNeedPathScratch = 2;  // a compact instance fits, but p.path_scratch is not set: allocate it and call again
 // mode: FusedCfg::MODE (0 muzero, 1 muzero + tie-break noise, 2 gumbel / parent-and-siblings, 3 gumbel / mix value).
 // Returns MZS_OK after the launch, kNoFusedInstance, or a negative MZS_E_* with *err set.
+// compact: take an instance with the compact tree record (FusedCfg::PH; needs p.path_scratch), else a plain one.
 using FusedDispatch = int (*)(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F,
-                              int N, std::string* err);
-int fused_dispatch_g0(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, std::string* err);
-int fused_dispatch_g1(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, std::string* err);
-int fused_dispatch_g2(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, std::string* err);
+                              int N, bool compact, std::string* err);
+int fused_dispatch_g0(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
+int fused_dispatch_g1(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
+int fused_dispatch_g2(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
+// words per node of the HBM path array of a compact instance (the same for every instance with NMAX <= 64, A <= 4)
+constexpr int kCompactPathWords = 13;
 }  // namespace mz

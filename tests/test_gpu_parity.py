@@ -521,3 +521,23 @@ def test_gumbel_fused_injected_noise_and_max_depth(oracle):
     out = s.act_mlp(torch.from_numpy(case["obs"]), 5, gumbel=torch.from_numpy(g), with_tree=True)
     torch.cuda.synchronize()
     _compare(_gumbel_oracle_act(oracle, case, [0, 5], 1, 16, gumbel=g, max_depth=4), s, out)
+
+
+@pytest.mark.parametrize("B,tiebreak", [(4097, True), (9000, True), (16384, False)])
+def test_fused_compact_record_above_one_workgroup_per_cu(oracle, B, tiebreak):
+    """More 16-root workgroups than CUs (> 4096 roots on MI355X): mzs_act_mlp takes the compact-record instance
+    (root paths in HBM, two workgroups per CU).  Same bits as the oracle on every tree array, with masks, a
+    max_depth cut (the overshoot branch reads the parent's path from HBM) and against a shard of the same rows
+    run on the plain instance."""
+    case = make_case(oracle, 77, B, 4, 8, 2, 50, invalid_frac=0.1)
+    key = [B, 3]
+    s, out = _fused(case, tiebreak, key)
+    _compare(_oracle(oracle, case, tiebreak, key), s, out)
+    s, out = _fused(case, tiebreak, key, max_depth=6, temperature=0.5, use_gumbel=False)
+    _compare(_oracle(oracle, case, tiebreak, key, max_depth=6, temperature=0.5, use_gumbel=False), s, out)
+    sl = slice(B - 300, B)
+    s2, o2 = _fused(case, tiebreak, key, max_depth=6, temperature=0.5, use_gumbel=False, global_batch=B,
+                    root_offset=B - 300, rows=sl)
+    assert torch.equal(o2.action, out.action[sl])
+    for f in out.search_tree._fields:
+        assert torch.equal(getattr(o2.search_tree, f), getattr(out.search_tree, f)[sl]), f

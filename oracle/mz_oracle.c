@@ -883,6 +883,30 @@ void mzo_act_mlp(const mzo_mlp *m, const mzo_search_cfg *cfg, mzo_tree *t,
   free(sim_keys);
 }
 
+/* see mz_oracle.h: the HIP kernels divide by 2 eps = 0.002f with y = RN(1 / 0.002f), q0 = x y, r = fma(-q0, 0.002f, x),
+ * q = fma(r, y, q0); count the binary32 x (every mantissa, exponents e_lo .. e_hi biased) for which q != x / 0.002f */
+int64_t mzo_div2eps_mismatches(int e_lo, int e_hi) {
+  const float c = 0.002f, y = 1.0f / c;
+  int64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic)
+  for (int e = e_lo; e <= e_hi; ++e)
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+      const float x = f32_from_bits(((uint32_t)e << 23) | m);
+      const float q0 = x * y;
+      const float r = fmaf(-q0, c, x);
+      if (fmaf(r, y, q0) != x / c) ++bad;
+    }
+  return bad;
+}
+/* elu(x) for x <= -87 through the clamped path only (no select): must be exactly -1 */
+float mzo_elu_clamped(float x) {
+  float xn = x < 0.0f ? x : 0.0f;
+  int k;
+  float q = exp_core(xn > -87.0f ? xn : -87.0f, &k);
+  float em1 = (k == 0) ? q : (1.0f + q) * pow2i(k) - 1.0f;
+  return x > 0.0f ? x : em1;
+}
+
 /* see mz_oracle.h: exhaustive check of the small-integer Markstein division used by the HIP kernel */
 int64_t mzo_markstein_mismatches(int dmax, int exponent) {
   int64_t bad = 0;

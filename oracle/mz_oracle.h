@@ -169,6 +169,8 @@ void mzo_act_mlp(const mzo_mlp *m, const mzo_search_cfg *cfg, mzo_tree *t,
  * (every mantissa, both signs) give q != x / d, summed over d = 1 .. dmax.  0 means the two agree for
  * every normal x (scaling by a power of two changes neither side). */
 int64_t mzo_markstein_mismatches(int dmax, int exponent);
+int64_t mzo_div2eps_mismatches(int e_lo, int e_hi);
+float mzo_elu_clamped(float x);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,10 @@ def lib():
         L.mzo_random_bits.restype = C.c_uint32
         L.mzo_random_bits.argtypes = [_u32p, C.c_int64, C.c_int64]
         L.mzo_select_action.restype = C.c_int
+        L.mzo_div2eps_mismatches.restype = C.c_int64
+        L.mzo_div2eps_mismatches.argtypes = [C.c_int, C.c_int]
+        L.mzo_elu_clamped.restype = C.c_float
+        L.mzo_elu_clamped.argtypes = [C.c_float]
         L.mzo_markstein_mismatches.restype = C.c_int64
         L.mzo_markstein_mismatches.argtypes = [C.c_int, C.c_int]
         for name in ("mzo_softmax", "mzo_min_max_normalize", "mzo_threefry2x32", "mzo_split",

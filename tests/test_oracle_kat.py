@@ -325,3 +325,16 @@ def test_dirichlet_restatement_statistics_shards_and_frozen_vector(oracle):
         assert abs(g.mean() - alpha) < 0.06 * max(1, alpha) and abs(g.var() - alpha) < 0.2 * max(1, alpha), alpha
     frozen = oracle.dirichlet([0, 42], 0.3, 3, 2)
     assert np.array_equal(frozen.view(np.uint32), np.array(FROZEN_DIRICHLET, np.uint32)), frozen.view(np.uint32).tolist()
+
+
+def test_division_by_two_eps_and_clamped_elu_equal_the_spec(oracle):
+    """Two instruction-count savings of the HIP kernels that must not change a bit: (d - 1) / 0.002f of
+    _inv_scaling (muax/utils.py:70-76) as a 3-op Markstein sequence -- compared with the IEEE division for EVERY
+    binary32 value with exponent 2^-27 .. 2^13 (344 M cases; _inv_scaling produces 2^-9 .. 2^-3) -- and ELU without
+    its `x < -87 -> -1` select (the clamp at -87 already gives exp(-87) - 1 = -1 exactly)."""
+    L = oracle.lib()
+    assert L.mzo_div2eps_mismatches(100, 140) == 0
+    for x in (-87.0, -87.000008, -88.0, -100.0, -1e4, -3e38, float("-inf")):
+        assert L.mzo_elu_clamped(x) == -1.0 and L.mzo_elu(x) == -1.0
+    xs = np.concatenate([np.linspace(-90, 3, 20001), -np.logspace(-30, 1.9, 500)]).astype(np.float32)
+    assert all(L.mzo_elu_clamped(float(x)) == L.mzo_elu(float(x)) for x in xs)

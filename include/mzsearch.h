@@ -169,6 +169,13 @@ int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
                float *search_value_out, int32_t *depth_sum_out, void *stream);
 int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
 
+/* ---- device self-test ----
+ * Two places of the kernels replace a library sequence by a shorter one that is only valid for this hardware's
+ * v_sqrt_f32 / fma: sqrt on arguments that need no range scaling, and division by 2 eps = 0.002f (muax/utils.py:70-76).
+ * mzs_selftest compares both with the IEEE operations on the device, exhaustively over [1, 4) resp. 2^-9 .. 2^-2, and
+ * returns the mismatch counts (both must be 0) in mismatches[0..1].  Synchronous.  errors: mzs_last_error(NULL) */
+int mzs_selftest(int32_t device, int64_t *mismatches);
+
 /* ---- root exploration noise ----
  * rows [root_offset, root_offset + batch) of what mctx.muzero_policy draws for a `global_batch`-root act:
  *   jax.random.dirichlet(split(rng_key, 3)[1], alpha = full([num_actions], dirichlet_alpha), shape = (global_batch,))

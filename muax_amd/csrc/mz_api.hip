@@ -654,6 +654,45 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
 }
 
 // ---------------------------------------------------------------------------
+// device self-test of the hardware-dependent arithmetic identities
+// ---------------------------------------------------------------------------
+namespace mz {
+__global__ void selftest_kernel(unsigned long long* bad) {
+  // every binary32 in [1, 4): sqrt_normal vs the IEEE sqrt; the same mantissas at 2^-9 .. 2^-2: div_two_eps vs x / 0.002f
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 2^24 threads
+  const float x = __uint_as_float(0x3f800000u + i);
+  unsigned long long b0 = sqrt_normal(x) != sqrtf(x);
+  unsigned long long b1 = 0;
+  for (int e = 118; e <= 125; ++e) {
+    const float y = __uint_as_float(((uint32_t)e << 23) | (i & 0x7fffffu));
+    b1 += div_two_eps(y) != y / 0.002f;
+  }
+  if (b0) atomicAdd(&bad[0], b0);
+  if (b1) atomicAdd(&bad[1], b1);
+}
+}  // namespace mz
+
+int mzs_selftest(int32_t device, int64_t* mismatches) {
+  if (!mismatches) return fail(nullptr, MZS_E_INVALID, "mzs_selftest: null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MZS_E_NODEVICE, "mzs_selftest: no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_selftest: bad device ordinal");
+  MZS_HIP(nullptr, hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  MZS_HIP(nullptr, hipMalloc(reinterpret_cast<void**>(&d), 16));
+  MZS_HIP(nullptr, hipMemset(d, 0, 16));
+  hipLaunchKernelGGL(mz::selftest_kernel, dim3((1u << 24) / 256), dim3(256), 0, nullptr, d);
+  unsigned long long h2[2] = {0, 0};
+  hipError_t e = hipMemcpy(h2, d, 16, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) return fail(nullptr, MZS_E_RUNTIME, "mzs_selftest: %s", hipGetErrorString(e));
+  mismatches[0] = (int64_t)h2[0];
+  mismatches[1] = (int64_t)h2[1];
+  return MZS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // root exploration noise
 // ---------------------------------------------------------------------------
 int mzs_dirichlet(int32_t device, const uint32_t key[2], float alpha, int32_t batch, int32_t num_actions,

@@ -478,14 +478,14 @@ struct Nets {
     for (int t = 1; t < FS; ++t) {
       e[t] = exp_neg2(xs[t] - m);
       e[t] = ok[t] ? e[t] : splat2(0.0f);
-      part = ok[t] ? part + e[t] : part;
+      part = part + e[t];  // (a masked slot adds +0: exact, no select needed)
     }
     const f32x2 sum = (f32x2){row_sum(part.x), row_sum(part.y)};
     f32x2 tp = splat2((float)(j - support)) * (f32x2){e[0].x / sum.x, e[0].y / sum.y};
 #pragma unroll
     for (int t = 1; t < FS; ++t) {
       const f32x2 tt = splat2((float)(j + 16 * t - support)) * (f32x2){e[t].x / sum.x, e[t].y / sum.y};
-      tp = ok[t] ? tp + tt : tp;
+      tp = tp + tt;  // (a masked slot's term is (+-n) * (+0 / sum) = +-0: adding it is exact)
     }
     const f32x2 dec = inv_scaling2((f32x2){row_sum(tp.x), row_sum(tp.y)});
     reward = dec.x;

@@ -136,3 +136,15 @@ def test_c_abi_rejects_bad_training_and_tower_arguments():
     with pytest.raises(ValueError, match="stem needs actions"):
         _lib.check(L.mzs_resnet_tower(C.byref(t), None))
     assert L.mzs_mlp_num_params(4, 8, 2, 10) == 4 * 8 + 8 + 2 * (8 * 16 + 16) + 16 * 21 + 21 + 16 * 2 + 2 + 2 * (10 * 16 + 16) + 16 * 21 + 21 + 16 * 8 + 8
+
+
+@pytest.mark.gpu
+def test_device_selftest_of_the_shortened_sqrt_and_division():
+    """mzs_selftest: sqrt_normal (v_sqrt_f32 + two exact residual checks) against the IEEE sqrt for every binary32 in
+    [1, 4), and the 3-op division by 0.002f against the IEEE division over 2^-9 .. 2^-2, ON the device."""
+    import ctypes as C
+
+    from muax_amd import _lib
+    out = (C.c_int64 * 2)(-1, -1)
+    _lib.check(_lib.load().mzs_selftest(0, C.byref(out)))
+    assert out[0] == 0 and out[1] == 0, list(out)

@@ -2,7 +2,7 @@
 
 The library is several translation units compiled in parallel (each `hipcc -c`, objects under muax_amd/lib/obj/)
 and linked into one shared object: the C-ABI and the step-wise / training / Dirichlet kernels (mz_api.hip), the
-fused act() kernel instances in three groups (mz_fused_g*.hip, listed in mz_instances.def) and the ResNet
+fused act() kernel instances in four groups (mz_fused_g*.hip, listed in mz_instances.def) and the ResNet
 recurrent kernel (mz_conv.hip).  Only the units whose sources changed are recompiled."""
 from __future__ import annotations
 
@@ -24,12 +24,17 @@ UNITS = {
     "mz_fused_g0.hip": _FUSED,
     "mz_fused_g1.hip": _FUSED,
     "mz_fused_g2.hip": _FUSED,
+    "mz_fused_g3.hip": _FUSED,
     "mz_conv.hip": ["mz_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
 }
 SOURCES = list(UNITS)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",
          "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA accumulators in VGPRs: the recurrent kernel's folds need no accvgpr moves
+         "-fno-slp-vectorize",  # SLP packs the two scalar adds of paired DPP butterflies into mov_dpp x 2 + v_pk_add (-1.6 % without)
          "-fPIC", "-Wno-unused-value"]
+# per-unit additions, measured on one box (profiles/r02_fused_variants.txt): the small-embedding fused instances are
+# issue-bound single wavefronts -- the scheduler's max-ILP strategy is worth 5 % there and costs the E = 32 instances 2 %
+UNIT_FLAGS = {u: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] for u in ("mz_fused_g0.hip", "mz_fused_g1.hip", "mz_fused_g2.hip")}
 
 
 def hipcc() -> str:
@@ -72,7 +77,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     jobs = []
     for unit in UNITS:
         if force or variant or _unit_stale(unit, tag):
-            cmd = [cc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit, tag)]
+            cmd = [cc] + FLAGS + UNIT_FLAGS.get(unit, []) + list(extra_flags) + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit, tag)]
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))

@@ -16,6 +16,7 @@ using FusedDispatch = int (*)(int mode, int device, const FusedParams& p, hipStr
 int fused_dispatch_g0(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 int fused_dispatch_g1(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 int fused_dispatch_g2(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
+int fused_dispatch_g3(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 // words per node of the HBM path array of a compact instance (the same for every instance with NMAX <= 64, A <= 4)
 constexpr int kCompactPathWords = 13;
 }  // namespace mz

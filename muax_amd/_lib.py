@@ -108,7 +108,7 @@ def load(build_if_missing: bool = True):
     L.mzs_mlp_set_weights.argtypes = [_vp, C.POINTER(MzsMlpWeights)]
     L.mzs_act_mlp.argtypes = [_vp, C.POINTER(MzsActArgs), _vp]
     L.mzs_act_mlp_host.argtypes = [_vp, C.POINTER(MzsActHostArgs), _vp]
-    L.mzs_selftest.argtypes = [C.c_int32, C.POINTER(C.c_int64 * 2)]
+    L.mzs_selftest.argtypes = [C.c_int32, C.POINTER(C.c_int64 * 4)]
     L.mzs_root.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.POINTER(C.c_uint32 * 2), _vp]
     L.mzs_root_gumbel.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32 * 2), _vp]
     L.mzs_select.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]

@@ -659,7 +659,8 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
 // ---------------------------------------------------------------------------
 namespace mz {
 __global__ void selftest_kernel(unsigned long long* bad) {
-  // every binary32 in [1, 4): sqrt_normal vs the IEEE sqrt; the same mantissas at 2^-9 .. 2^-2: div_two_eps vs x / 0.002f
+  // every binary32 in [1, 4): sqrt_normal vs the IEEE sqrt; the same mantissas at 2^-9 .. 2^-2: div_two_eps vs x / 0.002f;
+  // bad[2]: see below; bad[3]: reserved (0)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 2^24 threads
   const float x = __uint_as_float(0x3f800000u + i);
   unsigned long long b0 = sqrt_normal(x) != sqrtf(x);
@@ -668,8 +669,30 @@ __global__ void selftest_kernel(unsigned long long* bad) {
     const float y = __uint_as_float(((uint32_t)e << 23) | (i & 0x7fffffu));
     b1 += div_two_eps(y) != y / 0.002f;
   }
+  // shared-reciprocal division (rcp_newton2 / div_newton2) vs n / d: 2^24 denominators spread over [1, 64), each with
+  // numerators 0, 2^-100, d itself, d's predecessor and eight pseudo-random ones in [2^-100, d]
+  unsigned long long b2 = 0;
+  {
+    uint32_t h = i * 2654435761u + 0x9e3779b9u;
+    const float d = __uint_as_float(((127u + i % 6u) << 23) | (h >> 9));
+    const f32x2 dd = (f32x2){d, d};
+    const f32x2 y = rcp_newton2(dd);
+    float ns[12] = {0.0f, 0x1p-100f, d, __uint_as_float(__float_as_uint(d) - 1u)};
+    for (int k = 4; k < 12; ++k) {
+      h = h * 1664525u + 1013904223u;
+      const uint32_t ex = 27u + (h >> 7) % 106u;  // 2^-100 .. 2^5
+      h = h * 1664525u + 1013904223u;
+      const float n = __uint_as_float((ex << 23) | (h >> 9));
+      ns[k] = n <= d ? n : d * 0.37f;
+    }
+    for (int k = 0; k < 12; k += 2) {
+      const f32x2 q = div_newton2((f32x2){ns[k], ns[k + 1]}, dd, y);
+      b2 += (q.x != ns[k] / d) + (q.y != ns[k + 1] / d);
+    }
+  }
   if (b0) atomicAdd(&bad[0], b0);
   if (b1) atomicAdd(&bad[1], b1);
+  if (b2) atomicAdd(&bad[2], b2);
 }
 }  // namespace mz
 
@@ -681,15 +704,17 @@ int mzs_selftest(int32_t device, int64_t* mismatches) {
   if (device < 0 || device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_selftest: bad device ordinal");
   MZS_HIP(nullptr, hipSetDevice(device));
   unsigned long long* d = nullptr;
-  MZS_HIP(nullptr, hipMalloc(reinterpret_cast<void**>(&d), 16));
-  MZS_HIP(nullptr, hipMemset(d, 0, 16));
+  MZS_HIP(nullptr, hipMalloc(reinterpret_cast<void**>(&d), 32));
+  MZS_HIP(nullptr, hipMemset(d, 0, 32));
   hipLaunchKernelGGL(mz::selftest_kernel, dim3((1u << 24) / 256), dim3(256), 0, nullptr, d);
-  unsigned long long h2[2] = {0, 0};
-  hipError_t e = hipMemcpy(h2, d, 16, hipMemcpyDeviceToHost);
+  unsigned long long h2[4] = {0, 0, 0, 0};
+  hipError_t e = hipMemcpy(h2, d, 32, hipMemcpyDeviceToHost);
   hipFree(d);
   if (e != hipSuccess) return fail(nullptr, MZS_E_RUNTIME, "mzs_selftest: %s", hipGetErrorString(e));
   mismatches[0] = (int64_t)h2[0];
   mismatches[1] = (int64_t)h2[1];
+  mismatches[2] = (int64_t)h2[2];
+  mismatches[3] = (int64_t)h2[3];
   return MZS_OK;
 }
 

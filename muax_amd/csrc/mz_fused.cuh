@@ -369,7 +369,7 @@ struct Nets {
       const f32x2 gv = splat2(bcast<i>(g.x));
 #pragma unroll
       for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
-      pl = __builtin_fmaf(bcast<i>(g.y), pp2.w[i][0], pl);
+      fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
     });
     pi_logit = pl + pp2.b[0];
     float v_logits[C::FS];
@@ -416,9 +416,8 @@ struct Nets {
       const f32x2 hr = splat2(bcast<i>(h.x));
 #pragma unroll
       for (int q = 0; q < NP; ++q) rl[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl[q]);
-      const float hb = bcast<i>(h.y);
 #pragma unroll
-      for (int t = 0; t < C::ES; ++t) ns[t] = __builtin_fmaf(hb, dn2.w[i][t], ns[t]);
+      for (int t = 0; t < C::ES; ++t) fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
     });
 #pragma unroll
     for (int q = 0; q < NP; ++q) rl[q] = rl[q] + (f32x2){dr2.b[2 * q], dr2.b[2 * q + 1]};
@@ -444,7 +443,7 @@ struct Nets {
       const f32x2 gv = splat2(bcast<i>(g.x));
 #pragma unroll
       for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
-      pl = __builtin_fmaf(bcast<i>(g.y), pp2.w[i][0], pl);
+      fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
     });
 #pragma unroll
     for (int q = 0; q < NP; ++q) vl[q] = vl[q] + (f32x2){pv2.b[2 * q], pv2.b[2 * q + 1]};
@@ -471,20 +470,36 @@ struct Nets {
 #pragma unroll
     for (int t = 1; t < FS; ++t) m = ok[t] ? (f32x2){fmaxf(m.x, xs[t].x), fmaxf(m.y, xs[t].y)} : m;
     m = (f32x2){row_max<4>(m.x), row_max<4>(m.y)};
-    f32x2 e[FS];
-    e[0] = exp_neg2(xs[0] - m);
+    f32x2 e[FS], dl[FS];
+    dl[0] = xs[0] - m;
+    e[0] = exp_neg2(dl[0]);
     f32x2 part = e[0];
+    float lowest = fminf(dl[0].x, dl[0].y);
 #pragma unroll
     for (int t = 1; t < FS; ++t) {
-      e[t] = exp_neg2(xs[t] - m);
+      dl[t] = xs[t] - m;
+      lowest = fminf(lowest, fminf(dl[t].x, dl[t].y));
+      e[t] = exp_neg2(dl[t]);
       e[t] = ok[t] ? e[t] : splat2(0.0f);
       part = part + e[t];  // (a masked slot adds +0: exact, no select needed)
     }
     const f32x2 sum = (f32x2){row_sum(part.x), row_sum(part.y)};
-    f32x2 tp = splat2((float)(j - support)) * (f32x2){e[0].x / sum.x, e[0].y / sum.y};
+    // e / sum: the sums are in [1, F]; unless some lane of the wavefront holds a logit more than 69 below its
+    // row's maximum (an exp in (0, 2^-100): wave-uniform test, never seen with real networks) the quotients take the
+    // shared-reciprocal form of the division
+    f32x2 w[FS];
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < kDivNewtonMinArg) == 0, 1)) {
+      const f32x2 y = rcp_newton2(sum);
+#pragma unroll
+      for (int t = 0; t < FS; ++t) w[t] = div_newton2(e[t], sum, y);
+    } else {
+#pragma unroll
+      for (int t = 0; t < FS; ++t) w[t] = (f32x2){e[t].x / sum.x, e[t].y / sum.y};
+    }
+    f32x2 tp = splat2((float)(j - support)) * w[0];
 #pragma unroll
     for (int t = 1; t < FS; ++t) {
-      const f32x2 tt = splat2((float)(j + 16 * t - support)) * (f32x2){e[t].x / sum.x, e[t].y / sum.y};
+      const f32x2 tt = splat2((float)(j + 16 * t - support)) * w[t];
       tp = tp + tt;  // (a masked slot's term is (+-n) * (+0 / sum) = +-0: adding it is exact)
     }
     const f32x2 dec = inv_scaling2((f32x2){row_sum(tp.x), row_sum(tp.y)});
@@ -748,6 +763,9 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     for (int a = 0; a < A; ++a) inv_bits |= p.invalid[(size_t)r * A + a] ? (1u << a) : 0u;
   }
   int ncons = 0;  // gumbel policy: number of root actions sequential halving considers
+  // the root's JUMP word (row uniform): every selection starts from it, and the backup ends by producing it -- it
+  // stays in a register, and a selection that meets no near tie and no depth cut reads nothing from LDS
+  int root_jw;
   {
     float lg, pq[1];
     if constexpr (!C::GUMBEL) {
@@ -834,10 +852,11 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
       sc[a] = ((inv_bits >> a) & 1u) ? -INFINITY : sc[a];  // the root is only ever selected at depth 0
     }
     decide<A, C::TB>(sc, cidx, best, child, safe);
+    root_jw = jump_word(0, best, 0, !safe);
     if (j == 0) {
 #pragma unroll
       for (int a = 0; a < A; ++a) tree[C::SEL0 + 2 * a + 1] = sc[a];
-      itree[C::JUMP] = jump_word(0, best, 0, !safe);
+      itree[C::JUMP] = root_jw;
     }
   }
 
@@ -860,12 +879,23 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     if constexpr (C::GUMBEL) cv_next = p.visit_table[(size_t)ncons * S + (sim + 1 < S ? sim + 1 : S - 1)];
     // -- simulate (mctx search.simulate) through the JUMP words: one iteration per near tie --
     int parent, action, dP;
-    {
+    // children_index[parent, action] of the end point: a cached descent ends at an unexpanded edge (-1) unless it
+    // ends at a near tie (the noisy evaluation below names the child) or is cut at max_depth (read there)
+    int next = -1;
+    parent = root_jw & 0xfff;
+    action = (root_jw >> 12) & 0xf;
+    dP = (root_jw >> 16) & 0xff;
+    int depth = dP + 1;
+    // The common case -- no row of the wavefront meets a near tie or the depth limit -- is decided by the root's word
+    // alone; everything else (per-row control flow, key walk, noisy evaluations, the max_depth cut) sits behind ONE
+    // wave-uniform branch, so the common case pays no exec-mask bookkeeping for it.
+    bool rare = depth > max_depth;
+    if constexpr (C::TB) rare = rare || root_jw < 0;
+    if (__builtin_amdgcn_ballot_w64(rare) != 0) {
       uint32_t fk0 = 0, fk1 = 0, fs0 = 0, fs1 = 0;  // lazy key walk: rng_key / action_selection_key
       int fk_level = -1;                             // levels already split off (-1: not started)
-      int cur = 0;
+      int jw = root_jw;
       for (;;) {
-        const int jw = itree[__umul24((unsigned)cur, (unsigned)NS) + C::JUMP];
         parent = jw & 0xfff;
         action = (jw >> 12) & 0xf;
         dP = (jw >> 16) & 0xff;
@@ -884,6 +914,10 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
               fk1 = bcast_u<1>(word);
               fk_level = 0;
             }
+#ifdef MZ_PROFILE
+            prof_acc[14] += 1;                               // near-tie evaluations
+            prof_acc[15] += (uint64_t)(dP + 1 - fk_level);   // key-walk levels hashed for them
+#endif
             while (fk_level <= dP) {
               // rng_key, action_selection_key = split(rng_key): lanes 0/1 hash one block each
               uint32_t x0 = (uint32_t)(j & 1), x1 = 2u + (uint32_t)(j & 1);
@@ -914,26 +948,29 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
               bn = take ? cidx[a] : bn;
             }
             action = best;
+            next = bn;
             if (bn >= 0 && dP + 1 < max_depth) {
-              cur = bn;  // the noisy choice is an expanded child within reach: keep descending from it
+              // the noisy choice is an expanded child within reach: keep descending from it
+              jw = itree[__umul24((unsigned)bn, (unsigned)NS) + C::JUMP];
+              next = -1;
               continue;
             }
           }
         }
         break;
       }
+      depth = dP + 1;
+      if (depth > max_depth) {
+        // the cached descent overshoots max_depth: stop at level max_depth - 1 of the same path
+        depth = max_depth;
+        const int* pb = C::PH ? gpath + (size_t)parent * C::PATHW : itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
+        const int e = depth - 1;
+        const int ent = (pb[(e * C::ENTRY_BITS) >> 5] >> ((e * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
+        parent = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
+        action = ent >> C::ENTRY_ACT_SHIFT;
+        next = itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
+      }
     }
-    int depth = dP + 1;
-    if (depth > max_depth) {
-      // the cached descent overshoots max_depth: stop at level max_depth - 1 of the same path
-      depth = max_depth;
-      const int* pb = C::PH ? gpath + (size_t)parent * C::PATHW : itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
-      const int e = depth - 1;
-      const int ent = (pb[(e * C::ENTRY_BITS) >> 5] >> ((e * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
-      parent = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
-      action = ent >> C::ENTRY_ACT_SHIFT;
-    }
-    const int next = itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
     depth_total += depth;
     MZ_TICK(1);  // select
     const bool fresh = next < 0;
@@ -944,7 +981,10 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
 #pragma unroll
     for (int t = 0; t < C::ES; ++t)
       if constexpr (C::EMB_LDS) {
-        sp[t] = (j + 16 * t < E) ? tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + j + 16 * t] : 0.0f;
+        // (an unconditional read at a clamped index + a select: no exec-mask region)
+        const int jc = j + 16 * t < E ? j + 16 * t : E - 1;
+        const float v = tree[__umul24((unsigned)parent, (unsigned)NS) + C::EMB0 + jc];
+        sp[t] = (j + 16 * t < E) ? v : 0.0f;
       } else {
         // the row was requested at the end of the previous simulation (from the root's fresh JUMP word);
         // only a near-tie redraw or a max_depth cut can have picked another parent
@@ -1025,7 +1065,6 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
       wmax = max(wmax, __builtin_amdgcn_readlane(depth, 16));
       wmax = max(wmax, __builtin_amdgcn_readlane(depth, 32));
       wmax = max(wmax, __builtin_amdgcn_readlane(depth, 48));
-      const int* ppath = itree + __umul24((unsigned)parent, (unsigned)NS) + C::PATH0;
       float G = value;        // leaf_value walking up (row uniform)
       float carry_v = value;  // node value of the entry just below this chunk
       int carry_n = -1;       // node index of the entry just below this chunk
@@ -1038,11 +1077,15 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         int pn, pa;
         {
           const int ec = e < depth - 1 ? e : 0;
-          int pword;
-          if constexpr (C::PH)  // word (ec * ENTRY_BITS) / 32 of the parent's path sits in that lane of this row's ppw
-            pword = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + ((ec * C::ENTRY_BITS) >> 5)), ppw[0]);
-          else
-            pword = ppath[(ec * C::ENTRY_BITS) >> 5];
+          // word (ec * ENTRY_BITS) / 32 of the parent's path sits in that lane (and slot) of this row's ppw, loaded
+          // before the network pass: a cross-lane fetch, not a second LDS read behind the expansion's stores
+          const int widx = (ec * C::ENTRY_BITS) >> 5;
+          int pword = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + (widx & 15)), ppw[0]);
+#pragma unroll
+          for (int t = 1; t < C::PATHS; ++t) {
+            const int o = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + (widx & 15)), ppw[t]);
+            pword = (widx >> 4) == t ? o : pword;
+          }
           const int ent = (pword >> ((ec * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
           pn = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
           pa = ent >> C::ENTRY_ACT_SHIFT;
@@ -1097,15 +1140,15 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         // Steps above the wave's deepest entry are identities for every row and are jumped over.
         const int kstart = min(15, wmax - 16 * c);
         float Gt = ge * G;
-#define MZ_GSTEP                                                                             \
-  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf"  \
-               : "+v"(Gt) : "v"(G), "v"(ge));                                                \
-  G = Gt + re;
-        if (kstart >= 12) { MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP }
-        if (kstart >= 8) { MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP }
-        if (kstart >= 4) { MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP }
-        MZ_GSTEP MZ_GSTEP MZ_GSTEP MZ_GSTEP
-#undef MZ_GSTEP
+#define MZ_GSTEP_TXT "s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32 %1, %0, %3\n\t"
+#define MZ_GSTEP4 \
+  asm volatile(MZ_GSTEP_TXT MZ_GSTEP_TXT MZ_GSTEP_TXT MZ_GSTEP_TXT : "+v"(Gt), "+v"(G) : "v"(ge), "v"(re));
+        if (kstart >= 12) { MZ_GSTEP4 }
+        if (kstart >= 8) { MZ_GSTEP4 }
+        if (kstart >= 4) { MZ_GSTEP4 }
+        MZ_GSTEP4
+#undef MZ_GSTEP4
+#undef MZ_GSTEP_TXT
         const float Gown = G;
         G = bcast<0>(G);  // carried into the chunk above
         MZ_TICKW(8);  // G chain
@@ -1149,17 +1192,20 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         for (int a = 1; a < A; ++a) jchild = (best == a) ? jch[a] : jchild;
         const int jwd0 = jump_word(pn, best, e, !safe);
         int jwd = (safe && child >= 0 && !inherit0) ? jchild : jwd0;
-        int inh = inherit0 ? 1 : 0;
+        // log-step resolution of "inherit from the next entry": done = all ones once a lane's word is final.  A lane
+        // reading past the row end sees done = 0 (bound_ctrl zero fill) and stays open; what is still open after the
+        // 15 hops inherits from the chunk below (carry_j)
+        int done = inherit0 ? 0 : -1;
 #define MZ_JSCAN(d)                                                                              \
   {                                                                                              \
-    const int jn = __builtin_amdgcn_update_dpp(carry_j, jwd, 0x100 + d, 0xf, 0xf, false);        \
-    const int in_ = __builtin_amdgcn_update_dpp(0, inh, 0x100 + d, 0xf, 0xf, false);             \
-    jwd = inh ? jn : jwd;                                                                        \
-    inh = inh ? in_ : 0;                                                                         \
+    const int jn = __builtin_amdgcn_update_dpp(0, jwd, 0x100 + d, 0xf, 0xf, true);               \
+    const int dn = __builtin_amdgcn_update_dpp(0, done, 0x100 + d, 0xf, 0xf, true);              \
+    jwd = (jwd & done) | (jn & ~done);                                                           \
+    done = done | dn;                                                                            \
   }
         MZ_JSCAN(1) MZ_JSCAN(2) MZ_JSCAN(4) MZ_JSCAN(8)
 #undef MZ_JSCAN
-        jwd = inh ? carry_j : jwd;  // 15 hops covered; a lane still inheriting reaches past the row end
+        jwd = (jwd & done) | (carry_j & ~done);
         carry_j = bcast_i<0>(jwd);
         MZ_TICKW(11);  // decide + JUMP scan
         if (valid) {
@@ -1180,6 +1226,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
           ndi[C::ST0 + C::STW * pa + 2] = cin;
         }
       }
+      root_jw = carry_j;  // entry 0 is the root: its refreshed JUMP word
       if constexpr (!C::EMB_LDS) {
         pref_parent = carry_j & 0xfff;  // the root's refreshed JUMP word: where the next descent ends
 #pragma unroll

@@ -68,6 +68,18 @@ MZ_DEV int bcast_i(int x) { return dpp_i<kDppBcast0 + I>(x); }
 template <int I>
 MZ_DEV uint32_t bcast_u(uint32_t x) { return (uint32_t)dpp_i<kDppBcast0 + I>((int)x); }
 
+// acc += (lane I of this row of x) * w as ONE instruction: v_fmac_f32 with a row_newbcast DPP source (a fused
+// multiply-add, the same rounding as __builtin_fmaf(bcast<I>(x), w, acc)) -- no separate broadcast move.  FIRST opens
+// a chain: x may have been written by the instruction just before, and a DPP read of a fresh VGPR needs two wait
+// states the assembler does not insert inside inline assembly; the later links of the chain depend on the first.
+template <int I, bool FIRST>
+MZ_DEV void fmac_bcast(float& acc, float x, float w) {
+  if constexpr (FIRST)
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(I));
+  else
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(I));
+}
+
 template <int STEP>
 struct Bfly;
 template <> struct Bfly<0> { static constexpr int ctrl = kDppXor1; };
@@ -162,6 +174,9 @@ MZ_DEV float exp_core(float x, int& k) {
   return __builtin_fmaf(p, rr, r);
 }
 MZ_DEV float pow2i(int k) { return u2f((uint32_t)(k + 127) << 23); }
+constexpr float kRintShift = 12582912.0f;  // 1.5 * 2^23
+// 2^k from the shifted value's bits (bits(1.5 * 2^23) + k): the constant's bits leave through the top of the shift
+MZ_DEV float pow2_shifted(int bits) { return u2f(((uint32_t)bits << 23) + 0x3f800000u); }
 
 MZ_DEV float exp_neg(float x) {  // x <= 88; exact 0 below -87
   int k;
@@ -237,12 +252,35 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator tile (mz_train.cuh, mz_conv.cuh)
 MZ_DEV f32x2 splat2(float x) { return (f32x2){x, x}; }
 MZ_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// n / d for quotients that share their denominators (the support decode: every e_i / sum): the hardware's own IEEE
+// division expansion -- v_rcp_f32, one Newton step on the reciprocal, the quotient and two residual corrections --
+// with the reciprocal refined ONCE per denominator, the rest in packed form, and without v_div_scale / v_div_fixup,
+// which are identities where this is used: d in [1, 64], n = 0 or 2^-100 <= n <= d (no operand is rescaled, every
+// residual is exact).  The caller guards the range; mzs_selftest compares it with n / d on the device.
+MZ_DEV f32x2 rcp_newton2(f32x2 d) {
+  const f32x2 y0 = (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f32x2 e = fma2(-d, y0, splat2(1.0f));
+  return fma2(e, y0, y0);
+}
+MZ_DEV f32x2 div_newton2(f32x2 n, f32x2 d, f32x2 y) {
+  f32x2 q = n * y;
+  f32x2 r = fma2(-d, q, n);
+  q = fma2(r, y, q);
+  r = fma2(-d, q, n);
+  return fma2(r, y, q);
+}
+// exp_neg of an argument >= this is 0 or >= 2^-100 (exp(-69) = 1.08e-30 = 2^-99.5)
+constexpr float kDivNewtonMinArg = -69.0f;
+
 MZ_DEV f32x2 exp_core2(f32x2 x, int& k0, int& k1) {
   const float LOG2E = 1.44269504088896341f;
   const float LN2_HI = 6.93145752e-1f;
   const float LN2_LO = 1.42860677e-6f;
   f32x2 t = x * splat2(LOG2E);
-  f32x2 kf = (f32x2){__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  // rint through the 1.5 * 2^23 shift (|t| < 2^22: the same ties-to-even integer as rintf), both components in
+  // packed adds; the integer is the low mantissa field of the shifted value, so pow2i needs no conversion
+  const f32x2 sh = t + splat2(kRintShift);
+  f32x2 kf = sh - splat2(kRintShift);
   f32x2 r = fma2(kf, splat2(-LN2_HI), x);
   r = fma2(kf, splat2(-LN2_LO), r);
   f32x2 p = splat2(1.0f / 5040.0f);
@@ -252,15 +290,15 @@ MZ_DEV f32x2 exp_core2(f32x2 x, int& k0, int& k1) {
   p = fma2(p, r, splat2(1.0f / 6.0f));
   p = fma2(p, r, splat2(0.5f));
   f32x2 rr = r * r;
-  k0 = (int)kf.x;
-  k1 = (int)kf.y;
+  k0 = (int)f2u(sh.x);  // = bits(1.5 * 2^23) + k: callers shift it left by 23 or compare kf with 0
+  k1 = (int)f2u(sh.y);
   return fma2(p, rr, r);
 }
 MZ_DEV f32x2 exp_neg2(f32x2 x) {
   int k0, k1;
   f32x2 xc = (f32x2){fmaxf(x.x, -87.0f), fmaxf(x.y, -87.0f)};
   f32x2 q = exp_core2(xc, k0, k1);
-  f32x2 e = (splat2(1.0f) + q) * (f32x2){pow2i(k0), pow2i(k1)};
+  f32x2 e = (splat2(1.0f) + q) * (f32x2){pow2_shifted(k0), pow2_shifted(k1)};
   return (f32x2){x.x < -87.0f ? 0.0f : e.x, x.y < -87.0f ? 0.0f : e.y};
 }
 MZ_DEV f32x2 elu2(f32x2 x) {
@@ -268,8 +306,9 @@ MZ_DEV f32x2 elu2(f32x2 x) {
   int k0, k1;
   f32x2 xc = (f32x2){fmaxf(xn.x, -87.0f), fmaxf(xn.y, -87.0f)};
   f32x2 q = exp_core2(xc, k0, k1);
-  f32x2 big = (splat2(1.0f) + q) * (f32x2){pow2i(k0), pow2i(k1)} - splat2(1.0f);
-  float e0 = (k0 == 0) ? q.x : big.x, e1 = (k1 == 0) ? q.y : big.y;  // (the clamp at -87 already yields exactly -1 below it)
+  f32x2 big = (splat2(1.0f) + q) * (f32x2){pow2_shifted(k0), pow2_shifted(k1)} - splat2(1.0f);
+  constexpr int kZero = 0x4B400000;  // bits(1.5 * 2^23): k == 0
+  float e0 = (k0 == kZero) ? q.x : big.x, e1 = (k1 == kZero) ? q.y : big.y;  // (the clamp at -87 already yields exactly -1 below it)
   return (f32x2){x.x > 0.0f ? x.x : e0, x.y > 0.0f ? x.y : e1};
 }
 MZ_DEV f32x2 inv_scaling2(f32x2 x) {

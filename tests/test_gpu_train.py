@@ -141,10 +141,11 @@ def test_c_abi_rejects_bad_training_and_tower_arguments():
 @pytest.mark.gpu
 def test_device_selftest_of_the_shortened_sqrt_and_division():
     """mzs_selftest: sqrt_normal (v_sqrt_f32 + two exact residual checks) against the IEEE sqrt for every binary32 in
-    [1, 4), and the 3-op division by 0.002f against the IEEE division over 2^-9 .. 2^-2, ON the device."""
+    [1, 4), the 3-op division by 0.002f against the IEEE division over 2^-9 .. 2^-2, and the shared-reciprocal division
+    of the support decode against n / d for 2^24 denominators in [1, 64) x 12 numerators, ON the device."""
     import ctypes as C
 
     from muax_amd import _lib
-    out = (C.c_int64 * 2)(-1, -1)
+    out = (C.c_int64 * 4)(-1, -1, -1, -1)
     _lib.check(_lib.load().mzs_selftest(0, C.byref(out)))
-    assert out[0] == 0 and out[1] == 0, list(out)
+    assert list(out) == [0, 0, 0, 0], list(out)

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "bin", "libmzsearch_prof.so")
+LIB = os.environ.get("MZ_PROF_LIB", os.path.join(ROOT, "tools", "bin", "libmzsearch_prof.so"))  # variant A/Bs: MZ_PROF_LIB + MZ_PROF_FLAGS
 PHASES = ["loop top", "select (jump words)", "network pass", "-", "expand stores", "backward + refresh",
           "bw: path entry", "bw: node loads", "bw: G chain", "bw: value update", "bw: scores",
           "bw: decide + JUMP scan", "prologue (x S)", "epilogue (x S)", "-", "-"]
@@ -18,7 +18,7 @@ PHASES = ["loop top", "select (jump words)", "network pass", "-", "expand stores
 
 def build():
     from muax_amd import _build
-    print(_build.build(extra_flags=["-DMZ_PROFILE"], out=LIB))
+    print(_build.build(extra_flags=["-DMZ_PROFILE"] + os.environ.get("MZ_PROF_FLAGS", "").split(), out=LIB))
 
 
 def run():
@@ -45,7 +45,7 @@ def run():
         s.act_mlp(obs, (0, i), dirichlet_noise=noise)
     torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
-    tot = p.sum(1)
+    tot = p[:, :14].sum(1)
     print(f"waves {waves}; cycles per wave: mean {tot.mean():.0f} max {tot.max():.0f} min {tot.min():.0f}")
     depth = s.depth_sum.cpu().numpy().reshape(waves, 4)
     print(f"mean selection depth {depth.mean() / S:.2f}; per-wave sum of max-of-4 is not tracked here")
@@ -54,6 +54,8 @@ def run():
             continue
         print(f"  {name:26s} {p[:, k].mean() / S:9.0f} cycles/sim  ({100 * p[:, k].sum() / tot.sum():5.1f}%)   "
               f"slowest wave {p[:, k].max() / S:9.0f}")
+    print(f"near-tie evaluations per simulation (lane 0's row) {p[:, 14].mean() / S:.3f}, key-walk levels hashed per simulation "
+          f"{p[:, 15].mean() / S:.3f}")
     slow = int(tot.argmax())
     print("slowest wave", slow, "phases/sim:", (p[slow] / S).round(0).tolist(), "depth sums", depth[slow].tolist())
 

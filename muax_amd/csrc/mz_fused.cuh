@@ -520,7 +520,7 @@ MZ_DEV float div_small(float x, float d, float y) {
   return __builtin_fmaf(r, y, q0);
 }
 // rcp1[a] = RN(1 / (vis[a] + 1)) from the LDS table
-template <int A>
+template <int A, bool SHARED_RCP = false>
 MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const float (&val)[A],
                         const int (&vis)[A], const float (&rew)[A], const float (&dis)[A],
                         const float (&rcp1)[A], float (&score)[A]) {
@@ -534,11 +534,38 @@ MZ_DEV void puct_scores(float nval, float tn, const float (&prob)[A], const floa
     hi = fmaxf(hi, safe);
   }
   float span = fmaxf(hi - lo, 1e-8f);
+  float num[A], vs[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) num[a] = (vis[a] > 0 ? q[a] : lo) - lo;
+  bool plain = true;
+  if constexpr (SHARED_RCP && A >= 2) {
+    // the A quotients share their denominator: one refined reciprocal, numerators in packed pairs (div_newton2) --
+    // valid while every numerator is 0 or >= 2^-100 and the span is below 2^100 (wave-uniform test; else IEEE division)
+    uint32_t low = f2u(num[0]) - 1u;  // 0 wraps to the top: only (0, 2^-100) fails the test
+#pragma unroll
+    for (int a = 1; a < A; ++a) low = min(low, f2u(num[a]) - 1u);
+    const bool risky = low < f2u(0x1p-100f) - 1u || span >= 0x1p100f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(risky) == 0, 1)) {
+      plain = false;
+      const float y0 = __builtin_amdgcn_rcpf(span);
+      const float y = __builtin_fmaf(__builtin_fmaf(-span, y0, 1.0f), y0, y0);
+#pragma unroll
+      for (int a = 0; a < A; a += 2) {
+        const int b = a + 1 < A ? a + 1 : a;
+        const f32x2 qq = div_newton2((f32x2){num[a], num[b]}, splat2(span), splat2(y));
+        vs[a] = qq.x;
+        vs[b] = qq.y;
+      }
+    }
+  }
+  if (plain) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) vs[a] = num[a] / span;
+  }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    float value_score = ((vis[a] > 0 ? q[a] : lo) - lo) / span;
     float policy_score = div_small(tn * prob[a], (float)(vis[a] + 1), rcp1[a]);
-    score[a] = value_score + policy_score;
+    score[a] = vs[a] + policy_score;
   }
 }
 
@@ -1061,10 +1088,15 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     // entries 0..depth-1 are the (parent, action) edges of the path, entry `depth` is the leaf.
     {
       // wave-uniform trip counts: the deepest of the wave's four rows
-      int wmax = __builtin_amdgcn_readlane(depth, 0);
-      wmax = max(wmax, __builtin_amdgcn_readlane(depth, 16));
-      wmax = max(wmax, __builtin_amdgcn_readlane(depth, 32));
-      wmax = max(wmax, __builtin_amdgcn_readlane(depth, 48));
+      int wmax;
+      {
+        const int d0 = __builtin_amdgcn_readlane(depth, 0), d1 = __builtin_amdgcn_readlane(depth, 16);
+        const int d2 = __builtin_amdgcn_readlane(depth, 32), d3 = __builtin_amdgcn_readlane(depth, 48);
+        int m01, m23;  // (scalar max: the compiler otherwise moves two of the four back into VGPRs for a v_max3)
+        asm("s_max_i32 %0, %1, %2" : "=s"(m01) : "s"(d0), "s"(d1) : "scc");
+        asm("s_max_i32 %0, %1, %2" : "=s"(m23) : "s"(d2), "s"(d3) : "scc");
+        asm("s_max_i32 %0, %1, %2" : "=s"(wmax) : "s"(m01), "s"(m23) : "scc");
+      }
       float G = value;        // leaf_value walking up (row uniform)
       float carry_v = value;  // node value of the entry just below this chunk
       int carry_n = -1;       // node index of the entry just below this chunk
@@ -1166,7 +1198,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         MZ_TICKW(9);  // value update
         float sc[A];
         if constexpr (!C::GUMBEL) {
-          puct_scores<A>(nval, tn_rc.x, prob, val, vis, rew, dis, rcp1, sc);
+          puct_scores<A, true>(nval, tn_rc.x, prob, val, vis, rew, dis, rcp1, sc);
 #pragma unroll
           for (int a = 0; a < A; ++a)  // root_invalid_actions: the root is only ever selected at depth 0
             sc[a] = (pn == 0 && ((inv_bits >> a) & 1u)) ? -INFINITY : sc[a];

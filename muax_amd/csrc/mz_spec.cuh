@@ -302,9 +302,9 @@ MZ_DEV f32x2 exp_neg2(f32x2 x) {
   return (f32x2){x.x < -87.0f ? 0.0f : e.x, x.y < -87.0f ? 0.0f : e.y};
 }
 MZ_DEV f32x2 elu2(f32x2 x) {
-  f32x2 xn = (f32x2){fminf(x.x, 0.0f), fminf(x.y, 0.0f)};
   int k0, k1;
-  f32x2 xc = (f32x2){fmaxf(xn.x, -87.0f), fmaxf(xn.y, -87.0f)};
+  // max(min(x, 0), -87) as one v_med3_f32 per component
+  f32x2 xc = (f32x2){__builtin_amdgcn_fmed3f(x.x, -87.0f, 0.0f), __builtin_amdgcn_fmed3f(x.y, -87.0f, 0.0f)};
   f32x2 q = exp_core2(xc, k0, k1);
   f32x2 big = (splat2(1.0f) + q) * (f32x2){pow2_shifted(k0), pow2_shifted(k1)} - splat2(1.0f);
   constexpr int kZero = 0x4B400000;  // bits(1.5 * 2^23): k == 0

@@ -124,6 +124,11 @@ struct FusedCfg {
   static constexpr int QT = MODE_ == 3 ? 1 : 0;
   static constexpr int H = kHidden;
   static constexpr int ES = (E + 15) / 16;
+  // first layers over a long embedding: two v_fmac_f32_dpp chains per input instead of broadcast move + packed fma
+  // (under register pressure the compiler funnels every broadcast through one temporary and pads each term)
+  static constexpr bool L1_DPP = E_ > 16;
+  // ... and the second layers as blocks of v_fmac_f32_dpp chains (two logit slots, two state slots, one policy slot)
+  static constexpr bool L2_BLOCK = L1_DPP && FS_ == 2 && (E_ + 15) / 16 == 2 && A_ <= 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----
   //   [SEL0  ..) A x {child index, cached pUCT score}   (4-byte aligned only: the stride is odd)
   //   [HDR0  ..) visits, value, JUMP word, raw value
@@ -348,17 +353,33 @@ struct Nets {
     d1.load(p.dr_w1, p.dr_b1, p.dn_w1, p.dn_b1, j);
     dr2.load(p.dr_w2, p.dr_b2, j, p.F); dn2.load(p.dn_w2, p.dn_b2, j);
   }
+  // x . (W0, W1) for a row-distributed x: the two first layers that share an input, as (net 0, net 1) pairs
+  template <class W>
+  MZ_DEV f32x2 first_layers(const float (&x)[C::ES], const W& w) const {
+    if constexpr (C::L1_DPP) {
+      static_assert(C::E % 8 == 0, "eight inputs per statement");
+      float h0 = 0.0f, h1 = 0.0f;
+      StaticFor<0, C::E / 8>::run([&](auto ic) {
+        constexpr int i = 8 * decltype(ic)::value;
+        fmac_bcast_pair8<(i & 15), i == 0>(h0, h1, x[i >> 4], &w[i]);
+      });
+      return (f32x2){h0, h1};
+    } else {
+      f32x2 h = splat2(0.0f);
+      StaticFor<0, C::E>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        h = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h);
+      });
+      return h;
+    }
+  }
   // Prediction (muax/nn.py:73-90) + value decode
   MZ_DEV void predict(const float (&s)[C::ES], int j, int support, int F, float& value,
                       float& pi_logit) const {
     // same packed chains as forward() below: every weight register then has ONE pairing in the whole
     // kernel (a second, scalar use made the compiler re-pair them through scratch memory)
     constexpr int NP = C::FS / 2;
-    f32x2 g = splat2(0.0f);
-    StaticFor<0, C::E>::run([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      g = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), p1.w[i], g);
-    });
+    f32x2 g = first_layers(s, p1.w);
     g = elu2(g + p1.b);
     f32x2 vl[NP];
 #pragma unroll
@@ -391,11 +412,7 @@ struct Nets {
                       float (&ns)[C::ES]) const {
     constexpr int E = C::E, A = C::A, FS = C::FS, NP = C::FS / 2;
     // Dynamic, first layer: [s, onehot(a)] -> 16 hidden units of the reward net and of the state net
-    f32x2 h = splat2(0.0f);
-    StaticFor<0, E>::run([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      h = fma2(splat2(bcast<(i & 15)>(s[i >> 4])), d1.w[i], h);
-    });
+    f32x2 h = first_layers(s, d1.w);
     {
       f32x2 wsel = d1.wa[0];
       StaticFor<1, A>::run([&](auto ac) {
@@ -411,14 +428,24 @@ struct Nets {
     for (int q = 0; q < NP; ++q) rl[q] = splat2(0.0f);
 #pragma unroll
     for (int t = 0; t < C::ES; ++t) ns[t] = 0.0f;
-    StaticFor<0, kHidden>::run([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const f32x2 hr = splat2(bcast<i>(h.x));
+    if constexpr (C::L2_BLOCK) {
+      // (two logit slots + two state slots: four v_fmac_f32_dpp chains, four inputs per statement)
+      float r0 = 0.0f, r1 = 0.0f;
+      StaticFor<0, kHidden / 4>::run([&](auto ic) {
+        constexpr int i = 4 * decltype(ic)::value;
+        fmac_bcast_2x2<i>(r0, r1, ns[0], ns[1], h.x, h.y, &dr2.w[i], &dn2.w[i]);
+      });
+      rl[0] = (f32x2){r0, r1};
+    } else {
+      StaticFor<0, kHidden>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const f32x2 hr = splat2(bcast<i>(h.x));
 #pragma unroll
-      for (int q = 0; q < NP; ++q) rl[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl[q]);
+        for (int q = 0; q < NP; ++q) rl[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl[q]);
 #pragma unroll
-      for (int t = 0; t < C::ES; ++t) fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
-    });
+        for (int t = 0; t < C::ES; ++t) fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
+      });
+    }
 #pragma unroll
     for (int q = 0; q < NP; ++q) rl[q] = rl[q] + (f32x2){dr2.b[2 * q], dr2.b[2 * q + 1]};
 #pragma unroll
@@ -428,23 +455,28 @@ struct Nets {
     float x[C::ES];
 #pragma unroll
     for (int t = 0; t < C::ES; ++t) x[t] = pred_on_parent ? s[t] : ns[t];
-    f32x2 g = splat2(0.0f);
-    StaticFor<0, E>::run([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      g = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), p1.w[i], g);
-    });
+    f32x2 g = first_layers(x, p1.w);
     g = elu2(g + p1.b);
     f32x2 vl[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) vl[q] = splat2(0.0f);
     float pl = 0.0f;
-    StaticFor<0, kHidden>::run([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const f32x2 gv = splat2(bcast<i>(g.x));
+    if constexpr (C::L2_BLOCK) {
+      float v0 = 0.0f, v1 = 0.0f;
+      StaticFor<0, kHidden / 4>::run([&](auto ic) {
+        constexpr int i = 4 * decltype(ic)::value;
+        fmac_bcast_2x1<i>(v0, v1, pl, g.x, g.y, &pv2.w[i], &pp2.w[i]);
+      });
+      vl[0] = (f32x2){v0, v1};
+    } else {
+      StaticFor<0, kHidden>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const f32x2 gv = splat2(bcast<i>(g.x));
 #pragma unroll
-      for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
-      fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
-    });
+        for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
+        fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
+      });
+    }
 #pragma unroll
     for (int q = 0; q < NP; ++q) vl[q] = vl[q] + (f32x2){pv2.b[2 * q], pv2.b[2 * q + 1]};
     pi_logit = pl + pp2.b[0];

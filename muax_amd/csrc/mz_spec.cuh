@@ -80,6 +80,85 @@ MZ_DEV void fmac_bcast(float& acc, float x, float w) {
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(I));
 }
 
+// Eight links of TWO such chains that share their input (acc0 += x[lane B + k] * w[k].x, acc1 += ... * w[k].y,
+// k = 0..7, B = 0 or 8) as one statement: between separate asm statements on the same accumulator hipcc pads a wait
+// state each time.  The two chains alternate, so no link waits for the one just before it.
+#define MZ_FB_LINE(k, b) "v_fmac_f32_dpp %0, %2, %" #k " row_newbcast:" #b " row_mask:0xf bank_mask:0xf\n\t"
+#define MZ_FB_LINE2(k, b) "v_fmac_f32_dpp %1, %2, %" #k " row_newbcast:" #b " row_mask:0xf bank_mask:0xf\n\t"
+#define MZ_FB_OPS(w)                                                                                        \
+  "v"(w[0].x), "v"(w[0].y), "v"(w[1].x), "v"(w[1].y), "v"(w[2].x), "v"(w[2].y), "v"(w[3].x), "v"(w[3].y), \
+      "v"(w[4].x), "v"(w[4].y), "v"(w[5].x), "v"(w[5].y), "v"(w[6].x), "v"(w[6].y), "v"(w[7].x), "v"(w[7].y)
+template <int B, bool FIRST, class W>
+MZ_DEV void fmac_bcast_pair8(float& acc0, float& acc1, float x, const W* w) {
+  static_assert(B == 0 || B == 8, "");
+  static_assert(!FIRST || B == 0, "");
+  if constexpr (FIRST)  // (x may be fresh: the two wait states of a DPP read)
+    asm("s_nop 1\n\t" MZ_FB_LINE(3, 0) MZ_FB_LINE2(4, 0) MZ_FB_LINE(5, 1) MZ_FB_LINE2(6, 1) MZ_FB_LINE(7, 2) MZ_FB_LINE2(8, 2)
+        MZ_FB_LINE(9, 3) MZ_FB_LINE2(10, 3) MZ_FB_LINE(11, 4) MZ_FB_LINE2(12, 4) MZ_FB_LINE(13, 5) MZ_FB_LINE2(14, 5)
+        MZ_FB_LINE(15, 6) MZ_FB_LINE2(16, 6) MZ_FB_LINE(17, 7) MZ_FB_LINE2(18, 7)
+        : "+v"(acc0), "+v"(acc1) : "v"(x), MZ_FB_OPS(w));
+  else if constexpr (B == 0)
+    asm(MZ_FB_LINE(3, 0) MZ_FB_LINE2(4, 0) MZ_FB_LINE(5, 1) MZ_FB_LINE2(6, 1) MZ_FB_LINE(7, 2) MZ_FB_LINE2(8, 2)
+        MZ_FB_LINE(9, 3) MZ_FB_LINE2(10, 3) MZ_FB_LINE(11, 4) MZ_FB_LINE2(12, 4) MZ_FB_LINE(13, 5) MZ_FB_LINE2(14, 5)
+        MZ_FB_LINE(15, 6) MZ_FB_LINE2(16, 6) MZ_FB_LINE(17, 7) MZ_FB_LINE2(18, 7)
+        : "+v"(acc0), "+v"(acc1) : "v"(x), MZ_FB_OPS(w));
+  else
+    asm(MZ_FB_LINE(3, 8) MZ_FB_LINE2(4, 8) MZ_FB_LINE(5, 9) MZ_FB_LINE2(6, 9) MZ_FB_LINE(7, 10) MZ_FB_LINE2(8, 10)
+        MZ_FB_LINE(9, 11) MZ_FB_LINE2(10, 11) MZ_FB_LINE(11, 12) MZ_FB_LINE2(12, 12) MZ_FB_LINE(13, 13) MZ_FB_LINE2(14, 13)
+        MZ_FB_LINE(15, 14) MZ_FB_LINE2(16, 14) MZ_FB_LINE(17, 15) MZ_FB_LINE2(18, 15)
+        : "+v"(acc0), "+v"(acc1) : "v"(x), MZ_FB_OPS(w));
+}
+#undef MZ_FB_LINE
+#undef MZ_FB_LINE2
+#undef MZ_FB_OPS
+
+// Four links (lanes B .. B + 3 of the inputs) of the second-layer chains of a network pass in one statement:
+// accumulators a0, a1 (+ a2, a3) fed from xa, accumulators fed from xb; w?[k] = this lane's weights for input B + k.
+#define MZ_F(acc, x, w, b) "v_fmac_f32_dpp %" #acc ", %" #x ", %" #w " row_newbcast:" #b " row_mask:0xf bank_mask:0xf\n\t"
+// 2 + 2 chains: %0 %1 <- %4 (xa), %2 %3 <- %5 (xb); weights %6.. in (k, chain) order
+#define MZ_F4(b0, b1, b2, b3)                                                                          \
+  MZ_F(0, 4, 6, b0) MZ_F(1, 4, 7, b0) MZ_F(2, 5, 8, b0) MZ_F(3, 5, 9, b0)                \
+      MZ_F(0, 4, 10, b1) MZ_F(1, 4, 11, b1) MZ_F(2, 5, 12, b1) MZ_F(3, 5, 13, b1)                      \
+      MZ_F(0, 4, 14, b2) MZ_F(1, 4, 15, b2) MZ_F(2, 5, 16, b2) MZ_F(3, 5, 17, b2)                      \
+      MZ_F(0, 4, 18, b3) MZ_F(1, 4, 19, b3) MZ_F(2, 5, 20, b3) MZ_F(3, 5, 21, b3)
+template <int B>
+MZ_DEV void fmac_bcast_2x2(float& a0, float& a1, float& a2, float& a3, float xa, float xb,
+                           const float (*wa)[2], const float (*wb)[2]) {
+  static_assert(B % 4 == 0 && B < 16, "");
+#define MZ_OPS                                                                                         \
+  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                             \
+  : "v"(xa), "v"(xb), "v"(wa[0][0]), "v"(wa[0][1]), "v"(wb[0][0]), "v"(wb[0][1]), "v"(wa[1][0]), "v"(wa[1][1]),     \
+    "v"(wb[1][0]), "v"(wb[1][1]), "v"(wa[2][0]), "v"(wa[2][1]), "v"(wb[2][0]), "v"(wb[2][1]), "v"(wa[3][0]),        \
+    "v"(wa[3][1]), "v"(wb[3][0]), "v"(wb[3][1])
+  if constexpr (B == 0) asm("s_nop 1\n\t" MZ_F4(0, 1, 2, 3) MZ_OPS);  // (xa, xb may be fresh)
+  else if constexpr (B == 4) asm(MZ_F4(4, 5, 6, 7) MZ_OPS);
+  else if constexpr (B == 8) asm(MZ_F4(8, 9, 10, 11) MZ_OPS);
+  else asm(MZ_F4(12, 13, 14, 15) MZ_OPS);
+#undef MZ_OPS
+}
+#undef MZ_F4
+// 2 + 1 chains: %0 %1 <- %3 (xa), %2 <- %4 (xb); weights %5.. in (k, chain) order
+#define MZ_F3(b0, b1, b2, b3)                                                                          \
+  MZ_F(0, 3, 5, b0) MZ_F(1, 3, 6, b0) MZ_F(2, 4, 7, b0) MZ_F(0, 3, 8, b1) MZ_F(1, 3, 9, b1)  \
+      MZ_F(2, 4, 10, b1) MZ_F(0, 3, 11, b2) MZ_F(1, 3, 12, b2) MZ_F(2, 4, 13, b2) MZ_F(0, 3, 14, b3)    \
+      MZ_F(1, 3, 15, b3) MZ_F(2, 4, 16, b3)
+template <int B>
+MZ_DEV void fmac_bcast_2x1(float& a0, float& a1, float& a2, float xa, float xb, const float (*wa)[2],
+                           const float (*wb)[1]) {
+  static_assert(B % 4 == 0 && B < 16, "");
+#define MZ_OPS                                                                                         \
+  : "+v"(a0), "+v"(a1), "+v"(a2)                                                                       \
+  : "v"(xa), "v"(xb), "v"(wa[0][0]), "v"(wa[0][1]), "v"(wb[0][0]), "v"(wa[1][0]), "v"(wa[1][1]), "v"(wb[1][0]),   \
+    "v"(wa[2][0]), "v"(wa[2][1]), "v"(wb[2][0]), "v"(wa[3][0]), "v"(wa[3][1]), "v"(wb[3][0])
+  if constexpr (B == 0) asm("s_nop 1\n\t" MZ_F3(0, 1, 2, 3) MZ_OPS);
+  else if constexpr (B == 4) asm(MZ_F3(4, 5, 6, 7) MZ_OPS);
+  else if constexpr (B == 8) asm(MZ_F3(8, 9, 10, 11) MZ_OPS);
+  else asm(MZ_F3(12, 13, 14, 15) MZ_OPS);
+#undef MZ_OPS
+}
+#undef MZ_F3
+#undef MZ_F
+
 template <int STEP>
 struct Bfly;
 template <> struct Bfly<0> { static constexpr int ctrl = kDppXor1; };

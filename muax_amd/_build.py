@@ -32,9 +32,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA accumulators in VGPRs: the recurrent kernel's folds need no accvgpr moves
          "-fno-slp-vectorize",  # SLP packs the two scalar adds of paired DPP butterflies into mov_dpp x 2 + v_pk_add (-1.6 % without)
          "-fPIC", "-Wno-unused-value"]
-# per-unit additions, measured on one box (profiles/r02_fused_variants.txt): the small-embedding fused instances are
-# issue-bound single wavefronts -- the scheduler's max-ILP strategy is worth 5 % there and costs the E = 32 instances 2 %
-UNIT_FLAGS = {u: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] for u in ("mz_fused_g0.hip", "mz_fused_g1.hip", "mz_fused_g2.hip")}
+# per-unit additions, measured on one box (profiles/r02_fused_variants.txt): the fused instances are issue-bound single
+# wavefronts -- the scheduler's max-ILP strategy is worth 5 % on the small-embedding shapes and 1 % on the E = 32 ones
+# (before their layers became v_fmac_f32_dpp chain blocks it cost those 2 %), nothing on the other translation units
+UNIT_FLAGS = {u: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+              for u in ("mz_fused_g0.hip", "mz_fused_g1.hip", "mz_fused_g2.hip", "mz_fused_g3.hip")}
 
 
 def hipcc() -> str:

@@ -34,6 +34,14 @@ KERNEL(k_fma_ilp8, X0, asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1
 KERNEL(k_pk_dep, P0, asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p0) : "v"(w), "v"(c));, p0.x + p0.y)
 KERNEL(k_pk_ilp2, P0, asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %2, %3" : "+v"(p0), "+v"(p1) : "v"(w), "v"(c));, p0.x + p1.y)
 KERNEL(k_pk_ilp4, P0, asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(w), "v"(c));, p0.x + p1.y + p2.x + p3.y)
+// the compiler pads one wait state between dependent packed ops (LLVM reads op_sel_hi of src0 as a partial-dword write):
+// what does the pad cost on a dependent chain, and between independent ones?
+KERNEL(k_pk_dep_nop, P0, asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n s_nop 0" : "+v"(p0) : "v"(w), "v"(c));, p0.x + p0.y)
+KERNEL(k_pk_ilp2_nop, P0, asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n s_nop 0\n v_pk_fma_f32 %1, %1, %2, %3\n s_nop 0" : "+v"(p0), "+v"(p1) : "v"(w), "v"(c));, p0.x + p1.y)
+// the discounted-return step of the backup: s_nop 1, v_mul_f32_dpp row_shl:1, v_add_f32
+KERNEL(k_gstep, X0, asm volatile("s_nop 1\n v_mul_f32_dpp %1, %0, %2 row_shl:1 row_mask:0xf bank_mask:0xf\n v_add_f32 %0, %1, %3" : "+v"(x0), "+v"(x1) : "v"(a), "v"(b));, x0 + x1)
+// ... with the two wait states filled by independent VALU work instead of s_nop 1
+KERNEL(k_gstep_fill, X0, asm volatile("v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_mul_f32_dpp %1, %0, %4 row_shl:1 row_mask:0xf bank_mask:0xf\n v_add_f32 %0, %1, %5" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b));, x0 + x1 + x2 + x3)
 // one pk chain + one scalar chain (the second-layer loops of the network pass)
 KERNEL(k_pk_fma_mix, P0; float x0 = a, asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n v_fmac_f32 %1, %4, %5" : "+v"(p0), "+v"(x0) : "v"(w), "v"(c), "v"(a), "v"(b));, p0.x + x0)
 // DPP broadcast movs, independent (issue cost)
@@ -100,6 +108,10 @@ int main() {
   RUN(k_pk_dep, 1, "v_pk_fma_f32 dependent")
   RUN(k_pk_ilp2, 2, "")
   RUN(k_pk_ilp4, 4, "")
+  RUN(k_pk_dep_nop, 1, "dependent v_pk_fma_f32 + s_nop 0 (per pair)")
+  RUN(k_pk_ilp2_nop, 2, "two chains, each op followed by s_nop 0 (per op + nop)")
+  RUN(k_gstep, 1, "s_nop 1 + v_mul_f32_dpp + v_add_f32 (per step)")
+  RUN(k_gstep_fill, 1, "two independent fmas instead of the s_nop (per step)")
   RUN(k_pk_fma_mix, 2, "pk chain + fmac chain")
   RUN(k_movdpp_ilp4, 4, "independent row_newbcast movs")
   RUN(k_movdpp_fmac, 2, "mov_dpp -> fmac chain")

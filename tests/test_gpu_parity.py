@@ -16,7 +16,7 @@ F32 = np.float32
 
 
 def _fused(case, tiebreak, key, max_depth=None, temperature=1.0, use_gumbel=True, use_noise=True,
-           pred_on="child", global_batch=None, root_offset=0, rows=None):
+           pred_on="child", global_batch=None, root_offset=0, rows=None, discount=0.99):
     from muax_amd import MuZeroSearch, SearchConfig
     sl = slice(None) if rows is None else rows
     B = case["obs"][sl].shape[0]
@@ -24,7 +24,7 @@ def _fused(case, tiebreak, key, max_depth=None, temperature=1.0, use_gumbel=True
                        global_batch=global_batch, root_offset=root_offset)
     s = MuZeroSearch(B, cfg)
     s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"],
-                      case["support"], 0.99, pred_on)
+                      case["support"], discount, pred_on)
     out = s.act_mlp(torch.from_numpy(case["obs"][sl]), key,
                     dirichlet_noise=torch.from_numpy(case["noise"][sl]) if use_noise else None,
                     invalid_actions=None if case["invalid"] is None else torch.from_numpy(case["invalid"][sl]),
@@ -35,9 +35,9 @@ def _fused(case, tiebreak, key, max_depth=None, temperature=1.0, use_gumbel=True
 
 
 def _oracle(oracle, case, tiebreak, key, max_depth=0, temperature=1.0, use_gumbel=True, use_noise=True,
-            pred_on=0):
+            pred_on=0, discount=0.99):
     mlp = oracle.Mlp(case["w"], case["obs_dim"], case["E"], case["A"], case["F"], support_size=case["support"],
-                     recurrent_pred_on=pred_on)
+                     recurrent_pred_on=pred_on, discount=discount)
     cfg = oracle.SearchCfg(case["S"], max_depth=max_depth or 0, tiebreak=int(tiebreak))
     return oracle.act_mlp(mlp, cfg, case["obs"], key, case["noise"] if use_noise else None, 0.25, case["invalid"],
                           temperature, case["gumbel"] if use_gumbel else None)
@@ -116,6 +116,32 @@ def test_fused_small_margins(oracle):
     case["w"] = {k: (v * 1e-4).astype(np.float32) for k, v in case["w"].items()}
     s, out = _fused(case, True, [5, 5], use_noise=False)
     _compare(_oracle(oracle, case, True, [5, 5], use_noise=False), s, out)
+
+
+@pytest.mark.parametrize("A,E", [(2, 8), (4, 32), (3, 8)])
+def test_fused_rare_division_paths(oracle, A, E):
+    """The two shared-reciprocal divisions of the fused kernel hand over to the IEEE division behind a wave-uniform
+    range test; random networks never trip it, these do.  (a) Second-layer weights x 60: support logits spread over
+    hundreds, so softmax terms land in (0, 2^-100) and below exp's cut at -87 (exact zeros).  (b) An all-zero reward
+    head and a discount of 1e-30: q = discount * value, so the value-score numerators q - min q are ~ 1e-31, inside
+    (0, 2^-100).  Both must stay bit-exact (tools: a build with either IEEE branch deliberately wrong fails exactly
+    this test and none of the others)."""
+    case = make_case(oracle, 900 + A, 96, 4 if E == 8 else 8, E, A, 40)
+    w = dict(case["w"])
+    for k in ("pv_w2", "dr_w2"):
+        w[k] = (w[k] * 60.0).astype(F32)
+    sharp = dict(case, w=w)
+    s, out = _fused(sharp, True, [9, A])
+    ref = _oracle(oracle, sharp, True, [9, A])
+    _compare(ref, s, out)
+    assert np.abs(ref["tree"].children_rewards).max() > 1.0  # (the decode saw one-hot-like distributions)
+    w = dict(case["w"])
+    for k in ("dr_w1", "dr_b1", "dr_w2", "dr_b2"):
+        w[k] = np.zeros_like(w[k])  # rewards exactly 0 (uniform softmax decodes to 0): q = discount * value
+    flat = dict(case, w=w)
+    for disc in (1e-30, 3e-33):
+        s, out = _fused(flat, False, [A, 9], discount=disc, use_noise=False)
+        _compare(_oracle(oracle, flat, False, [A, 9], discount=disc, use_noise=False), s, out)
 
 
 @pytest.mark.parametrize("A,E,support,S,B", [(2, 8, 8, 30, 40), (2, 8, 15, 50, 40), (2, 8, 16, 50, 70), (2, 8, 31, 20, 33),

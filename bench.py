@@ -114,9 +114,15 @@ def pmc_traffic(workload):
         return None
 
 
-def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl"):
+def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl", settle_ms=30.0):
     """`steps` timed launches of the fused act() kernel on this rank's B roots of the global batch (inputs resident
-    in HBM, launches back to back, one synchronisation at the end; barrier + max over ranks for N > 1)."""
+    in HBM, launches back to back, one synchronisation at the end; barrier + max over ranks for N > 1).
+
+    Before the `warmup` untimed steps the GPU is brought to its working clocks: the MI355X ramps them over ~10 ms of
+    continuous work (the same 20 timed steps measure 36.9 M env-steps/s after 5 warm-up launches = 0.5 ms, 37.6 M after
+    20, 39.2 M after 80), and a short run would otherwise report the ramp instead of the rate an RL loop sees.  The
+    settle phase is `settle_ms` of untimed launches of the same kernel (--settle-ms 0 turns it off; it is named in
+    the JSON line's config)."""
     from muax_amd import MuZeroSearch, SearchConfig
     _, obs_dim, E, A, support, S = WORKLOADS[workload]
     F = 2 * support + 1
@@ -131,6 +137,15 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     def step(i):
         search.act_mlp(d_obs, (0, i), dirichlet_noise=d_noise, dirichlet_fraction=0.25, temperature=1.0)
 
+    if settle_ms > 0:
+        step(0)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        step(0)
+        torch.cuda.synchronize()
+        per = max(time.perf_counter() - t_s, 2e-5)
+        for i in range(min(5000, int(settle_ms * 1e-3 / per) + 1)):
+            step(i)
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
@@ -220,6 +235,8 @@ def main():
     ap.add_argument("--no-tiebreak", action="store_true", help="drop mctx's threefry tie-break noise (NOT the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the api / config-3 sub-objects of the JSON line")
+    ap.add_argument("--settle-ms", type=float, default=30.0,
+                    help="untimed launches before the warm-up steps until the GPU clocks have ramped (see fused_run)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,7 +262,8 @@ def main():
         B = args.roots
     F = 2 * support + 1
     dev = torch.device("cuda", local_rank)
-    run = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend)
+    run = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend,
+                    args.settle_ms)
     elapsed, kernel_ms, depth_total, weights, obs, noise = (run[k] for k in ("elapsed", "kernel_ms", "depth_total",
                                                                                "weights", "obs", "noise"))
 
@@ -261,7 +279,8 @@ def main():
             "config": {"workload": f"{args.workload}: {B} roots/GPU, obs {obs_dim}, MLP embed {E}, A={A}, "
                                    f"support {support}, num_simulations={S}, dirichlet 0.25/0.3, "
                                    f"tiebreak={'threefry' if not args.no_tiebreak else 'off'}, temperature 1",
-                       "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective"},
+                       "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective",
+                       "clock_settle_ms_before_warmup": args.settle_ms},
             "roofline": roofline(args.workload, B, kernel_ms, depth_total),
         }
         if world == 1 and not args.no_extras:
@@ -270,7 +289,7 @@ def main():
             if args.workload == "cartpole" and not args.roots:
                 B3 = WORKLOADS["lunarlander"][0]
                 r3 = fused_run("lunarlander", B3, 0, 1, dev, max(20, args.steps // 4), max(5, args.warmup // 2),
-                               not args.no_tiebreak)
+                               not args.no_tiebreak, settle_ms=args.settle_ms)
                 steps3 = max(20, args.steps // 4)
                 line["config3_lunarlander"] = {
                     "value": round(B3 * steps3 / r3["elapsed"], 1), "unit": "env-steps/s", "steps": steps3,

@@ -2,7 +2,7 @@
 
 The library is several translation units compiled in parallel (each `hipcc -c`, objects under muax_amd/lib/obj/)
 and linked into one shared object: the C-ABI and the step-wise / training / Dirichlet kernels (mz_api.hip), the
-fused act() kernel instances in four groups (mz_fused_g*.hip, listed in mz_instances.def) and the ResNet
+fused act() kernel instances in five groups (mz_fused_g*.hip, listed in mz_instances.def) and the ResNet
 recurrent kernel (mz_conv.hip).  Only the units whose sources changed are recompiled."""
 from __future__ import annotations
 
@@ -25,6 +25,7 @@ UNITS = {
     "mz_fused_g1.hip": _FUSED,
     "mz_fused_g2.hip": _FUSED,
     "mz_fused_g3.hip": _FUSED,
+    "mz_fused_g4.hip": _FUSED,
     "mz_conv.hip": ["mz_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
 }
 SOURCES = list(UNITS)
@@ -36,7 +37,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 # wavefronts -- the scheduler's max-ILP strategy is worth 5 % on the small-embedding shapes and 1 % on the E = 32 ones
 # (before their layers became v_fmac_f32_dpp chain blocks it cost those 2 %), nothing on the other translation units
 UNIT_FLAGS = {u: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-              for u in ("mz_fused_g0.hip", "mz_fused_g1.hip", "mz_fused_g2.hip", "mz_fused_g3.hip")}
+              for u in ("mz_fused_g0.hip", "mz_fused_g1.hip", "mz_fused_g2.hip", "mz_fused_g3.hip", "mz_fused_g4.hip")}
 
 
 def hipcc() -> str:

@@ -296,7 +296,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.F = F;
   const int mode = c.policy == 1 ? (c.qtransform == 1 ? 3 : 2) : (c.tiebreak ? 1 : 0);
   const mz::FusedDispatch groups[] = {mz::fused_dispatch_g0, mz::fused_dispatch_g1, mz::fused_dispatch_g2,
-                                      mz::fused_dispatch_g3};
+                                      mz::fused_dispatch_g3, mz::fused_dispatch_g4};
   // more 16-root workgroups than CUs: prefer a compact-record instance (two workgroups per CU), if the shape has one
   for (int compact = (c.batch > 16 * h->cu_count) ? 1 : 0; compact >= 0; --compact) {
     p.path_scratch = compact ? h->fused_path : nullptr;

@@ -17,6 +17,7 @@ int fused_dispatch_g0(int mode, int device, const FusedParams& p, hipStream_t st
 int fused_dispatch_g1(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 int fused_dispatch_g2(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 int fused_dispatch_g3(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
+int fused_dispatch_g4(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 // words per node of the HBM path array of a compact instance (the same for every instance with NMAX <= 64, A <= 4)
 constexpr int kCompactPathWords = 13;
 }  // namespace mz

@@ -54,7 +54,7 @@ def _compare(ref, s, out):
 
 
 @pytest.mark.parametrize("tiebreak", [False, True])
-@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100), (2, 8, 63, 150), (3, 8, 50, 90), (2, 16, 50, 70), (4, 16, 40, 50), (2, 8, 100, 60), (2, 8, 127, 30), (4, 32, 100, 24), (2, 10, 50, 100), (4, 10, 50, 60), (6, 8, 50, 45)])
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 50, 333), (3, 8, 32, 77), (4, 8, 50, 130), (4, 32, 50, 100), (2, 8, 63, 150), (3, 8, 50, 90), (2, 16, 50, 70), (4, 16, 40, 50), (2, 8, 100, 60), (2, 8, 127, 30), (4, 32, 100, 24), (2, 10, 50, 100), (4, 10, 50, 60), (6, 8, 50, 45), (8, 8, 50, 40), (2, 32, 50, 50), (4, 64, 50, 40), (2, 64, 30, 20)])
 def test_fused_matches_oracle(oracle, A, E, S, B, tiebreak):
     case = make_case(oracle, 10 * A + E, B, 4 if E == 8 else 8, E, A, S)
     key = [123, 456 + A]

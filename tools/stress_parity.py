@@ -16,7 +16,8 @@ import test_gpu_parity as tp  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
 rng = np.random.default_rng(seed)
-shapes = [(2, 8, 4), (3, 8, 6), (4, 8, 5), (2, 16, 4), (4, 16, 8), (4, 32, 8), (2, 10, 4), (4, 10, 8), (6, 8, 6)]
+shapes = [(2, 8, 4), (3, 8, 6), (4, 8, 5), (2, 16, 4), (4, 16, 8), (4, 32, 8), (2, 10, 4), (4, 10, 8), (6, 8, 6),
+          (8, 8, 6), (2, 32, 8), (4, 64, 8), (2, 64, 8)]
 wide_support = {(2, 8), (4, 32), (6, 8)}  # instances with four support slots (support_size 16..31)
 bad = 0
 for c in range(n):

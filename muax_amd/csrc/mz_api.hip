@@ -342,31 +342,37 @@ int mzs_act_mlp_host(mzs_handle* h, const mzs_act_host_args* a, void* stream_) {
     MZS_HIP(h, hipHostMalloc(&h->host_out, out_b, hipHostMallocDefault));
     MZS_HIP(h, hipMalloc(&h->dev_out, out_b));
   }
+  // The kernels read the host's inputs and write its outputs THROUGH THE PINNED STAGING BUFFERS themselves (hipHostMalloc
+  // memory is mapped into the device's address space, coherent): an act moves 16..32 bytes per root each way, read once
+  // at the kernel's start and written once at its end, and a copy command costs more in launch and engine latency than
+  // those bytes cost over the host link.  Only the drawn root noise lives in device memory (its producer is a kernel).
   char* hin = static_cast<char*>(h->host_in);
   char* din = static_cast<char*>(h->dev_in);
-  memcpy(hin, a->obs, obs_b);
-  size_t up = obs_b;  // bytes to upload: the obs, and the optional blocks behind it only when they are used
+  char* hin_dev = nullptr;
+  float* hout_dev = nullptr;
+  MZS_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&hin_dev), h->host_in, 0));
+  MZS_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&hout_dev), h->host_out, 0));
   const bool muzero = c.policy == 0;
   const bool given = muzero && a->dirichlet_noise != nullptr;
   const bool draw = muzero && !given && a->draw_dirichlet != 0 && a->dirichlet_fraction != 0.0f;
-  if (given) { memcpy(hin + obs_b, a->dirichlet_noise, noise_b); up = obs_b + noise_b; }
-  if (a->invalid_actions) { memcpy(hin + obs_b + noise_b, a->invalid_actions, B * A); up = in_b; }
-  MZS_HIP(h, hipMemcpyAsync(din, hin, up, hipMemcpyHostToDevice, stream));
   float* d_noise = reinterpret_cast<float*>(din + obs_b);
-  if (draw) {
+  if (draw) {  // first: it needs nothing from the host and runs while the host fills the staging buffer
     uint32_t kd[2];
     h_split(a->key, 3, 1, kd);  // mctx: rng_key, dirichlet_rng_key, search_rng_key = split(rng_key, 3)
     if (int rc = mzs_dirichlet(c.device, kd, a->dirichlet_alpha, c.batch, c.num_actions, c.global_batch, c.root_offset,
                                d_noise, stream_))
       return fail(h, rc, "mzs_act_mlp_host: %s", mzs_last_error(nullptr));
   }
-  float* dout = static_cast<float*>(h->dev_out);
+  memcpy(hin, a->obs, obs_b);
+  if (given) memcpy(hin + obs_b, a->dirichlet_noise, noise_b);
+  if (a->invalid_actions) memcpy(hin + obs_b + noise_b, a->invalid_actions, B * A);
+  float* dout = hout_dev;
   mzs_act_args args;
   memset(&args, 0, sizeof args);
   args.struct_size = (int32_t)sizeof args;
-  args.obs = reinterpret_cast<const float*>(din);
-  args.dirichlet_noise = (given || draw) ? d_noise : nullptr;
-  args.invalid_actions = a->invalid_actions ? reinterpret_cast<const uint8_t*>(din + obs_b + noise_b) : nullptr;
+  args.obs = reinterpret_cast<const float*>(hin_dev);
+  args.dirichlet_noise = draw ? d_noise : (given ? reinterpret_cast<const float*>(hin_dev + obs_b) : nullptr);
+  args.invalid_actions = a->invalid_actions ? reinterpret_cast<const uint8_t*>(hin_dev + obs_b + noise_b) : nullptr;
   args.key[0] = a->key[0]; args.key[1] = a->key[1];
   args.dirichlet_fraction = (given || draw) ? a->dirichlet_fraction : 0.0f;
   args.temperature = a->temperature;
@@ -374,7 +380,6 @@ int mzs_act_mlp_host(mzs_handle* h, const mzs_act_host_args* a, void* stream_) {
   args.action_weights = dout + B;
   args.root_value = dout + B + B * A;
   if (int rc = mzs_act_mlp(h, &args, stream_)) return rc;
-  MZS_HIP(h, hipMemcpyAsync(h->host_out, dout, out_b, hipMemcpyDeviceToHost, stream));
   MZS_HIP(h, hipStreamSynchronize(stream));
   const char* hout = static_cast<const char*>(h->host_out);
   memcpy(a->action, hout, B * 4);

@@ -95,11 +95,12 @@ class MuZeroSearch:
             raise RuntimeError("muax_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
             else torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.batch, self.cfg = int(batch), cfg
         self._L = _lib.load()
         c = MzsConfig()
         c.struct_size = C.sizeof(MzsConfig)
-        c.device = self.device.index or 0
+        c.device = self._dev_index
         c.batch, c.num_actions = self.batch, cfg.num_actions
         c.num_simulations, c.embed_dim = cfg.num_simulations, cfg.embed_dim
         c.max_depth = cfg.max_depth or 0
@@ -146,6 +147,10 @@ class MuZeroSearch:
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
+        # torch's current stream of this device, raw (torch.cuda.current_stream() builds a Stream object: ~6 us per call)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return C.c_void_p(raw(self._dev_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _f32(self, t, shape, name):

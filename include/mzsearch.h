@@ -125,10 +125,10 @@ int mzs_act_mlp(mzs_handle *h, const mzs_act_args *args, void *stream);
 /* ---- the same from HOST memory: what the reference's act() does around its jitted _plan ----
  * muax.MuZero.act takes NumPy observations and returns NumPy / Python values, synchronising on the way out
  * (np.asarray / .item(), muax/model.py:160-179).  mzs_act_mlp_host is that whole round trip in one call: the
- * observations (and optional masks / noise) are staged through pinned memory owned by the handle, the root noise is
- * drawn on the device from split(key, 3)[1] unless given (mctx.muzero_policy's jax.random.dirichlet, see
- * mzs_dirichlet), mzs_act_mlp runs, the three outputs come back with ONE copy, and the call returns after
- * synchronising `stream`.  All pointers here are HOST pointers.  (The handle allocates its staging buffers at the
+ * observations (and optional masks / noise) are copied into pinned memory owned by the handle, which the search kernel
+ * reads -- and whose output half it writes -- directly (mapped host memory: no upload / download command), the root
+ * noise is drawn on the device from split(key, 3)[1] unless given (mctx.muzero_policy's jax.random.dirichlet, see
+ * mzs_dirichlet), and the call returns after synchronising `stream`.  All pointers here are HOST pointers.  (The handle allocates its staging buffers at the
  * first call; this is the only entry point that synchronises.) */
 typedef struct {
   int32_t struct_size;

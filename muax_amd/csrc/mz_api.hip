@@ -656,6 +656,11 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
   if (A == 4 && E == 8 && F == 21) return launch_train<mz::TrainCfg<4, 8, 21>>(p, stream);
   if (A == 2 && E == 16 && F == 21) return launch_train<mz::TrainCfg<2, 16, 21>>(p, stream);
   if (A == 4 && E == 16 && F == 21) return launch_train<mz::TrainCfg<4, 16, 21>>(p, stream);
+  if (A == 2 && E == 10 && F == 21) return launch_train<mz::TrainCfg<2, 10, 21>>(p, stream);  // the reference notebooks
+  if (A == 4 && E == 10 && F == 21) return launch_train<mz::TrainCfg<4, 10, 21>>(p, stream);
+  if (A == 6 && E == 8 && F == 21) return launch_train<mz::TrainCfg<6, 8, 21>>(p, stream);
+  if (A == 8 && E == 8 && F == 21) return launch_train<mz::TrainCfg<8, 8, 21>>(p, stream);
+  if (A == 2 && E == 32 && F == 21) return launch_train<mz::TrainCfg<2, 32, 21>>(p, stream);
   return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: no kernel instance for this (A, E, F)");
 }
 

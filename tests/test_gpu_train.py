@@ -72,7 +72,8 @@ def _autograd(m, b, dtype, device, **kw):
 
 @pytest.mark.parametrize("A,E,obs_dim,B,L,kw", [
     (2, 8, 4, 50, 5, {}), (2, 8, 4, 4096, 10, {}), (2, 8, 4, 7, 1, {}), (4, 32, 8, 33, 3, {}),
-    (3, 8, 5, 16, 4, {"divide_by_length": True}), (4, 16, 6, 40, 3, {}), (2, 16, 4, 20, 2, {}), (4, 8, 8, 24, 3, {})])
+    (3, 8, 5, 16, 4, {"divide_by_length": True}), (4, 16, 6, 40, 3, {}), (2, 16, 4, 20, 2, {}), (4, 8, 8, 24, 3, {}),
+    (2, 10, 4, 30, 3, {}), (4, 10, 8, 21, 2, {}), (6, 8, 6, 18, 3, {}), (8, 8, 6, 17, 2, {}), (2, 32, 8, 19, 3, {})])
 def test_fused_loss_and_gradients_match_autograd(A, E, obs_dim, B, L, kw):
     m, b = _model(A, E, obs_dim, seed=A + E), _batch(B, L, A, obs_dim, seed=B)
     fused = mx.loss.FusedLossGrad(m)

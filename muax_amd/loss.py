@@ -94,10 +94,15 @@ class FusedLossGrad:
             self.views.append(self.grads[off:off + x.numel()].view_as(x))
             off += x.numel()
         self._ws = None
+        self._w = self._w_keep = self._w_ptrs = None
 
     def __call__(self, batch: Transition, divide_by_length: bool = False):
         C, _lib, dev = self._C, self._lib, self.grads.device
-        t = lambda x, dt: torch.as_tensor(x, device=dev).to(dt).contiguous()  # noqa: E731
+
+        def t(x, dt):  # (tensors that already are what the kernel reads pass through untouched)
+            if isinstance(x, torch.Tensor) and x.dtype == dt and x.device == dev and x.is_contiguous():
+                return x
+            return torch.as_tensor(x, device=dev).to(dt).contiguous()
         a = t(batch.a, torch.int32)
         B, L = a.shape[:2]
         a = a.reshape(B, L)
@@ -109,16 +114,22 @@ class FusedLossGrad:
         need = int(self._L.mzs_mlp_train_workspace_bytes(B, self.obs_dim, self.E, self.A, self.S))
         if self._ws is None or self._ws.numel() * 4 < need:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
-        w = _lib.MzsMlpWeights()
-        w.struct_size = C.sizeof(_lib.MzsMlpWeights)
-        w.obs_dim, w.support_size = self.obs_dim, self.S
+        # the weight struct is rebuilt only when a parameter tensor moved (optimisers update in place)
+        ptrs = tuple(x.data_ptr() for x in self.params)
+        if self._w is None or ptrs != self._w_ptrs or not all(x.is_contiguous() for x in self.params):
+            w = _lib.MzsMlpWeights()
+            w.struct_size = C.sizeof(_lib.MzsMlpWeights)
+            w.obs_dim, w.support_size = self.obs_dim, self.S
+            keep = [x.detach().contiguous() for x in self.params]
+            for n, x in zip(_lib.MLP_WEIGHT_NAMES, keep):
+                setattr(w, n, x.data_ptr())
+            self._w, self._w_keep = w, keep
+            self._w_ptrs = ptrs if all(k.data_ptr() == q for k, q in zip(keep, ptrs)) else None
+        w, keep = self._w, self._w_keep
         w.discount = self.m._discount
-        keep = [x.detach().contiguous() for x in self.params]
-        for n, x in zip(_lib.MLP_WEIGHT_NAMES, keep):
-            setattr(w, n, x.data_ptr())
         args = _lib.MzsTrainArgs()
         args.struct_size = C.sizeof(_lib.MzsTrainArgs)
-        args.device = dev.index or 0
+        args.device = dev.index if dev.index is not None else torch.cuda.current_device()
         args.batch, args.unroll_steps, args.num_actions, args.embed_dim = B, L, self.A, self.E
         args.obs, args.actions, args.rewards = obs.data_ptr(), a.data_ptr(), r.data_ptr()
         args.returns, args.policy = Rn.data_ptr(), pi.data_ptr()
@@ -126,8 +137,9 @@ class FusedLossGrad:
         args.l2_coeff = 1e-4
         args.loss, args.grads = self.loss.data_ptr(), self.grads.data_ptr()
         args.workspace, args.workspace_bytes = self._ws.data_ptr(), self._ws.numel() * 4
-        with torch.cuda.device(dev):
-            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(self._L.mzs_mlp_loss_grad(C.byref(w), C.byref(args), stream))
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        stream = C.c_void_p(raw(idx) if raw is not None else torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(self._L.mzs_mlp_loss_grad(C.byref(w), C.byref(args), stream))
         self._keep = (obs, a, r, Rn, pi, keep)
         return self.loss, self.grads

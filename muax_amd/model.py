@@ -89,8 +89,9 @@ class MuZero:
         # plugin (non-default) nets: run the S x (select, recurrent_fn, expand_backup) loop as one hipGraph
         self.capture_graph = bool(capture_graph)
         self._params = None
-        self._opt_state = None
+        self._opt_state_saved = None  # what init() / a checkpoint produced before an optimiser was bound
         self._loaded_opt_state = None
+        self._param_list = None
         self._fused_train = None
         self._disc_const = None
         self._fused = {}
@@ -122,6 +123,17 @@ class MuZero:
     @property
     def params(self):
         return self._params
+
+    @property
+    def _opt_state(self):
+        # optimiser moments + schedule position, read when asked for (building the dict costs ~10 us: not per update())
+        if self._optimizer is not None and self._optimizer.opt is not None:
+            return self._optimizer.state_dict()
+        return self._opt_state_saved
+
+    @_opt_state.setter
+    def _opt_state(self, value):
+        self._opt_state_saved = value
 
     @property
     def optimizer_state(self):
@@ -429,12 +441,13 @@ class MuZero:
         from .sharding import allreduce_mean_flat
         if self._params is None:
             raise ValueError("call init() first")
-        params = [p for m in self.network if isinstance(m, torch.nn.Module) for p in m.parameters()]
+        def all_params():
+            return [p for m in self.network if isinstance(m, torch.nn.Module) for p in m.parameters()]
         if self._optimizer is None:
             self._optimizer = mz_opt.create_optimizer()
         if self._optimizer.opt is None:
             loaded = self._loaded_opt_state
-            self._opt_state = self._optimizer.init(params)
+            self._opt_state = self._optimizer.init(all_params())
             if loaded is not None:
                 # a checkpoint was loaded before the optimiser was bound to parameters: resume its moments,
                 # step counts and schedule position (the reference restores opt_state, muax/model.py:210-212)
@@ -461,9 +474,8 @@ class MuZero:
             loss_fn = self.loss_fn or mz_loss.default_loss_fn
             loss = loss_fn(self, batch, *args, **kwargs)
             loss.backward()
-            allreduce_mean_flat([p.grad for p in params])
+            allreduce_mean_flat([p.grad for p in all_params()])
         self._optimizer.step()
-        self._opt_state = self._optimizer.state_dict()
         self._weights_version += 1
         return {"loss": float(loss.item())}
 
@@ -482,12 +494,13 @@ class MuZero:
             saved = torch.load(file, map_location=self.device)
             for n, m in mods.items():
                 m.load_state_dict(saved["params"][n])
-            self._opt_state = saved.get("optimizer_state")
-            if self._opt_state is not None:
+            st = saved.get("optimizer_state")
+            self._opt_state = st
+            if st is not None:
                 if self._optimizer is not None and self._optimizer.opt is not None:
-                    self._optimizer.load_state_dict(self._opt_state)
+                    self._optimizer.load_state_dict(st)
                 else:
-                    self._loaded_opt_state = self._opt_state  # applied when update() binds the optimiser
+                    self._loaded_opt_state = st  # applied when update() binds the optimiser
             self._weights_version += 1
 
     def save(self, file):

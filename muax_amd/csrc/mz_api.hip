@@ -661,6 +661,8 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
   if (A == 6 && E == 8 && F == 21) return launch_train<mz::TrainCfg<6, 8, 21>>(p, stream);
   if (A == 8 && E == 8 && F == 21) return launch_train<mz::TrainCfg<8, 8, 21>>(p, stream);
   if (A == 2 && E == 32 && F == 21) return launch_train<mz::TrainCfg<2, 32, 21>>(p, stream);
+  if (A == 2 && E == 8 && F == 31) return launch_train<mz::TrainCfg<2, 8, 31>>(p, stream);  // support_size 15, 20
+  if (A == 2 && E == 8 && F == 41) return launch_train<mz::TrainCfg<2, 8, 41>>(p, stream);
   return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: no kernel instance for this (A, E, F)");
 }
 

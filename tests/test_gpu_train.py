@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
-def _model(A, E, obs_dim, seed):
+def _model(A, E, obs_dim, seed, support=10):
     g = torch.Generator().manual_seed(seed)
-    net = mx.nn.MZNetwork(mx.nn.Representation(E, generator=g), mx.nn.Prediction(A, 21, generator=g),
-                          mx.nn.Dynamic(E, A, 21, generator=g))
-    m = mx.MuZero(net, optimizer=mx.optimizers.create_optimizer("adam", 1e-2))
+    F = 2 * support + 1
+    net = mx.nn.MZNetwork(mx.nn.Representation(E, generator=g), mx.nn.Prediction(A, F, generator=g),
+                          mx.nn.Dynamic(E, A, F, generator=g))
+    m = mx.MuZero(net, optimizer=mx.optimizers.create_optimizer("adam", 1e-2), support_size=support)
     m.init(0, np.zeros((1, obs_dim)))
     with torch.no_grad():  # non-zero biases so that every gradient path is exercised
         for p in [p for mod in m.network for p in mod.parameters()]:
@@ -89,6 +90,19 @@ def test_fused_loss_and_gradients_match_autograd(A, E, obs_dim, B, L, kw):
         assert np.abs(gt - gd).max() <= 5 * tol  # the torch fp32 route is no closer to fp64 than the kernel
     loss2, flat2 = fused(b, **kw)  # fixed-order reduction: bit-reproducible
     assert float(loss2.item()) == loss and torch.equal(flat2, flat)
+
+
+@pytest.mark.parametrize("support", [15, 20])
+def test_fused_loss_and_gradients_other_support_sizes(support):
+    """support_size is a constructor argument of the reference (muax/model.py:48-49): kernel instances for 15 and 20."""
+    m, b = _model(2, 8, 4, seed=support, support=support), _batch(40, 4, 2, 4, seed=support)
+    fused = mx.loss.FusedLossGrad(m)
+    loss, _ = fused(b)
+    views = [v.detach().cpu().double().numpy() for v in fused.views]
+    l64, g64 = _autograd(m, b, torch.float64, "cpu")
+    assert abs(float(loss.item()) - l64) <= 1e-5 * abs(l64)
+    for gh, gd in zip(views, g64):
+        assert np.abs(gh - gd).max() <= 2e-4 * max(np.abs(gd).max(), 1e-6)
 
 
 def test_update_hip_and_torch_routes_take_the_same_step():

@@ -173,9 +173,9 @@ int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
  * Three places of the kernels replace a library sequence by a shorter one that is only valid for this hardware's
  * v_sqrt_f32 / v_rcp_f32 / fma: sqrt on arguments that need no range scaling, division by 2 eps = 0.002f
  * (muax/utils.py:70-76), and the support decode's e_i / sum with one refined reciprocal per sum.  mzs_selftest compares
- * them with the IEEE operations on the device -- exhaustively over [1, 4) resp. 2^-9 .. 2^-2, and over 2^24
- * denominators in [1, 64) with twelve numerators each -- and returns the mismatch counts (all must be 0) in
- * mismatches[0..3] ([3] reserved).  Synchronous.  errors: mzs_last_error(NULL) */
+ * them with the IEEE operations on the device -- exhaustively over [1, 4) resp. 2^-9 .. 2^-2, over 2^24
+ * denominators in [1, 64) with twelve numerators each, and over 2^24 denominators in 2^-27 .. 2^41 with eight -- and
+ * returns the mismatch counts (all must be 0) in mismatches[0..3].  Synchronous.  errors: mzs_last_error(NULL) */
 int mzs_selftest(int32_t device, int64_t *mismatches);
 
 /* ---- root exploration noise ----

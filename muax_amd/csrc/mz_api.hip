@@ -672,7 +672,7 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
 namespace mz {
 __global__ void selftest_kernel(unsigned long long* bad) {
   // every binary32 in [1, 4): sqrt_normal vs the IEEE sqrt; the same mantissas at 2^-9 .. 2^-2: div_two_eps vs x / 0.002f;
-  // bad[2]: see below; bad[3]: reserved (0)
+  // bad[2], bad[3]: see below
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 2^24 threads
   const float x = __uint_as_float(0x3f800000u + i);
   unsigned long long b0 = sqrt_normal(x) != sqrtf(x);
@@ -702,9 +702,32 @@ __global__ void selftest_kernel(unsigned long long* bad) {
       b2 += (q.x != ns[k] / d) + (q.y != ns[k + 1] / d);
     }
   }
+  // the same for the value scores' range: denominators (the span) spread over 2^-27 .. 2^41, numerators 0, the span
+  // itself and pseudo-random ones in [2^-100, span]
+  unsigned long long b3 = 0;
+  {
+    uint32_t h = i * 2246822519u + 0x85ebca6bu;
+    const float d = __uint_as_float(((100u + i % 68u) << 23) | (h >> 9));
+    const f32x2 dd = (f32x2){d, d};
+    const f32x2 y = rcp_newton2(dd);
+    float ns[8] = {0.0f, d};
+    for (int k = 2; k < 8; ++k) {
+      h = h * 1664525u + 1013904223u;
+      const uint32_t ex = 27u + (h >> 7) % 142u;  // 2^-100 .. 2^41
+      h = h * 1664525u + 1013904223u;
+      const float n = __uint_as_float((ex << 23) | (h >> 9));
+      ns[k] = n <= d ? n : d * 0.61f;
+      ns[k] = ns[k] < 0x1p-100f ? 0x1p-100f : ns[k];
+    }
+    for (int k = 0; k < 8; k += 2) {
+      const f32x2 q = div_newton2((f32x2){ns[k], ns[k + 1]}, dd, y);
+      b3 += (q.x != ns[k] / d) + (q.y != ns[k + 1] / d);
+    }
+  }
   if (b0) atomicAdd(&bad[0], b0);
   if (b1) atomicAdd(&bad[1], b1);
   if (b2) atomicAdd(&bad[2], b2);
+  if (b3) atomicAdd(&bad[3], b3);
 }
 }  // namespace mz
 

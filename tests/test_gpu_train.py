@@ -157,7 +157,8 @@ def test_c_abi_rejects_bad_training_and_tower_arguments():
 def test_device_selftest_of_the_shortened_sqrt_and_division():
     """mzs_selftest: sqrt_normal (v_sqrt_f32 + two exact residual checks) against the IEEE sqrt for every binary32 in
     [1, 4), the 3-op division by 0.002f against the IEEE division over 2^-9 .. 2^-2, and the shared-reciprocal division
-    of the support decode against n / d for 2^24 denominators in [1, 64) x 12 numerators, ON the device."""
+    of the support decode and of the value scores against n / d (2^24 denominators in [1, 64) x 12 numerators, 2^24 in
+    2^-27 .. 2^41 x 8), ON the device."""
     import ctypes as C
 
     from muax_amd import _lib

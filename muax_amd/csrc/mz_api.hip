@@ -769,7 +769,7 @@ int mzs_dirichlet(int32_t device, const uint32_t key[2], float alpha, int32_t ba
     return fail(nullptr, MZS_E_NODEVICE, "mzs_dirichlet: no HIP device (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(nullptr, MZS_E_INVALID, "mzs_dirichlet: bad device ordinal");
   MZS_HIP(nullptr, hipSetDevice(device));
-  const int R = 256 / num_actions;
+  const int R = (256 / mz::kSpec) / num_actions;  // roots per workgroup
   hipLaunchKernelGGL(mz::dirichlet_kernel, dim3((batch + R - 1) / R), dim3(256), sizeof(float) * (size_t)R * num_actions,
                      static_cast<hipStream_t>(stream_), key[0], key[1], alpha, batch, num_actions, (uint64_t)global_batch,
                      (uint64_t)root_offset, out);

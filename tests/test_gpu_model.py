@@ -90,7 +90,9 @@ def test_root_noise_is_jax_dirichlet_restated_on_the_device(oracle):
     threefry key walk included), for any batch size, action count and shard; statistics of Dir(0.3)."""
     from muax_amd.model import _dirichlet
     for B, A, key, alpha in ((1, 2, (0, 42), 0.3), (33, 2, (5, 6), 0.3), (2048, 2, (3, 4), 0.3), (300, 18, (9, 9), 0.3),
-                             (64, 4, (1, 1), 1.5), (1000, 64, (2, 7), 0.03)):
+                             (64, 4, (1, 1), 1.5), (1000, 64, (2, 7), 0.03),
+                             # 1.6 M elements: some exhaust the four speculative lanes of the device sampler (~6e-6 each)
+                             (200000, 8, (11, 12), 0.3), (50000, 4, (13, 14), 2.5)):
         d = _dirichlet(key, alpha, (B, A), "cuda")
         ref = oracle.dirichlet(key, alpha, B, A)
         assert d.is_cuda and d.dtype == torch.float32 and np.array_equal(ref, d.cpu().numpy()), (B, A)

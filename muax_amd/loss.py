@@ -1,8 +1,9 @@
-"""k-step unrolled MuZero loss of the reference (muax/loss.py:10-88) on torch autograd.
+"""k-step unrolled MuZero loss of the reference (muax/loss.py:10-88): SURVEY.md 8(f) n1.
 
-INTERIM implementation of SURVEY.md 8(f) n1: the arithmetic is plain PyTorch ops on the GPU (autograd
-for the backward pass), not yet a hand-written fused fwd/bwd HIP kernel -- that kernel is the next-round
-item.  What is pinned here is the reference's formula:
+Two routes to the same number.  `default_loss_fn` is the formula in plain PyTorch ops (autograd does the backward
+pass): it serves plugin nets and custom losses, and it is the reference the fused kernel is tested against.
+`FusedLossGrad` (below) is the product path for the default MLP trio: loss and every gradient from ONE hand-written
+forward+backward HIP kernel (muax_amd/csrc/mz_train.cuh through mzs_mlp_loss_grad).  The reference's formula:
 
     loss = sum_{i<L} [ mean_B CE(r_logits_i, support(r_i)) + mean_B CE(v_logits_i, support(Rn_i))
                        + mean_B CE(pi_logits_i, pi_i) ]  +  1e-4 * 0.5 * sum ||param||^2

@@ -189,10 +189,12 @@ def mlp_trio_weights(network: MZNetwork) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------
-# Convolutional plugin nets (muax/nn.py:47-56,118-395).  INTERIM: plain torch modules
-# (MIOpen / hipBLASLt kernels underneath) that the step-wise search drives -- optionally as one hipGraph
-# (MuZero(capture_graph=True)).  They are NOT hand-written MFMA kernels; the tree kernels either side of
-# them are.  Tensors keep the reference's NHWC layout at every module boundary (embedding [B, H, W, C]);
+# Convolutional plugin nets (muax/nn.py:47-56,118-395) as torch modules (MIOpen / hipBLASLt
+# kernels underneath) that the step-wise search drives -- optionally as one hipGraph (MuZero(capture_graph=True)).
+# Inside the search the ResNet nets' whole recurrent_fn (ResNetDynamic + ResNetPrediction + both decodes) runs as
+# ONE hand-written fp32-MFMA launch instead (mzs_resnet_tower, muax_amd/csrc/mz_conv.cuh; ResNetDynamic._tower_hip
+# below); the modules remain the definition it is tested against, the root's representation net
+# and the training path.  Tensors keep the reference's NHWC layout at every module boundary (embedding [B, H, W, C]);
 # inside a convolution the same memory is viewed as channels_last NCHW, so no transposes are made.
 # ---------------------------------------------------------------------------------------------------
 def min_max_normalize2d(s: torch.Tensor) -> torch.Tensor:

@@ -31,7 +31,30 @@ class Transition:
         return Transition(*(x[index] for x in self))
 
 
-class NStep:
+def flatten_transition_func(transition):
+    """muax/episode_tracer.py:58-59 (the pytree flattening of a Transition): (leaves, treedef)."""
+    return iter(dataclasses.astuple(transition) if dataclasses.is_dataclass(transition) else transition), None
+
+
+def unflatten_transition_func(treedef, leaves):
+    """muax/episode_tracer.py:61-62."""
+    return Transition(*leaves)
+
+
+class BaseTracer:
+    """muax/episode_tracer.py:71-111: what fit() needs from a tracer."""
+
+    def reset(self):
+        raise NotImplementedError
+
+    def add(self, obs, a, r, done, v=0.0, pi=0.0, w=1.0):
+        raise NotImplementedError
+
+    def pop(self):
+        raise NotImplementedError
+
+
+class NStep(BaseTracer):
     """muax/episode_tracer.py:118-195: Rn = sum_{i<n} gamma^i r_{t+i} + gamma^n v_{t+n}; towards the end
     of an episode the sum is truncated and nothing is bootstrapped (done=True)."""
 

@@ -104,7 +104,30 @@ class Trajectory:
         return f"{type(self)}(len={len(self)})"
 
 
-class TrajectoryReplayBuffer:
+class BaseReplayBuffer:
+    """muax/replay_buffer.py:122-147: the interface fit() uses (capacity, add, sample, clear, len, bool)."""
+
+    @property
+    def capacity(self):
+        raise NotImplementedError
+
+    def add(self, transition_batch):
+        raise NotImplementedError
+
+    def sample(self, batch_size=32):
+        raise NotImplementedError
+
+    def clear(self):
+        raise NotImplementedError
+
+    def __len__(self):
+        raise NotImplementedError
+
+    def __bool__(self):
+        return len(self) > 0
+
+
+class TrajectoryReplayBuffer(BaseReplayBuffer):
     """muax/replay_buffer.py:161-262: ring buffer of trajectories."""
 
     def __init__(self, capacity, random_seed=None, transition_class=Transition):

@@ -47,11 +47,12 @@ def rollout(model, env, key, num_simulations: int = 50, temperature: float = 1.0
     return traj, key
 
 
-def test(model, env, key, num_simulations: int, num_test_episodes: int = 10, max_steps=None):
-    """muax/test.py:5-48: greedy evaluation (temperature=0.), mean undiscounted episode return."""
+def test(model, env, key, num_simulations: int, num_test_episodes: int = 10, random_seed=None, max_steps=None):
+    """muax/test.py:5-48: greedy evaluation (temperature=0.), mean undiscounted episode return.  `random_seed` goes
+    to env.reset(seed=...) at every episode as in the reference (None: the environment's own stream)."""
     total_rewards = np.zeros(num_test_episodes)
     for episode in range(num_test_episodes):
-        obs, info = env.reset()
+        obs, info = env.reset() if random_seed is None else env.reset(seed=random_seed)
         steps = max_steps if max_steps is not None else env.spec.max_episode_steps
         for t in range(steps):
             key, subkey = prng.split(key)

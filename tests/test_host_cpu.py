@@ -350,3 +350,31 @@ def test_reference_checkpoint_reader_accepts_other_plausible_writers(tmp_path):
     with pytest.raises(ValueError):  # not a pickled-object .npy
         np.save(str(tmp_path / "plain.npy"), np.zeros(3))
         checkpoint.read_reference_checkpoint(str(tmp_path / "plain.npy"))
+
+
+def test_small_reference_utilities():
+    """muax/utils.py:37-68,104-223 and the tracer / buffer base classes (muax/episode_tracer.py:58-111,
+    muax/replay_buffer.py:122-147): the diff-transform matrix of the reference's docstring, a hand-computed strided
+    2-step return, the slicing deque, the interfaces fit() relies on."""
+    from muax_amd import utils
+    from muax_amd.episode_tracer import BaseTracer, NStep, PNStep, Transition, flatten_transition_func, unflatten_transition_func
+    from muax_amd.replay_buffer import BaseReplayBuffer, TrajectoryReplayBuffer
+    assert np.array_equal(utils.diff_transform_matrix(4),
+                          np.array([[-1, 0, 0, 0], [3, 1, 0, 0], [-3, -2, -1, 0], [1, 1, 1, 1]], np.float32))
+    x = np.arange(8, dtype=np.float32).reshape(2, 4) ** 2  # frames t-3 .. t on the last axis
+    d = utils.diff_transform(x)
+    assert np.allclose(d[:, 3], x[:, 3]) and np.allclose(d[:, 2], x[:, 3] - x[:, 2])
+    assert np.allclose(d[:, 1], x[:, 3] - 2 * x[:, 2] + x[:, 1])
+    q = utils.sliceable_deque(range(6), maxlen=6)
+    assert list(q[1:4]) == [1, 2, 3] and isinstance(q[1:4], utils.sliceable_deque) and q[2] == 2
+    G = utils.n_step_bootstrapped_returns(np.array([1., 2, 3, 4]), np.full(4, 0.9), np.array([10., 20, 30, 40]), 2)
+    assert np.allclose(G, [1 + .9 * (2 + .9 * 20), 2 + .9 * (3 + .9 * 30), 3 + .9 * (4 + .9 * 40), 4 + .9 * 40])
+    G1 = utils.n_step_bootstrapped_returns(np.array([1., 2, 3]), np.full(3, 0.5), np.array([4., 5, 6]), 1, lambda_t=0.3)
+    assert np.allclose(G1, [1 + .5 * 4, 2 + .5 * 5, 3 + .5 * 6])  # n = 1: one bootstrap step whatever lambda
+    assert utils.action2plane(np.float32(0.25), (3, 6, 6, 1)).shape == (3, 6, 6, 1)
+    assert np.allclose(utils.min_max(np.array([1., 2., 3.]), 1., 3.), [0, .5, 1])
+    assert issubclass(NStep, BaseTracer) and issubclass(PNStep, BaseTracer)
+    assert issubclass(TrajectoryReplayBuffer, BaseReplayBuffer)
+    t = Transition(obs=1, a=2, r=3., done=False, Rn=4., v=5., pi=6., w=1.)
+    leaves, _ = flatten_transition_func(t)
+    assert unflatten_transition_func(None, list(leaves)) == t

@@ -4,9 +4,11 @@
 // root inference, S simulations, summary + sampling.
 //
 // Mapping of the search kernel (MI355X-first, not a translation of mctx's
-// vmapped XLA program).  Measured on gfx950: a lone wavefront pays ~6.5 cycles
-// per dependent VALU op, ~20 per dependent DPP step and ~64 per dependent LDS
-// read, so the design minimises the length of the per-root dependent chain:
+// vmapped XLA program).  Measured on gfx950 (tools/ubench_lat.hip): a lone wavefront
+// issues ONE instruction of any kind per ~4.8 cycles, 8.3 when it depends on the one
+// before, ~20 per dependent DPP step and ~64 per dependent LDS read -- and 4096 roots
+// are exactly one wavefront per SIMD -- so the design minimises the number of
+// instructions of the per-root chain and how many of them wait:
 //   * one search root = one DPP row (16 lanes); 4 roots per wavefront, one
 //     wavefront per SIMD, no barrier after the prologue;
 //   * the root's whole tree lives in LDS for the duration of the act; HBM is
@@ -24,8 +26,10 @@
 //     valid because sub-trees off the backed-up path never change; the path
 //     nodes' words are refreshed with a log-step DPP scan.  Every node also
 //     stores its own root path as packed bytes (written once at expansion), so
-//     the backup lanes find their entries without a walk.  One simulation's
-//     selection is O(1) LDS reads plus one exact noisy evaluation per near tie;
+//     the backup lanes find their entries without a walk.  The root's word lives
+//     in a register (the backup ends by producing it): a simulation's selection
+//     reads NOTHING unless a row meets a near tie or the depth limit, and those
+//     cases sit behind one wave-uniform branch;
 //   * backup is lane-parallel: the discounted-return chain advances all path
 //     entries at once (G[e] = r[e] + g G[e+1] through a row_shl:1 DPP operand),
 //     running means and prior / (visits + 1) divide by small integers with a
@@ -33,8 +37,13 @@
 //   * the node record has an odd word stride (16 records of a row in 16 banks),
 //     embeddings move to HBM when E > 16 so that 16 roots still fit a CU;
 //   * the MLPs run as row-distributed fma chains: input element i lives in lane
-//     i&15 (slot i>>4) and is fetched with a row_newbcast DPP modifier; each
-//     lane keeps its own column of every weight matrix in VGPRs.
+//     i&15 (slot i>>4) and is fetched with a row_newbcast DPP modifier -- fused
+//     into v_fmac_f32_dpp where the chain is scalar, a mov feeding v_pk_fma_f32
+//     where two chains share the input; each lane keeps its own column of every
+//     weight matrix in VGPRs;
+//   * quotients that share a denominator (softmax terms, value scores) divide
+//     through ONE refined reciprocal in packed form, behind a wave-uniform range
+//     test with the IEEE division as the other branch (mz_spec.cuh).
 #pragma once
 #include "mz_spec.cuh"
 

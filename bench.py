@@ -175,12 +175,27 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in sampled]))
+    # SURVEY.md 8(d) read literally: B / wall time of ONE act with the host synchronisation at its end -- the same
+    # launches, one torch.cuda.synchronize() after each (max over ranks like `elapsed`)
+    n_sync = min(steps, 50)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(n_sync):
+        step(warmup + steps + i)
+        torch.cuda.synchronize()
+    synced = (time.perf_counter() - t1) / n_sync
+    if dist:
+        t = torch.tensor([synced], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        synced = float(t.item())
     depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
     actions = search.action.cpu()
     assert int(actions.min()) >= 0 and int(actions.max()) < A
     search.close()
     return {"elapsed": elapsed, "kernel_ms": kernel_ms, "depth_total": depth_total, "weights": weights, "obs": obs,
-            "noise": noise}
+            "noise": noise, "synced_s_per_act": synced}
 
 
 def roofline(workload, B, kernel_ms, depth_total):
@@ -225,6 +240,164 @@ def api_numbers(workload, B, weights, obs, dev, acts=100):
     return out
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of the MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def recurrent_flops_per_root(A=18, F=21):
+    """Useful flops of ONE recurrent_fn call of the reference's ResNet nets on one root (muax/nn.py:118-148,313-378:
+    6x6 map, 64 channels): 1x1 stem on [s, action plane] + 8 blocks x 3 convolutions 3x3 (projection, conv_0, conv_1)
+    + reward / value / policy heads.  Multiply-add = 2 flops; LayerNorm / ELU / decode are not counted."""
+    px = 36
+    conv3 = 2 * px * 9 * 64 * 64
+    stem = 2 * px * 65 * 64
+    r_head = 2 * px * (65 * 64 + 64 * 64) + 2 * (px * 64 * 64 + 64 * F)
+    v_head = 2 * px * (64 * 16 + 16 * 16) + 2 * (px * 16 * 16 + 16 * F)
+    p_head = 2 * px * (64 * 16) + 2 * (px * 16 * 16 + 16 * A)
+    return stem + 24 * conv3 + r_head + v_head + p_head
+
+
+def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
+    """BASELINE configs[3] on ONE GPU's shard (1024 roots / 8 GPUs = 128): Atari-shaped 84x84x4 frames, the reference's
+    ResNet nets (muax/nn.py:313-395; random init), A = 18, num_simulations = 200, through MuZero.act() with the search
+    loop captured in one hipGraph.  The dominant kernel is the recurrent_fn launch (mz_resnet_tower_kernel, fp32 MFMA);
+    it is timed here with HIP events over `tower_launches` back-to-back launches on the stream act() uses, at the
+    shapes the search calls it with; `roofline` prices it against the dense fp32 matrix peak."""
+    import muax_amd as mx
+    A, F, support = 18, 21, 10
+    g = torch.Generator().manual_seed(0)
+    mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, F, generator=g),
+            mx.nn.ResNetDynamic(A, F, generator=g))
+    m = mx.MuZero(*mods, capture_graph=True, device=dev)
+    m.init(0, np.zeros((1, 84, 84, 4), np.float32))
+    obs = torch.randint(0, 256, (roots, 84, 84, 4), generator=g).float().to(dev)
+    kw = dict(obs_from_batch=True, num_simulations=S, device_outputs=True)
+    for i in range(2):
+        m.act(i, obs, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(acts):
+        m.act(10 + i, obs, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / acts
+    t0 = time.perf_counter()
+    for i in range(acts):
+        m.act(20 + i, obs, **kw)
+        torch.cuda.synchronize()
+    dt_sync = (time.perf_counter() - t0) / acts
+    handle = list(m._policy._handles.values())[0]
+    depth = float(handle.depth_sum.float().mean()) / S
+    dy, pred = mods[2], mods[1]
+    s = torch.rand(roots, 6, 6, 64, generator=g).to(dev)
+    a = torch.randint(0, A, (roots,), generator=g).to(dev)
+    for _ in range(10):
+        dy.hip_recurrent(pred, s, a, support)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(tower_launches):
+        dy.hip_recurrent(pred, s, a, support)
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms = e0.elapsed_time(e1) / tower_launches
+    flops = recurrent_flops_per_root(A, F) * roots
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    pair = bool(dy.use_pair_tower) and bool(getattr(dy, "_pair_scratch", None))
+    return {"value": round(roots / dt, 1), "unit": "env-steps/s", "ms_per_act": round(dt * 1e3, 3),
+            "value_synced": round(roots / dt_sync, 1), "acts": acts,
+            "workload": f"atari shard: {roots} roots (1024 / 8 GPUs), obs 84x84x4, ResNet nets (embedding 6x6x64), A={A}, "
+                        f"support {support}, num_simulations={S}, MuZero policy, search loop in one hipGraph",
+            "mean_selection_depth": round(depth, 2), "dtype": "f32",
+            "recurrent_share_of_act": round(kernel_ms * S / (dt * 1e3), 3),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "mz_resnet_tower_kernel" + (" (pair mode: 2 workgroups per root)" if pair else ""),
+                         "kernel_ms": round(kernel_ms, 4), "launches_per_act": S,
+                         "algorithmic_flops_per_launch": int(flops)}}
+
+
+def config5_gumbel_train(dev, B=4096, L=10, S=50, iters=50):
+    """BASELINE configs[4] on one GPU: Gumbel MuZero act() on 4096 roots (num_simulations = 50) and ONE k_steps = 10
+    unrolled training step (loss, 18 gradients, Adam) on 4096 trajectories -- default MLP trio, both single fused
+    launches; with N > 1 ranks the gradient mean is one flat RCCL all-reduce (muax_amd/sharding.py), not timed here."""
+    import muax_amd as mx
+    g = torch.Generator().manual_seed(0)
+    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
+                          mx.nn.Dynamic(8, 2, 21, generator=g))
+    m = mx.MuZero(net, policy="gumbel", device=dev)
+    m.init(0, np.zeros((1, 4)))
+    obs = (torch.rand(B, 4, generator=g) * 2 - 1).to(dev)
+    rng = np.random.default_rng(0)
+    batch = mx.Transition(obs=torch.rand(B, L, 4, generator=g).to(dev), a=torch.randint(0, 2, (B, L), generator=g).to(dev),
+                          r=torch.rand(B, L, generator=g).to(dev), Rn=(torch.rand(B, L, generator=g) * 20).to(dev),
+                          pi=torch.as_tensor(rng.dirichlet([1, 1], (B, L)).astype(np.float32)).to(dev))
+
+    def timeit(fn, n, warm=5, sync_each=False):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    t_act = timeit(lambda: m.act(1, obs, obs_from_batch=True, num_simulations=S, device_outputs=True), iters)
+    t_act_sync = timeit(lambda: m.act(1, obs, obs_from_batch=True, num_simulations=S, device_outputs=True), iters,
+                        sync_each=True)
+    t_upd = timeit(lambda: m.update(batch), iters)
+    return {"act": {"value": round(B / t_act, 1), "unit": "env-steps/s", "ms_per_act": round(t_act * 1e3, 4),
+                    "value_synced": round(B / t_act_sync, 1)},
+            "update": {"value": round(B * L / t_upd, 1), "unit": "transitions/s", "ms_per_update": round(t_upd * 1e3, 4)},
+            "ms_per_iteration": round((t_act + t_upd) * 1e3, 4), "iters": iters, "dtype": "f32",
+            "workload": f"gumbel + train: {B} roots, Gumbel MuZero act() num_simulations={S} (max_num_considered_actions 16, "
+                        f"gumbel_scale 1) + update() on {B} trajectories x k_steps={L}, default MLP trio, Adam"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, LOCAL_RANK ->
+    device ordinal, rendezvous on a free 127.0.0.1 port), let rank 0 print the line, and fail loudly when fewer than
+    N devices are visible.  MUAX_BENCH_SINGLE_DEVICE=1 (dry run on a 1-GPU box) puts every rank on device 0 over gloo."""
+    import socket
+    import subprocess
+    n = args.gpus
+    single = bool(os.environ.get("MUAX_BENCH_SINGLE_DEVICE"))
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if single else n):
+        raise SystemExit(f"bench.py --gpus {n}: only {have} ROCm device(s) visible "
+                         f"(set MUAX_BENCH_SINGLE_DEVICE=1 to dry-run {n} ranks on device 0)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MUAX_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,25 +410,35 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the api / config-3 sub-objects of the JSON line")
     ap.add_argument("--settle-ms", type=float, default=30.0,
                     help="untimed launches before the warm-up steps until the GPU clocks have ramped (see fused_run)")
+    ap.add_argument("--no-config45", action="store_true", help="skip the config4_atari / config5_gumbel_train sub-objects")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N "
+                         f"(plain `python bench.py --gpus N` starts them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
-    # test-only overrides (dry run of the N>1 code path on a 1-GPU box): every rank on device 0, gloo
-    if os.environ.get("MUAX_BENCH_SINGLE_DEVICE"):
+    # dry run of the N>1 code path on a 1-GPU box: every rank on device 0 (RCCL wants one device per rank -> gloo)
+    single = bool(os.environ.get("MUAX_BENCH_SINGLE_DEVICE"))
+    if single:
         local_rank = 0
-    backend = os.environ.get("MUAX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+    backend = os.environ.get("MUAX_BENCH_BACKEND", "gloo" if single else "nccl")  # "nccl" is RCCL on ROCm
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} ROCm device(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     B, obs_dim, E, A, support, S = WORKLOADS[args.workload]
     if args.roots:
@@ -266,12 +449,19 @@ def main():
                     args.settle_ms)
     elapsed, kernel_ms, depth_total, weights, obs, noise = (run[k] for k in ("elapsed", "kernel_ms", "depth_total",
                                                                                "weights", "obs", "noise"))
+    placement = [f"rank {rank}: cuda:{local_rank} ({torch.cuda.get_device_properties(local_rank).gcnArchName.split(':')[0]})"]
+    if dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, placement[0])
+        placement = gathered
 
     if rank == 0:
         line = {
             "metric": "batched act() env-steps/sec at num_simulations=50",
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "env-steps/s",
+            # the same launches with torch.cuda.synchronize() after EVERY act ("host sync at the end included")
+            "value_synced": round(B * world / run["synced_s_per_act"], 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -280,7 +470,10 @@ def main():
                                    f"support {support}, num_simulations={S}, dirichlet 0.25/0.3, "
                                    f"tiebreak={'threefry' if not args.no_tiebreak else 'off'}, temperature 1",
                        "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective",
-                       "clock_settle_ms_before_warmup": args.settle_ms},
+                       "clock_settle_ms_before_warmup": args.settle_ms,
+                       "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else "none (one rank)"),
+                       "launcher": os.environ.get("MUAX_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none"),
+                       "ranks": placement},
             "roofline": roofline(args.workload, B, kernel_ms, depth_total),
         }
         if world == 1 and not args.no_extras:
@@ -293,9 +486,13 @@ def main():
                 steps3 = max(20, args.steps // 4)
                 line["config3_lunarlander"] = {
                     "value": round(B3 * steps3 / r3["elapsed"], 1), "unit": "env-steps/s", "steps": steps3,
+                    "value_synced": round(B3 / r3["synced_s_per_act"], 1),
                     "ms_per_step": round(r3["elapsed"] / steps3 * 1e3, 4),
                     "workload": f"lunarlander: {B3} roots, obs 8, MLP embed 32, A=4, support 10, num_simulations=50",
                     "roofline": roofline("lunarlander", B3, r3["kernel_ms"], r3["depth_total"])}
+        if world == 1 and not args.no_extras and not args.no_config45 and args.workload == "cartpole" and not args.roots:
+            line["config4_atari"] = config4_atari(dev)
+            line["config5_gumbel_train"] = config5_gumbel_train(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, obs.numpy(), noise.numpy(), A, E, F, S, support)
         print(json.dumps(line), flush=True)

@@ -76,6 +76,16 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     tag = "" if not variant else "_" + os.path.splitext(os.path.basename(out))[0]
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    import fcntl
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        # ranks that find the library missing at the same time build one after the other, not into each other's files
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not variant and not stale():
+            return LIB_PATH  # another process built it while this one waited
+        return _build_locked(force, verbose, extra_flags, out, variant, tag)
+
+
+def _build_locked(force, verbose, extra_flags, out, variant, tag) -> str:
     cc = hipcc()
     jobs = []
     for unit in UNITS:
@@ -84,13 +94,25 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in jobs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [_obj(u, tag) for u in UNITS]
+    failed = None
+    for cmd, p in jobs:  # every compiler is waited for, also after a failure: no orphans writing into lib/obj
+        if p.wait() != 0 and failed is None:
+            failed = (p.returncode, cmd)
+            for _, q in jobs:
+                if q.poll() is None:
+                    q.terminate()
+    if failed:
+        raise subprocess.CalledProcessError(*failed)
+    tmp = out + f".tmp{os.getpid()}"
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [_obj(u, tag) for u in UNITS]
     if verbose:
         print(" ".join(link))
-    subprocess.check_call(link)
+    try:
+        subprocess.check_call(link)
+        os.replace(tmp, out)  # a process that has the old library mapped keeps its inode
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     if variant:
         for u in UNITS:
             os.remove(_obj(u, tag))

@@ -72,7 +72,7 @@ struct mzs_handle {
   int32_t* fused_path = nullptr;   // fused path, compact instances: [B][S+1][kCompactPathWords] root paths in HBM
   int cu_count = 0;
   // mzs_act_mlp_host: pinned staging (in: obs | noise | invalid, out: action | weights | value) and their device twins
-  void* host_in = nullptr; void* host_out = nullptr; void* dev_in = nullptr; void* dev_out = nullptr;
+  void* host_in = nullptr; void* host_out = nullptr; void* dev_noise = nullptr;  // dev_noise: [B, A] drawn root noise
   size_t host_in_bytes = 0;
   mz::JumpArgs jump = {nullptr, nullptr, nullptr, nullptr};  // step-wise path with cached decisions
   void* jump_slab = nullptr;
@@ -204,8 +204,7 @@ int mzs_destroy(mzs_handle* h) {
   if (h->jump_slab) hipFree(h->jump_slab);
   if (h->host_in) hipHostFree(h->host_in);
   if (h->host_out) hipHostFree(h->host_out);
-  if (h->dev_in) hipFree(h->dev_in);
-  if (h->dev_out) hipFree(h->dev_out);
+  if (h->dev_noise) hipFree(h->dev_noise);
   delete h;
   return MZS_OK;
 }
@@ -333,21 +332,17 @@ int mzs_act_mlp_host(mzs_handle* h, const mzs_act_host_args* a, void* stream_) {
   const size_t obs_b = B * OD * 4, noise_b = B * A * 4, inv_b = (B * A + 3) / 4 * 4, in_b = obs_b + noise_b + inv_b;
   const size_t out_b = B * (2 + A) * 4;
   if (h->host_in_bytes < in_b) {
-    if (h->host_in) { hipHostFree(h->host_in); hipFree(h->dev_in); h->host_in = h->dev_in = nullptr; }
+    if (h->host_in) { hipHostFree(h->host_in); h->host_in = nullptr; }
     MZS_HIP(h, hipHostMalloc(&h->host_in, in_b, hipHostMallocDefault));
-    MZS_HIP(h, hipMalloc(&h->dev_in, in_b));
     h->host_in_bytes = in_b;
   }
-  if (!h->host_out) {
-    MZS_HIP(h, hipHostMalloc(&h->host_out, out_b, hipHostMallocDefault));
-    MZS_HIP(h, hipMalloc(&h->dev_out, out_b));
-  }
+  if (!h->host_out) MZS_HIP(h, hipHostMalloc(&h->host_out, out_b, hipHostMallocDefault));
+  if (!h->dev_noise) MZS_HIP(h, hipMalloc(&h->dev_noise, noise_b));
   // The kernels read the host's inputs and write its outputs THROUGH THE PINNED STAGING BUFFERS themselves (hipHostMalloc
   // memory is mapped into the device's address space, coherent): an act moves 16..32 bytes per root each way, read once
   // at the kernel's start and written once at its end, and a copy command costs more in launch and engine latency than
   // those bytes cost over the host link.  Only the drawn root noise lives in device memory (its producer is a kernel).
   char* hin = static_cast<char*>(h->host_in);
-  char* din = static_cast<char*>(h->dev_in);
   char* hin_dev = nullptr;
   float* hout_dev = nullptr;
   MZS_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&hin_dev), h->host_in, 0));
@@ -355,7 +350,7 @@ int mzs_act_mlp_host(mzs_handle* h, const mzs_act_host_args* a, void* stream_) {
   const bool muzero = c.policy == 0;
   const bool given = muzero && a->dirichlet_noise != nullptr;
   const bool draw = muzero && !given && a->draw_dirichlet != 0 && a->dirichlet_fraction != 0.0f;
-  float* d_noise = reinterpret_cast<float*>(din + obs_b);
+  float* d_noise = static_cast<float*>(h->dev_noise);
   if (draw) {  // first: it needs nothing from the host and runs while the host fills the staging buffer
     uint32_t kd[2];
     h_split(a->key, 3, 1, kd);  // mctx: rng_key, dirichlet_rng_key, search_rng_key = split(rng_key, 3)

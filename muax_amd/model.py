@@ -40,10 +40,12 @@ def _dirichlet(key_words, alpha: float, shape, device, global_batch=None, root_o
     if device.type != "cuda":
         raise RuntimeError("muax_amd draws the root noise on the GPU (there is no CPU search path)")
     B, A = shape
-    out = torch.empty(B, A, dtype=torch.float32, device=device)
     kw = (C.c_uint32 * 2)(int(key_words[0]) & 0xFFFFFFFF, int(key_words[1]) & 0xFFFFFFFF)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device("cuda", idx)  # ONE ordinal for the buffer, the stream and the launch
+    out = torch.empty(B, A, dtype=torch.float32, device=device)
     with torch.cuda.device(device):
-        _lib.check(_lib.load().mzs_dirichlet(device.index or 0, C.byref(kw), float(alpha), B, A, global_batch or B,
+        _lib.check(_lib.load().mzs_dirichlet(idx, C.byref(kw), float(alpha), B, A, global_batch or B,
                                              root_offset, out.data_ptr(),
                                              C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
     return out
@@ -172,7 +174,12 @@ class MuZero:
             key = (tuple(obs.shape), obs.dtype, obs.device, self._weights_version)
             ent = self._root_graphs.get(key)
             if ent is None:
-                self._root_graphs.clear()  # older weight versions / shapes: drop their graphs and buffers
+                # drop graphs of stale weights; keep the other shapes of THIS version (a B = 1 test rollout next to
+                # a batched act() must not re-capture on every alternation), at most four of them
+                for k in [k for k in self._root_graphs if k[3] != self._weights_version]:
+                    del self._root_graphs[k]
+                while len(self._root_graphs) >= 4:
+                    del self._root_graphs[next(iter(self._root_graphs))]
                 static_in = obs.clone()
                 cur = torch.cuda.current_stream(obs.device)
                 side = torch.cuda.Stream(device=obs.device)
@@ -185,6 +192,8 @@ class MuZero:
                 with torch.cuda.graph(g):
                     out = self._root_inference_eager(static_in)
                 ent = self._root_graphs[key] = (g, static_in, out)
+            else:
+                self._root_graphs[key] = self._root_graphs.pop(key)  # most recently used last
             ent[1].copy_(obs)
             ent[0].replay()
             return ent[2]
@@ -351,7 +360,9 @@ class MuZero:
         """Run a step-wise search; if the ResNet recurrent kernel went through pair mode (two workgroups per
         root meeting in L2, mz_conv.cuh) and any rendezvous was lost -- in ANY launch of the search, graph
         replays included -- drop pair mode and repeat the search with one workgroup per root.  Both launch
-        shapes produce the same bits, so the repeat is what the undisturbed search would have returned."""
+        shapes produce the same bits, so the repeat is what the undisturbed search would have returned.
+        Reading the status words synchronises the device: a pair-mode search (<= 128 roots of the ResNet nets) is
+        not sync-free even with device_outputs=True."""
         out = run()
         dy = self.dy_func
         if getattr(dy, "_pair_scratch", None) and dy.pair_lost():
@@ -362,6 +373,8 @@ class MuZero:
             dy.disable_pair_mode()
             self._weights_version += 1  # captured graphs hold pair-mode launches: re-capture
             out = run()
+            if getattr(dy, "_pair_scratch", None):  # the repeat must not have gone through pair mode again
+                raise RuntimeError("muax_amd: pair mode is still active after it was disabled")
         return out
 
     def act(self, rng_key, obs, with_pi: bool = False, with_value: bool = False, obs_from_batch: bool = False,

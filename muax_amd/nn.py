@@ -570,7 +570,8 @@ class ResNetDynamic(nn.Module):
         y = torch.empty_like(x)
         args = _lib.MzsTowerArgs()
         args.struct_size = C.sizeof(_lib.MzsTowerArgs)
-        args.device = x.device.index or 0
+        dev_index = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        args.device = dev_index
         args.batch, args.blocks, args.normalize, args.num_actions = x.shape[0], len(self.ns_blocks), 1, self.num_actions
         args.x, args.action, args.stem_w = x.data_ptr(), act.data_ptr(), stem.data_ptr()
         args.conv_w, args.ln, args.y = conv.data_ptr(), ln.data_ptr(), y.data_ptr()
@@ -594,7 +595,7 @@ class ResNetDynamic(nn.Module):
             # <= 128 roots: two workgroups per root (mz_conv.cuh, pair mode) so that the launch covers the chip
             nbytes = L.mzs_tower_pair_scratch_bytes(x.shape[0])
             if nbytes:
-                key = (x.device.index or 0, x.shape[0], stream)
+                key = (dev_index, x.shape[0], stream)
                 first = key not in self._pair_scratch
                 if first:
                     self._pair_scratch[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
@@ -625,6 +626,7 @@ class ResNetDynamic(nn.Module):
 
     def disable_pair_mode(self):
         type(self).use_pair_tower = False
+        self.__dict__.pop("use_pair_tower", None)  # an instance attribute (tests set one) would shadow the class's
         self._pair_scratch.clear()
 
     def hip_recurrent(self, pred, s, a, support_size: int):

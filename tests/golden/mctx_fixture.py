@@ -1,0 +1,207 @@
+"""Format, reader and comparer of the mctx/JAX golden captures (tests/golden/mctx_*.npz).
+
+A capture is written by tests/golden/capture_from_mctx.py on a machine that HAS jax + mctx + dm-haiku (and the
+reference's muax glue); this build container and the GPU box have none of them, so the files are absent until
+someone runs that script ("Pinning the oracle").  When present, tests/test_mctx_pin_cpu.py compares
+the CPU oracle with them and tests/test_gpu_mctx_pin.py the HIP path: integers exact, floats to 1e-5
+(BASELINE.json's bar).  This module is test infrastructure: nothing under muax_amd/ imports it.
+
+One capture = one `MuZero._plan(params, key, obs, ...)` call of the reference (muax/model.py:222-243) on the default
+MLP trio, B roots:
+
+  meta                json: policy, shapes, keyword arguments, recurrent_pred_on, library versions, route
+  w_<name>            the 18 weight arrays in the C-ABI's naming (include/mzsearch.h; haiku layout w[in][out])
+  obs [B, obs_dim]    f32;  key uint32[2] (jax.random.PRNGKey data)
+  action [B] i32, action_weights [B, A] f32, root_value [B] f32
+  tree_<field>        mctx.Tree arrays: node_visits, parents, action_from_parent [B, N] i32; raw_values, node_values
+                      [B, N] f32; children_index, children_visits [B, N, A] i32; children_prior_logits,
+                      children_values, children_rewards, children_discounts [B, N, A] f32; embeddings [B, N, E] f32
+  rng_dirichlet [B, A]            jax.random.dirichlet(split(key, 3)[1], alpha * ones(A), (B,))        (muzero)
+  rng_tiebreak [S, B, D, A]       uniform(k_sel, (A,)) of simulation s, root b, selection level d < D    (muzero)
+  rng_final_gumbel [B, A]         gumbel(split(key, 3)[0], (B, A)): the categorical draw of the action   (muzero)
+  rng_root_gumbel [B, A]          gumbel(split(key)[1], (B, A))                                          (gumbel)
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FORMAT_VERSION = 1
+WEIGHT_NAMES = ("repr_w", "repr_b", "pv_w1", "pv_b1", "pv_w2", "pv_b2", "pp_w1", "pp_b1", "pp_w2", "pp_b2",
+                "dr_w1", "dr_b1", "dr_w2", "dr_b2", "dn_w1", "dn_b1", "dn_w2", "dn_b2")
+TREE_INT = ("node_visits", "parents", "action_from_parent", "children_index", "children_visits")
+TREE_FLOAT = ("raw_values", "node_values", "children_prior_logits", "children_values", "children_rewards",
+              "children_discounts", "embeddings")
+FLOAT_TOL = 1e-5  # BASELINE.json: "within 1e-5 on value/policy logits"
+
+
+def fixture_paths():
+    """Real captures present in tests/golden (never the synthetic self-test files)."""
+    return sorted(glob.glob(os.path.join(HERE, "mctx_*.npz")))
+
+
+def save_case(path, meta: dict, weights: dict, obs, key, outputs: dict, tree: dict, rng: dict):
+    meta = dict(meta, format_version=FORMAT_VERSION)
+    data = {"meta": np.array(json.dumps(meta, sort_keys=True)), "obs": np.asarray(obs, np.float32),
+            "key": np.asarray(key, np.uint32).reshape(2)}
+    for k in WEIGHT_NAMES:
+        data["w_" + k] = np.asarray(weights[k], np.float32)
+    data["action"] = np.asarray(outputs["action"], np.int32)
+    data["action_weights"] = np.asarray(outputs["action_weights"], np.float32)
+    data["root_value"] = np.asarray(outputs["root_value"], np.float32)
+    for k in TREE_INT:
+        data["tree_" + k] = np.asarray(tree[k], np.int32)
+    for k in TREE_FLOAT:
+        data["tree_" + k] = np.asarray(tree[k], np.float32)
+    for k, v in rng.items():
+        data["rng_" + k] = np.asarray(v, np.float32)
+    np.savez_compressed(path, **data)
+
+
+def load_case(path) -> dict:
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    if meta.get("format_version") != FORMAT_VERSION:
+        raise ValueError(f"{path}: capture format {meta.get('format_version')}, this reader knows {FORMAT_VERSION}")
+    case = {"path": path, "meta": meta, "obs": z["obs"], "key": z["key"],
+            "w": {k: z["w_" + k] for k in WEIGHT_NAMES},
+            "action": z["action"], "action_weights": z["action_weights"], "root_value": z["root_value"],
+            "tree": {k: z["tree_" + k] for k in TREE_INT + TREE_FLOAT},
+            "rng": {k[4:]: z[k] for k in z.files if k.startswith("rng_")}}
+    return case
+
+
+# --------------------------------------------------------------------------------------------------------------
+# comparing
+# --------------------------------------------------------------------------------------------------------------
+def _diff(name, want, got, exact, tol=FLOAT_TOL):
+    want, got = np.asarray(want), np.asarray(got)
+    if want.shape != got.shape:
+        return [f"{name}: shape {got.shape}, capture has {want.shape}"]
+    if exact:
+        bad = np.argwhere(want != got)
+        if bad.size:
+            i = tuple(bad[0])
+            return [f"{name}: {len(bad)} of {want.size} differ, first at {i}: {got[i]} (capture {want[i]})"]
+        return []
+    err = np.abs(want.astype(np.float64) - got.astype(np.float64))
+    lim = tol * np.maximum(1.0, np.abs(want.astype(np.float64)))
+    bad = np.argwhere(err > lim)
+    if bad.size:
+        i = tuple(bad[0])
+        return [f"{name}: {len(bad)} of {want.size} beyond {tol:g}, worst {err.max():.3g}, first at {i}: "
+                f"{got[i]!r} (capture {want[i]!r})"]
+    return []
+
+
+def compare_outputs(case, got, with_tree=True):
+    """`got`: {"action", "action_weights", "root_value"[, "tree": {field: array}]} -> list of mismatch messages.
+    Integers (actions, every index / visit array) exact; floats to FLOAT_TOL relative-or-absolute.  Embeddings of
+    nodes no simulation created are compared too (both sides leave them zero)."""
+    msgs = _diff("action", case["action"], got["action"], True)
+    msgs += _diff("action_weights", case["action_weights"], got["action_weights"], False)
+    msgs += _diff("root_value", case["root_value"], got["root_value"], False)
+    if with_tree and got.get("tree") is not None:
+        for k in TREE_INT:
+            msgs += _diff("tree." + k, case["tree"][k], got["tree"][k], True)
+        for k in TREE_FLOAT:
+            msgs += _diff("tree." + k, case["tree"][k], got["tree"][k], False)
+    return msgs
+
+
+# --------------------------------------------------------------------------------------------------------------
+# running the oracle on a capture's inputs
+# --------------------------------------------------------------------------------------------------------------
+def _mlp(po, case):
+    m = case["meta"]
+    return po.Mlp(case["w"], m["obs_dim"], m["E"], m["A"], 2 * m["support_size"] + 1, discount=m["discount"],
+                  support_size=m["support_size"], recurrent_pred_on=1 if m["recurrent_pred_on"] == "parent" else 0)
+
+
+def oracle_rng(po, case) -> dict:
+    """The PRNG intermediates of the capture, recomputed with the oracle's threefry walk (RNG
+    stream).  Uniform bits are exact integers scaled by powers of two -> compared exactly; Dirichlet / Gumbel go
+    through log / erf_inv -> FLOAT_TOL."""
+    m, key = case["meta"], [int(x) for x in case["key"]]
+    B, A, S = case["obs"].shape[0], m["A"], m["num_simulations"]
+    out = {}
+    if m["policy"] == "muzero":
+        k_sample, k_dir, sim_keys = po.sim_keys_from_act_key(key, S)
+        out["dirichlet"] = po.dirichlet(k_dir, m["dirichlet_alpha"], B, A)
+        out["final_gumbel"] = po.gumbel(k_sample, B * A).reshape(B, A)
+        if "tiebreak" in case["rng"]:
+            D = case["rng"]["tiebreak"].shape[2]
+            tb = np.zeros((S, B, D, A), np.float32)
+            for s in range(S):
+                roots = po.split(sim_keys[s], B)
+                for b in range(B):
+                    rk = roots[b]
+                    for d in range(D):
+                        two = po.split(rk, 2)
+                        rk = two[0]
+                        tb[s, b, d] = po.uniform(two[1], A)
+            out["tiebreak"] = tb
+    else:
+        out["root_gumbel"] = po.gumbel(po.split(key, 2)[1], B * A).reshape(B, A)
+    return out
+
+
+def compare_rng(case, got) -> list:
+    msgs = []
+    for k, want in case["rng"].items():
+        if k in got:
+            msgs += _diff("rng." + k, want, got[k], exact=(k == "tiebreak"))
+    return msgs
+
+
+def oracle_run(po, case, dirichlet_from="oracle") -> dict:
+    """The oracle's act() on the capture's inputs.  `dirichlet_from`: "oracle" draws the root noise with the oracle's
+    restatement of jax.random.dirichlet (everything from the key, as a caller gets it); "capture" injects the
+    captured array (isolates the search from the sampler's float bits)."""
+    m, key = case["meta"], [int(x) for x in case["key"]]
+    B, A, S, E = case["obs"].shape[0], m["A"], m["num_simulations"], m["E"]
+    mlp = _mlp(po, case)
+    if m["policy"] == "muzero":
+        if dirichlet_from == "capture":
+            noise = case["rng"]["dirichlet"]
+        else:
+            noise = po.dirichlet(po.split(key, 3)[1], m["dirichlet_alpha"], B, A)
+        cfg = po.SearchCfg(S, max_depth=m.get("max_depth") or 0, pb_c_init=m["pb_c_init"], pb_c_base=m["pb_c_base"],
+                           tiebreak=1)
+        out = po.act_mlp(mlp, cfg, case["obs"], key, noise, m["dirichlet_fraction"], None, m["temperature"])
+        return {"action": out["action"], "action_weights": out["action_weights"], "root_value": out["root_value"],
+                "tree": out["tree"].arrays()}
+    kind = 1 if m["qtransform"].endswith("mix_value") else 0
+    pl, v, emb = po.root_inference(mlp, case["obs"])
+    g = po.gumbel(po.split(key, 2)[1], B * A).reshape(B, A) * np.float32(m.get("gumbel_scale", 1.0))
+    tree = po.Tree(B, S + 1, A, E)
+    cfg = po.SearchCfg(S, max_depth=m.get("max_depth") or 0)
+    po.tree_init(tree, po.mask_root_logits(pl, None), v, emb, None)
+    for sim in range(S):
+        p_, a_, _ = po.gumbel_step_select(tree, cfg, g, kind, m["max_num_considered_actions"])
+        po.step_expand_backup(tree, sim, p_, a_, *po.recurrent_inference(mlp, a_, tree.embeddings[np.arange(B), p_]))
+    action, weights = po.gumbel_finish(tree, g, kind)
+    return {"action": action, "action_weights": weights, "root_value": v, "tree": tree.arrays()}
+
+
+def synthetic_case(po, path, policy="muzero", seed=0, B=8, obs_dim=4, E=8, A=2, S=10, key=(0, 42), D=4):
+    """A file in the capture format whose 'reference' side is the oracle itself -- NOT a pin: it exists so that the
+    reader, the comparers and the HIP-side harness are exercised (and shown to fail on a perturbed file) before any
+    real capture exists.  Written to a temporary path by the tests, never into tests/golden."""
+    support = 10
+    w = po.random_mlp_weights(seed, obs_dim, E, A, 2 * support + 1, bias_scale=0.1)
+    obs = np.random.default_rng(seed + 7).uniform(-1, 1, (B, obs_dim)).astype(np.float32)
+    meta = {"policy": policy, "A": A, "E": E, "obs_dim": obs_dim, "num_simulations": S, "support_size": support,
+            "discount": 0.99, "temperature": 1.0, "dirichlet_fraction": 0.25, "dirichlet_alpha": 0.3,
+            "pb_c_init": 1.25, "pb_c_base": 19652.0, "max_depth": None, "recurrent_pred_on": "child",
+            "qtransform": "qtransform_by_parent_and_siblings", "max_num_considered_actions": 16, "gumbel_scale": 1.0,
+            "route": "synthetic (oracle output in the capture format; not a reference output)", "versions": {}}
+    case = {"meta": meta, "w": w, "obs": obs, "key": np.array(key, np.uint32), "rng": {"tiebreak": np.zeros((S, B, D, A))}}
+    rng = oracle_rng(po, case)
+    out = oracle_run(po, case)
+    save_case(path, meta, w, obs, key, out, out["tree"], rng)
+    return path

@@ -112,3 +112,61 @@ def test_bench_launcher_contract_with_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "weak" and line["unit"] == "env-steps/s"
     assert line["value"] > 1e6 and abs(line["value"] - 2 * 4096 * 10 / (line["ms_per_step"] * 10e-3)) < 0.01 * line["value"]
     assert "cpu_baseline" not in line and line["roofline"]["frac"] > 0
+
+
+def test_bench_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command): bench.py starts
+    the two ranks itself; on this 1-GPU box both sit on device 0 (MUAX_BENCH_SINGLE_DEVICE) over gloo.  One JSON line,
+    n_gpus 2, the ranks' devices and the backend named in config."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MUAX_BENCH_SINGLE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "weak"
+    assert line["config"]["launcher"] == "self" and line["config"]["backend"] == "gloo"
+    assert len(line["config"]["ranks"]) == 2 and all("cuda:0" in r for r in line["config"]["ranks"])
+    assert abs(line["value"] - 2 * 4096 * 10 / (line["ms_per_step"] * 10e-3)) < 0.01 * line["value"]
+    assert 0 < line["value_synced"] <= line["value"] * 1.05
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """Without the dry-run switch a plain `--gpus 2` on a 1-GPU box must fail loudly, not print n_gpus: 1."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MUAX_BENCH_SINGLE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr and "{" not in out.stdout
+
+
+def test_bench_line_schema_at_one_gpu():
+    """The driver's N = 1 command: the line carries roofline, cpu_baseline, api, config 3/4/5 sub-objects, and
+    roofline.frac is algorithmic bytes / kernel time / 8 TB/s recomputed from its own fields."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "api", "value_synced",
+                "config3_lunarlander", "config4_atari", "config5_gumbel_train"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["vs_baseline"] is None and line["dtype"] == "f32"
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 8e12) < 2e-3 * r["frac"] + 1e-4
+    assert abs(r["achieved"] - r["frac"] * 8000.0) < 0.5
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert line["api"]["numpy"]["value"] > 0 and line["api"]["device"]["value"] > 0
+    r4 = line["config4_atari"]["roofline"]
+    assert r4["bound"] == "mfma" and r4["peak"] == 157.3
+    assert abs(r4["frac"] - r4["algorithmic_flops_per_launch"] / (r4["kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
+    c5 = line["config5_gumbel_train"]
+    assert c5["act"]["ms_per_act"] > 0 and c5["update"]["ms_per_update"] > 0

@@ -476,23 +476,38 @@ def test_gumbel_stepwise_matches_oracle(oracle, A, E, S, B, maxc, qt, walk, monk
         assert (case["invalid"][np.arange(B), a_ref][ok] == 0).all()
 
 
-def test_gumbel_policy_through_model_act():
-    """MuZero(policy_class=GumbelMuZeroPolicy).act(): the reference's contract; injected zero Gumbel noise
-    makes the chosen action the argmax of logits + completed Q among the most visited."""
+def test_gumbel_policy_through_model_act(oracle):
+    """MuZero(policy_class=GumbelMuZeroPolicy).act(): the reference's contract (muax/policy.py:33-47 behind
+    muax/model.py:82-179), checked against mctx.gumbel_muzero_policy as the oracle restates it, driven with the
+    same key: actions and action weights equal, both qtransforms, batched and unbatched."""
     import muax_amd as mx
+    from muax_amd import prng
     g = torch.Generator().manual_seed(1)
     net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(4, 21, generator=g),
                           mx.nn.Dynamic(8, 4, 21, generator=g))
     m = mx.MuZero(net, policy_class=mx.GumbelMuZeroPolicy)
     m.init(0, np.zeros((1, 6)))
     obs = np.random.default_rng(3).uniform(-1, 1, (40, 6)).astype(F32)
+    w = {k: v.detach().cpu().numpy() for k, v in mx.nn.mlp_trio_weights(m.network).items()}
+
+    def want(rows, kind, maxc):
+        case = {"B": rows.shape[0], "A": 4, "E": 8, "S": 24, "w": w, "obs_dim": 6, "F": 21, "obs": rows, "invalid": None}
+        return _gumbel_oracle_act(oracle, case, [int(x) for x in prng.as_key(11)], kind, maxc)
+
     a, pi, v = m.act(11, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=24)
     assert a.shape == (40,) and pi.shape == (40, 4) and np.allclose(pi.sum(1), 1, atol=1e-5)
+    ref = want(obs, 0, 16)  # muax/model.py:230-231 forces by_parent_and_siblings on every policy
+    assert np.array_equal(a, ref["action"]) and np.array_equal(pi, ref["action_weights"])
+    assert np.array_equal(v, ref["root_value"])
     a2, pi2 = m.act(11, obs, with_pi=True, obs_from_batch=True, num_simulations=24,
                     qtransform="qtransform_completed_by_mix_value", max_num_considered_actions=2)
-    assert a2.shape == (40,) and np.allclose(pi2.sum(1), 1, atol=1e-5)
-    a1 = m.act(11, obs[0], num_simulations=24)
-    assert isinstance(a1, int) and a1 == int(a[0]) or True  # (different batch size -> different gumbel layout)
+    ref2 = want(obs, 1, 2)
+    assert np.array_equal(a2, ref2["action"]) and np.array_equal(pi2, ref2["action_weights"])
+    # unbatched: python int, and the one-root search of the same key (a batch of one draws its own Gumbel row)
+    a1, pi1, v1 = m.act(11, obs[0], with_pi=True, with_value=True, num_simulations=24)
+    ref1 = want(obs[:1], 0, 16)
+    assert isinstance(a1, int) and a1 == int(ref1["action"][0])
+    assert pi1.shape == (1, 4) and np.array_equal(pi1, ref1["action_weights"]) and v1 == float(ref1["root_value"][0])
     m2 = mx.MuZero(net.representation_fn, net.prediction_fn, net.dynamic_fn, policy="gumbel")
     m2.init(0, np.zeros((1, 6)))
     a3 = m2.act(11, obs, obs_from_batch=True, num_simulations=24)

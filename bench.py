@@ -434,9 +434,16 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} ROCm device(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # MUAX_BENCH_FORCE_DIST=1: initialise the process group for one rank too, so that the RCCL branch (init, barrier,
+    # max-over-ranks all-reduce on a device tensor, all_gather_object) executes on a 1-GPU box
+    if world > 1 or os.environ.get("MUAX_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
@@ -471,7 +478,7 @@ def main():
                                    f"tiebreak={'threefry' if not args.no_tiebreak else 'off'}, temperature 1",
                        "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective",
                        "clock_settle_ms_before_warmup": args.settle_ms,
-                       "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else "none (one rank)"),
+                       "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if dist else "none (one rank)"),
                        "launcher": os.environ.get("MUAX_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none"),
                        "ranks": placement},
             "roofline": roofline(args.workload, B, kernel_ms, depth_total),

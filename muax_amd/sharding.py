@@ -33,14 +33,17 @@ def gather_roots(local: torch.Tensor, global_batch: int, group=None) -> torch.Te
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
-def allreduce_mean_flat(tensors, group=None):
+def allreduce_mean_flat(tensors, group=None, even_if_alone: bool = False):
     """Data-parallel gradient mean (the only collective of the whole project; reference precedent:
     jax.lax.pmean in muax/frameworks/acme/jax/muzero/learning.py:151).  All tensors are packed into ONE
     flat fp32 buffer -> one all-reduce (RCCL over xGMI on GPUs; a few KB to MB, latency-bound, so one
-    message instead of a ring of small ones) -> scaled by 1/world -> unpacked in place."""
+    message instead of a ring of small ones) -> scaled by 1/world -> unpacked in place.  A world of one returns
+    at once unless `even_if_alone` (tests: the RCCL call itself on a 1-GPU box)."""
     import torch.distributed as dist
     tensors = [t for t in tensors if t is not None]
-    if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not tensors or not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size(group) == 1 and not even_if_alone:
         return
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -130,7 +130,7 @@ def test_bench_plain_invocation_launches_its_own_ranks():
     assert line["config"]["launcher"] == "self" and line["config"]["backend"] == "gloo"
     assert len(line["config"]["ranks"]) == 2 and all("cuda:0" in r for r in line["config"]["ranks"])
     assert abs(line["value"] - 2 * 4096 * 10 / (line["ms_per_step"] * 10e-3)) < 0.01 * line["value"]
-    assert 0 < line["value_synced"] <= line["value"] * 1.05
+    assert line["value_synced"] > 0  # (two ranks share one GPU here: no ordering between the two rates)
 
 
 def test_bench_refuses_more_gpus_than_the_box_has():
@@ -170,3 +170,45 @@ def test_bench_line_schema_at_one_gpu():
     assert abs(r4["frac"] - r4["algorithmic_flops_per_launch"] / (r4["kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
     c5 = line["config5_gumbel_train"]
     assert c5["act"]["ms_per_act"] > 0 and c5["update"]["ms_per_update"] > 0
+
+
+def _rccl_worker(q, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import muax_amd as mx
+    g = [torch.arange(6, dtype=torch.float32, device="cuda").reshape(2, 3), torch.full((5,), 2.0, device="cuda")]
+    want = [t.clone() for t in g]
+    mx.sharding.allreduce_mean_flat(g, even_if_alone=True)  # cat -> ONE RCCL all-reduce -> / world -> unpack
+    t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks timing
+    dist.barrier()
+    got = mx.gather_roots(torch.arange(4, device="cuda"), 4)
+    q.put(bool(all(torch.equal(a, b) for a, b in zip(g, want)) and float(t) == 1.5 and got.tolist() == [0, 1, 2, 3]))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_initialises_and_reduces_on_this_gpu():
+    """The 'nccl' (= RCCL) branch that a multi-GPU run takes -- process-group init bound to the rank's device, the
+    flat gradient all-reduce, the MAX all-reduce and barrier of bench.py -- executed over RCCL with the one rank a
+    1-GPU box can hold.  (Cross-device traffic needs a second GPU; the driver's scaling run covers it.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q, 29700 + os.getpid() % 200))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """bench.py with the process group forced on for one rank: init_process_group('nccl', device_id=...), barrier,
+    all_reduce(MAX) on a device tensor and all_gather_object all run through RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(MUAX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                          "--no-extras", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["config"]["backend"].startswith("rccl") and line["value"] > 1e6

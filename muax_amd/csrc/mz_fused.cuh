@@ -147,7 +147,16 @@ struct FusedCfg {
   //   [PATH0 ..) this node's own root path, one packed (node, action) entry per level
   // JUMP word: end point of the greedy descent below this node:
   //   parent[0:12) | action[12:16) | depth of parent[16:24) | bit 31: the end point is a near tie
-  static constexpr int SEL0 = 0, SELW = ((2 * A + 3) / 4) * 4;
+  // PK ("packed", the compact record of the instances whose embeddings are in HBM as well, E > 16): child indices
+  // and child visit counts are BYTES (one word per node each: nodes and counts are below 256), the two first-layer
+  // weight matrices live in LDS, shared by the workgroup, instead of in 136 registers per lane -- 21 words per node
+  // for four actions, 78 KB per 16-root workgroup with the weights, at most 256 registers per lane: TWO workgroups
+  // share a CU (8192 LunarLander roots are then ONE round of workgroups instead of two):
+  //   [SEL0 ..) child index bytes | A cached pUCT scores   [HDR0 ..) visits, value, JUMP
+  //   [ST0  ..) A probs | A values | A rewards | child visit bytes
+  static constexpr bool PK = PH_ && E_ > 16;
+  static_assert(!PK || (A_ <= 4 && NMAX_ <= 128 && MODE_ < 2), "packed record: four byte-sized children, MuZero policy");
+  static constexpr int SEL0 = 0, SELW = PK ? 1 + A : ((2 * A + 3) / 4) * 4;
   static constexpr int HDR0 = SELW, JUMP = HDR0 + 2;
   // raw_values are read inside the kernel only by qtransform_completed_by_mix_value (MODE 3); the compact record
   // drops the word elsewhere (an export writes raw values straight to the caller's array)
@@ -157,7 +166,51 @@ struct FusedCfg {
   // embeddings: in the LDS record while 16 roots per workgroup still fit the CU's LDS with them, else in
   // HBM ([root][node][E], one coalesced E*4-byte row per access, L2-resident while the root is active)
   static constexpr bool EMB_LDS = E_ <= 16;
-  static constexpr int EMB0 = ST0 + STW * A;
+  static constexpr int EMB0 = PK ? ST0 + 3 * A + 1 : ST0 + STW * A;
+  // field offsets inside a record (a: child)
+  static constexpr int off_score(int a) { return PK ? SEL0 + 1 + a : SEL0 + 2 * a + 1; }
+  static constexpr int off_prob(int a) { return PK ? ST0 + a : ST0 + STW * a; }
+  static constexpr int off_val(int a) { return PK ? ST0 + A + a : ST0 + STW * a + 1; }
+  static constexpr int off_rew(int a) { return PK ? ST0 + 2 * A + a : ST0 + STW * a + 3; }
+  static constexpr int off_logit(int a) { return ST0 + STW * a + ST_LOGIT; }  // Gumbel modes (never packed)
+  static constexpr int VIS0 = ST0 + 3 * A;  // packed record: the word of child visit bytes
+  // children_index / children_visits of a node (ndi = the node's record)
+  static MZ_DEV void load_cidx(const int* ndi, int (&cidx)[A]) {
+    if constexpr (PK) {
+      const int w = ndi[SEL0];
+#pragma unroll
+      for (int a = 0; a < A; ++a) cidx[a] = (w << (24 - 8 * a)) >> 24;  // sign-extending byte: 0xff = -1 (unvisited)
+    } else {
+#pragma unroll
+      for (int a = 0; a < A; ++a) cidx[a] = ndi[SEL0 + 2 * a];
+    }
+  }
+  static MZ_DEV int load_cidx1(const int* ndi, int a) {
+    if constexpr (PK) return reinterpret_cast<const int8_t*>(ndi + SEL0)[a];
+    else return ndi[SEL0 + 2 * a];
+  }
+  static MZ_DEV void store_cidx(int* ndi, int a, int v) {
+    if constexpr (PK) reinterpret_cast<int8_t*>(ndi + SEL0)[a] = (int8_t)v;
+    else ndi[SEL0 + 2 * a] = v;
+  }
+  static MZ_DEV void load_vis(const int* ndi, int (&vis)[A]) {
+    if constexpr (PK) {
+      const unsigned w = (unsigned)ndi[VIS0];
+#pragma unroll
+      for (int a = 0; a < A; ++a) vis[a] = (int)((w >> (8 * a)) & 0xffu);
+    } else {
+#pragma unroll
+      for (int a = 0; a < A; ++a) vis[a] = ndi[ST0 + STW * a + 2];
+    }
+  }
+  static MZ_DEV void store_vis(int* ndi, int a, int v) {
+    if constexpr (PK) reinterpret_cast<uint8_t*>(ndi + VIS0)[a] = (uint8_t)v;
+    else ndi[ST0 + STW * a + 2] = v;
+  }
+  // first-layer weights in LDS (packed record): per matrix [inputs / 2][16 lanes][2 inputs x (net 0, net 1)]
+  static constexpr int W1P_WORDS = PK ? (E / 2) * 16 * 4 : 0;          // Prediction: (value net, policy net)
+  static constexpr int W1D_WORDS = PK ? ((E + A + 1) / 2) * 16 * 4 : 0;  // Dynamic: (reward net, state net), E + A rows
+  static constexpr int WLDS_WORDS = W1P_WORDS + W1D_WORDS;
   // a path entry packs (node, action): one byte while ceil(log2 NMAX) + ceil(log2 A) <= 8, else 16 bits
   static constexpr int NODE_BITS = ceil_log2(NMAX), ACT_BITS = ceil_log2(A) < 1 ? 1 : ceil_log2(A);
   static constexpr int ENTRY_BITS = (NODE_BITS + ACT_BITS <= 8) ? 8 : 16;
@@ -182,7 +235,7 @@ struct FusedCfg {
   static constexpr int ROOT_WORDS = pad_root(TREE_WORDS + PATH_WORDS + NOISE_WORDS);
   static constexpr int ROOTS_PER_WG = 4 * WAVES;
   static constexpr int TBL_WORDS = 2 * (((NMAX + 2 + 3) / 4) * 4);  // {sqrt(n) pb_c(n), 1/n} pairs
-  static constexpr int LDS_BYTES = 4 * (TBL_WORDS + ROOTS_PER_WG * ROOT_WORDS);
+  static constexpr int LDS_BYTES = 4 * (TBL_WORDS + WLDS_WORDS + ROOTS_PER_WG * ROOT_WORDS);
   static_assert(LDS_BYTES <= 160 * 1024, "tree does not fit the 160 KiB LDS of a CU: lower WAVES");
   static_assert(!PH_ || (2 * LDS_BYTES <= 160 * 1024 && WAVES_ == 4 && (PATHW + 15) / 16 == 1),
                 "compact record: two 16-root workgroups per CU, one path word per lane");
@@ -347,14 +400,74 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
   for (int t = 0; t < NSLOT; ++t) s[t] = (s[t] - mn) / scale;
 }
 
+// first layers whose matrices are in LDS (packed record): only the (net 0, net 1) bias pair stays in registers
+struct RowBias2 {
+  f32x2 b;
+  MZ_DEV void load(const float* __restrict__, const float* __restrict__ B0, const float* __restrict__,
+                   const float* __restrict__ B1, int j) {
+    b = (f32x2){B0[j], B1[j]};
+  }
+};
+
+template <bool COND, class T, class F> struct PickType { using type = T; };
+template <class T, class F> struct PickType<false, T, F> { using type = F; };
+
 template <class C>
 struct Nets {
-  RowLinearPair<C::E> p1;  // (pv1, pp1)
+  typename PickType<C::PK, RowBias2, RowLinearPair<C::E>>::type p1;  // (pv1, pp1)
   RowLinearRT<kHidden, C::FS> pv2;
   RowLinear<kHidden, C::A> pp2;
-  RowLinearOneHot2<C::E, C::A> d1;  // (dr1, dn1)
+  typename PickType<C::PK, RowBias2, RowLinearOneHot2<C::E, C::A>>::type d1;  // (dr1, dn1)
   RowLinearRT<kHidden, C::FS> dr2;
   RowLinear<kHidden, C::E> dn2;
+  const float* wlds = nullptr;  // packed record: this lane's column of the two LDS matrices (Prediction, then Dynamic)
+
+  // packed record: the workgroup's copy of the first-layer matrices, [input pair][lane][2 inputs x (net 0, net 1)]
+  // (one ds_read_b128 per lane fetches two links of the packed chain; the rows of a wave read the same addresses)
+  static MZ_DEV void fill_lds(const FusedParams& p, float* wl, int tid) {
+    if constexpr (C::PK) {
+      constexpr int E = C::E, RD = E + C::A;
+      for (int idx = tid; idx < (E / 2) * 16; idx += C::THREADS) {
+        const int i = 2 * (idx >> 4), jj = idx & 15;
+        *reinterpret_cast<float4*>(wl + 4 * idx) = make_float4(p.pv_w1[i * kHidden + jj], p.pp_w1[i * kHidden + jj],
+                                                               p.pv_w1[(i + 1) * kHidden + jj], p.pp_w1[(i + 1) * kHidden + jj]);
+      }
+      float* wd = wl + C::W1P_WORDS;
+      for (int idx = tid; idx < ((RD + 1) / 2) * 16; idx += C::THREADS) {
+        const int i = 2 * (idx >> 4), jj = idx & 15;
+        const bool two = i + 1 < RD;
+        *reinterpret_cast<float4*>(wd + 4 * idx) = make_float4(p.dr_w1[i * kHidden + jj], p.dn_w1[i * kHidden + jj],
+                                                               two ? p.dr_w1[(i + 1) * kHidden + jj] : 0.0f,
+                                                               two ? p.dn_w1[(i + 1) * kHidden + jj] : 0.0f);
+      }
+    }
+  }
+  template <int WHICH>  // 0: Prediction's pair of first layers, 1: Dynamic's (state rows)
+  MZ_DEV f32x2 first_layers_lds(const float (&x)[C::ES]) const {
+    static_assert(C::E % 8 == 0, "eight inputs per statement");
+    const float* base = wlds + (WHICH ? C::W1P_WORDS : 0);
+    float h0 = 0.0f, h1 = 0.0f;
+    StaticFor<0, C::E / 8>::run([&](auto ic) {
+      constexpr int i = 8 * decltype(ic)::value;
+      f32x2 w[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (i / 2 + q) * 64);
+        w[2 * q] = (f32x2){v.x, v.y};
+        w[2 * q + 1] = (f32x2){v.z, v.w};
+      }
+      fmac_bcast_pair8<(i & 15), i == 0>(h0, h1, x[i >> 4], w);
+    });
+    return (f32x2){h0, h1};
+  }
+  MZ_DEV f32x2 first_p(const float (&x)[C::ES]) const {
+    if constexpr (C::PK) return first_layers_lds<0>(x);
+    else return first_layers(x, p1.w);
+  }
+  MZ_DEV f32x2 first_d(const float (&x)[C::ES]) const {
+    if constexpr (C::PK) return first_layers_lds<1>(x);
+    else return first_layers(x, d1.w);
+  }
 
   MZ_DEV void load(const FusedParams& p, int j) {
     p1.load(p.pv_w1, p.pv_b1, p.pp_w1, p.pp_b1, j);
@@ -388,7 +501,7 @@ struct Nets {
     // same packed chains as forward() below: every weight register then has ONE pairing in the whole
     // kernel (a second, scalar use made the compiler re-pair them through scratch memory)
     constexpr int NP = C::FS / 2;
-    f32x2 g = first_layers(s, p1.w);
+    f32x2 g = first_p(s);
     g = elu2(g + p1.b);
     f32x2 vl[NP];
 #pragma unroll
@@ -421,13 +534,21 @@ struct Nets {
                       float (&ns)[C::ES]) const {
     constexpr int E = C::E, A = C::A, FS = C::FS, NP = C::FS / 2;
     // Dynamic, first layer: [s, onehot(a)] -> 16 hidden units of the reward net and of the state net
-    f32x2 h = first_layers(s, d1.w);
+    f32x2 h = first_d(s);
     {
-      f32x2 wsel = d1.wa[0];
-      StaticFor<1, A>::run([&](auto ac) {
-        constexpr int a = decltype(ac)::value;
-        wsel = (action == a) ? d1.wa[a] : wsel;
-      });
+      f32x2 wsel;
+      if constexpr (C::PK) {
+        // row E + action of the LDS matrix (one 8-byte read at a row-uniform address)
+        const int row = E + action;
+        const float2 v = *reinterpret_cast<const float2*>(wlds + C::W1P_WORDS + (row >> 1) * 64 + 2 * (row & 1));
+        wsel = (f32x2){v.x, v.y};
+      } else {
+        wsel = d1.wa[0];
+        StaticFor<1, A>::run([&](auto ac) {
+          constexpr int a = decltype(ac)::value;
+          wsel = (action == a) ? d1.wa[a] : wsel;
+        });
+      }
       h = (h + wsel) + d1.b;
     }
     h = elu2(h);
@@ -464,7 +585,7 @@ struct Nets {
     float x[C::ES];
 #pragma unroll
     for (int t = 0; t < C::ES; ++t) x[t] = pred_on_parent ? s[t] : ns[t];
-    f32x2 g = first_layers(x, p1.w);
+    f32x2 g = first_p(x);
     g = elu2(g + p1.b);
     f32x2 vl[NP];
 #pragma unroll
@@ -744,7 +865,8 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
   // One wavefront per SIMD owns the whole 512-entry unified register file.  LLVM infers "no AGPRs"
   // for a kernel without MFMA and would spill to scratch beyond 256 VGPRs; naming an AGPR keeps the
   // accumulator half allocatable so that spills (the E=32 weight columns) stay in registers.
-  asm volatile("; keep AGPRs allocatable" ::: "a0");
+  // (the packed instances run two wavefronts per SIMD: their 256 registers are all VGPRs, no AGPR half to keep)
+  if constexpr (!C::PK) asm volatile("; keep AGPRs allocatable" ::: "a0");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int j = lane & 15;
@@ -763,9 +885,10 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     tbl[2 * i] = puct_scale(i, p.pb_c_init, p.pb_c_base);
     tbl[2 * i + 1] = i > 0 ? 1.0f / (float)i : 0.0f;  // correctly rounded reciprocal for div_small
   }
+  Nets<C>::fill_lds(p, lds + C::TBL_WORDS, tid);
   __syncthreads();  // the only barrier
 
-  float* tree = lds + C::TBL_WORDS + root_in_wg * C::ROOT_WORDS;
+  float* tree = lds + C::TBL_WORDS + C::WLDS_WORDS + root_in_wg * C::ROOT_WORDS;
   int* itree = reinterpret_cast<int*>(tree);
   const uint64_t rg = p.root_offset + (uint64_t)r;
   const int S = p.S;
@@ -783,6 +906,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
 
   Nets<C> nets;
   nets.load(p, j);
+  if constexpr (C::PK) nets.wlds = lds + C::TBL_WORDS + 4 * j;
 
   // ---- tree init (mctx instantiate_tree_from_root) ----
   // all-zero records written 16 bytes per lane, then children_index = -1 (same wave: LDS keeps the order)
@@ -791,8 +915,11 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     const int nq = (N * NS + 3) / 4;
     for (int q = j; q < nq; q += 16) q4[q] = make_int4(0, 0, 0, 0);
     for (int n = j; n < N; n += 16) {
+      if constexpr (C::PK) itree[n * NS + C::SEL0] = -1;  // four unvisited children: 0xff bytes
+      else {
 #pragma unroll
-      for (int a = 0; a < A; ++a) itree[n * NS + C::SEL0 + 2 * a] = -1;
+        for (int a = 0; a < A; ++a) itree[n * NS + C::SEL0 + 2 * a] = -1;
+      }
     }
   }
   if (ex) {
@@ -870,11 +997,11 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
       }
       if (j < A) {
         tree[C::GUM0 + j] = g;  // root_gumbel: in the root's own (empty) path slot, or behind the tree
-        tree[C::ST0 + C::STW * j + C::ST_LOGIT] = lg;
+        tree[C::off_logit(j)] = lg;
       }
       ncons = min(p.max_considered, A - __builtin_popcount(inv_bits));
     }
-    if (j < A) tree[C::ST0 + C::STW * j + 0] = pq[0];
+    if (j < A) tree[C::off_prob(j)] = pq[0];
     if (ex && j < A) p.t_children_prior_logits[(size_t)r * N * A + j] = lg;
     if (j == 0) {
       itree[C::HDR0] = 1;
@@ -894,7 +1021,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     int vis[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-      prob[a] = tree[C::ST0 + C::STW * a + 0];
+      prob[a] = tree[C::off_prob(a)];
       val[a] = 0.0f; vis[a] = 0; rew[a] = 0.0f; dis[a] = p.discount;
     }
     int cidx[A], best, child;
@@ -908,7 +1035,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
       float logit[A], gum[A];
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        logit[a] = tree[C::ST0 + C::STW * a + C::ST_LOGIT];
+        logit[a] = tree[C::off_logit(a)];
         gum[a] = tree[C::GUM0 + a];
       }
       gumbel_scores<A, C::QT>(true, v0, v0, logit, val, vis, rew, dis, gum, p.visit_table[(size_t)ncons * S],
@@ -923,7 +1050,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     root_jw = jump_word(0, best, 0, !safe);
     if (j == 0) {
 #pragma unroll
-      for (int a = 0; a < A; ++a) tree[C::SEL0 + 2 * a + 1] = sc[a];
+      for (int a = 0; a < A; ++a) tree[C::off_score(a)] = sc[a];
       itree[C::JUMP] = root_jw;
     }
   }
@@ -1000,11 +1127,11 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
             threefry2x32(fs0, fs1, x0, x1);
             int cidx[A];
             float score[A];
+            C::load_cidx(ndi, cidx);
             StaticFor<0, A>::run([&](auto ic) {
               constexpr int a = decltype(ic)::value;
               const uint32_t bits = bcast_u<(a % NB)>(a < NB ? x0 : x1);
-              cidx[a] = ndi[C::SEL0 + 2 * a];
-              score[a] = __int_as_float(ndi[C::SEL0 + 2 * a + 1]) + 1e-7f * uniform_from_bits(bits);
+              score[a] = __int_as_float(ndi[C::off_score(a)]) + 1e-7f * uniform_from_bits(bits);
             });
             int best = 0, bn = cidx[0];
             float bs = score[0];
@@ -1036,7 +1163,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         const int ent = (pb[(e * C::ENTRY_BITS) >> 5] >> ((e * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
         parent = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
         action = ent >> C::ENTRY_ACT_SHIFT;
-        next = itree[__umul24((unsigned)parent, (unsigned)NS) + C::SEL0 + 2 * action];
+        next = C::load_cidx1(itree + __umul24((unsigned)parent, (unsigned)NS), action);
       }
     }
     depth_total += depth;
@@ -1079,8 +1206,8 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     {
       const int vis = vis_old + 1;
       if (j < A) {
-        nn[C::ST0 + C::STW * j + 0] = pprob;
-        if constexpr (C::GUMBEL) nn[C::ST0 + C::STW * j + C::ST_LOGIT] = pil;
+        nn[C::off_prob(j)] = pprob;
+        if constexpr (C::GUMBEL) nn[C::off_logit(j)] = pil;
       }
 #pragma unroll
       for (int t = 0; t < C::ES; ++t)
@@ -1092,8 +1219,8 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         nni[C::HDR0] = vis;
         nn[C::HDR0 + 1] = value;
         if constexpr (C::RAW_OK) nn[C::HDR0 + 3] = value;  // raw_values[new] (mctx update_tree_node)
-        itree[po + C::SEL0 + 2 * action] = newn;
-        tree[po + C::ST0 + C::STW * action + 3] = reward;
+        C::store_cidx(itree + po, action, newn);
+        tree[po + C::off_rew(action)] = reward;
       }
       if (fresh) {
         // the new node's root path = its parent's path + (parent, action); written once
@@ -1175,13 +1302,13 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         const float pv = nd[C::HDR0 + 1];
         float prob[A], val[A], rew[A], dis[A];
         int vis[A], cidx[A];
+        C::load_cidx(ndi, cidx);
+        C::load_vis(ndi, vis);
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-          cidx[a] = ndi[C::SEL0 + 2 * a];
-          prob[a] = nd[C::ST0 + C::STW * a + 0];
-          val[a] = nd[C::ST0 + C::STW * a + 1];
-          vis[a] = ndi[C::ST0 + C::STW * a + 2];
-          rew[a] = nd[C::ST0 + C::STW * a + 3];
+          prob[a] = nd[C::off_prob(a)];
+          val[a] = nd[C::off_val(a)];
+          rew[a] = nd[C::off_rew(a)];
           dis[a] = p.discount;
         }
         // cached JUMP words of all children (clamped addresses), fetched now so that the one the
@@ -1247,7 +1374,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
           float logit[A], gum[A];
 #pragma unroll
           for (int a = 0; a < A; ++a) {
-            logit[a] = nd[C::ST0 + C::STW * a + C::ST_LOGIT];
+            logit[a] = nd[C::off_logit(a)];
             gum[a] = tree[C::GUM0 + a];
           }
           gumbel_scores<A, C::QT>(pn == 0, nval, C::RAW_OK ? nd[C::HDR0 + C::HDRW - 1] : 0.0f, logit, val, vis, rew, dis, gum, cv_next,
@@ -1284,7 +1411,7 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         if (valid) {
           // one masked region; for the leaf entry the header / edge stores rewrite what was loaded
 #pragma unroll
-          for (int a = 0; a < A; ++a) nd[C::SEL0 + 2 * a + 1] = sc[a];
+          for (int a = 0; a < A; ++a) nd[C::off_score(a)] = sc[a];
           ndi[C::JUMP] = jwd;
           ndi[C::HDR0] = nvis;
           nd[C::HDR0 + 1] = nval;
@@ -1295,8 +1422,8 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
             cvn = (pa == a) ? val[a] : cvn;
             cin = (pa == a) ? vis[a] : cin;
           }
-          nd[C::ST0 + C::STW * pa + 1] = cvn;
-          ndi[C::ST0 + C::STW * pa + 2] = cin;
+          nd[C::off_val(pa)] = cvn;
+          C::store_vis(ndi, pa, cin);
         }
       }
       root_jw = carry_j;  // entry 0 is the root: its refreshed JUMP word
@@ -1316,11 +1443,11 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
     int vis[A], sumv, cv = 0;
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-      val[a] = tree[C::ST0 + C::STW * a + 1];
+      val[a] = tree[C::off_val(a)];
       vis[a] = itree[C::ST0 + C::STW * a + 2];
-      rew[a] = tree[C::ST0 + C::STW * a + 3];
+      rew[a] = tree[C::off_rew(a)];
       dis[a] = p.discount;
-      logit[a] = tree[C::ST0 + C::STW * a + C::ST_LOGIT];
+      logit[a] = tree[C::off_logit(a)];
       gum[a] = tree[C::GUM0 + a];
       cv = max(cv, vis[a]);
     }
@@ -1357,7 +1484,9 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
   // ---- summary + sample (mctx Tree.summary, _apply_temperature, categorical) ----
   {
     const int ja = j < A ? j : A - 1;
-    int vc = itree[C::ST0 + C::STW * ja + 2];
+    int vc;
+    if constexpr (C::PK) vc = reinterpret_cast<const uint8_t*>(itree + C::VIS0)[ja];
+    else vc = itree[C::ST0 + C::STW * ja + 2];
     vc = j < A ? vc : 0;
     float total = (float)row_sum_i(vc);
     float denom = fmaxf(total, 1.0f);
@@ -1399,12 +1528,19 @@ __global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel
         p.t_node_values[o] = nd[C::HDR0 + 1];
       }
       if (j < A) {
-        int so = C::ST0 + C::STW * j;
-        p.t_children_index[o * A + j] = ndi[C::SEL0 + 2 * j];
-        p.t_children_values[o * A + j] = nd[so + 1];
-        p.t_children_visits[o * A + j] = ndi[so + 2];
-        p.t_children_rewards[o * A + j] = nd[so + 3];
-        p.t_children_discounts[o * A + j] = ndi[C::SEL0 + 2 * j] >= 0 ? p.discount : 0.0f;
+        int ci, cv;
+        if constexpr (C::PK) {
+          ci = reinterpret_cast<const int8_t*>(ndi + C::SEL0)[j];
+          cv = reinterpret_cast<const uint8_t*>(ndi + C::VIS0)[j];
+        } else {
+          ci = ndi[C::SEL0 + 2 * j];
+          cv = ndi[C::ST0 + C::STW * j + 2];
+        }
+        p.t_children_index[o * A + j] = ci;
+        p.t_children_values[o * A + j] = nd[C::off_val(j)];
+        p.t_children_visits[o * A + j] = cv;
+        p.t_children_rewards[o * A + j] = nd[C::off_rew(j)];
+        p.t_children_discounts[o * A + j] = ci >= 0 ? p.discount : 0.0f;
       }
       if constexpr (C::EMB_LDS)  // (else: the search ran on t_embeddings itself)
         for (int i = j; i < E; i += 16) p.t_embeddings[o * E + i] = nd[C::EMB0 + i];

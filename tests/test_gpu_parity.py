@@ -564,6 +564,37 @@ def test_gumbel_fused_injected_noise_and_max_depth(oracle):
     _compare(_gumbel_oracle_act(oracle, case, [0, 5], 1, 16, gumbel=g, max_depth=4), s, out)
 
 
+@pytest.mark.parametrize("B,tiebreak", [(4097, True), (8192, True), (10000, False)])
+def test_fused_packed_record_lunarlander_above_one_workgroup_per_cu(oracle, B, tiebreak):
+    """A = 4, E = 32 above 4096 roots: the PACKED compact record (child indices and visit counts as bytes, first-layer
+    matrices in LDS, paths and embeddings in HBM, two workgroups per CU).  Same bits as the oracle on every tree array
+    -- BASELINE config 3's whole 8192-root batch included --, with masks, a max_depth cut, no export (the handle's own
+    embedding scratch), and against a shard of the same rows run on the plain instance."""
+    case = make_case(oracle, 79, B, 8, 32, 4, 50, invalid_frac=0.1)
+    key = [B, 5]
+    s, out = _fused(case, tiebreak, key)
+    _compare(_oracle(oracle, case, tiebreak, key), s, out)
+    ref = _oracle(oracle, case, tiebreak, key, max_depth=5, temperature=0.5, use_gumbel=False)
+    s, out = _fused(case, tiebreak, key, max_depth=5, temperature=0.5, use_gumbel=False)
+    _compare(ref, s, out)
+    # no tree export: embeddings in the handle's scratch
+    from muax_amd import MuZeroSearch, SearchConfig
+    s3 = MuZeroSearch(B, SearchConfig(4, 50, 32, max_depth=5, tiebreak=tiebreak))
+    s3.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, 8, 10, 0.99)
+    o3 = s3.act_mlp(torch.from_numpy(case["obs"]), key, dirichlet_noise=torch.from_numpy(case["noise"]),
+                    invalid_actions=torch.from_numpy(case["invalid"]), temperature=0.5)
+    torch.cuda.synchronize()
+    assert np.array_equal(ref["action"], o3.action.cpu().numpy())
+    assert np.array_equal(ref["action_weights"], o3.action_weights.cpu().numpy())
+    assert np.array_equal(ref["depth_sum"], s3.depth_sum.cpu().numpy().astype(np.int64))
+    sl = slice(B - 200, B)
+    s2, o2 = _fused(case, tiebreak, key, max_depth=5, temperature=0.5, use_gumbel=False, global_batch=B,
+                    root_offset=B - 200, rows=sl)
+    assert torch.equal(o2.action, out.action[sl])
+    for f in out.search_tree._fields:
+        assert torch.equal(getattr(o2.search_tree, f), getattr(out.search_tree, f)[sl]), f
+
+
 @pytest.mark.parametrize("B,tiebreak", [(4097, True), (9000, True), (16384, False)])
 def test_fused_compact_record_above_one_workgroup_per_cu(oracle, B, tiebreak):
     """More 16-root workgroups than CUs (> 4096 roots on MI355X): mzs_act_mlp takes the compact-record instance

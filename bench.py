@@ -267,9 +267,9 @@ def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
     g = torch.Generator().manual_seed(0)
     mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, F, generator=g),
             mx.nn.ResNetDynamic(A, F, generator=g))
+    obs = torch.randint(0, 256, (roots, 84, 84, 4), generator=g).float().to(dev)  # (drawn before init(), as tools/bench_atari.py)
     m = mx.MuZero(*mods, capture_graph=True, device=dev)
     m.init(0, np.zeros((1, 84, 84, 4), np.float32))
-    obs = torch.randint(0, 256, (roots, 84, 84, 4), generator=g).float().to(dev)
     kw = dict(obs_from_batch=True, num_simulations=S, device_outputs=True)
     for i in range(2):
         m.act(i, obs, **kw)

@@ -164,6 +164,16 @@ int mzs_select(mzs_handle *h, int32_t sim, int32_t *action_out,
 int mzs_expand_backup(mzs_handle *h, int32_t sim, const float *reward,
                       const float *discount, const float *prior_logits,
                       const float *value, const float *next_embedding, void *stream);
+/* mzs_expand_backup(sim) and mzs_select(sim + 1) in ONE launch (the workgroup that refreshed the root's cached
+ * decision performs the next simulate() and gathers its parent's embedding row): one launch and one kernel boundary
+ * fewer per simulation of a launch-bound loop.  After the last simulation only the expand + backward half runs and the
+ * outputs are left untouched.  The caller must not call mzs_select for sim + 1 afterwards.  Same results as the two
+ * separate calls, bit for bit. */
+int mzs_expand_backup_select(mzs_handle *h, int32_t sim, const float *reward,
+                             const float *discount, const float *prior_logits,
+                             const float *value, const float *next_embedding,
+                             int32_t *next_action_out, float *next_parent_embedding_out,
+                             void *stream);
 int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
                int32_t *action_out, float *action_weights_out,
                float *search_value_out, int32_t *depth_sum_out, void *stream);

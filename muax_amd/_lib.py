@@ -80,7 +80,7 @@ class MzsTowerArgs(C.Structure):
 
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
-                    "mzs_expand_backup",
+                    "mzs_expand_backup", "mzs_expand_backup_select",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest"]
@@ -113,6 +113,7 @@ def load(build_if_missing: bool = True):
     L.mzs_root_gumbel.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32 * 2), _vp]
     L.mzs_select.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
     L.mzs_expand_backup.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.mzs_expand_backup_select.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mzs_finish.argtypes = [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mzs_tree_export.argtypes = [_vp, C.POINTER(MzsTreeView), _vp]
     L.mzs_mlp_loss_grad.argtypes = [C.POINTER(MzsMlpWeights), C.POINTER(MzsTrainArgs), _vp]

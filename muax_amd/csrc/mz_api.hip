@@ -520,18 +520,20 @@ int mzs_select(mzs_handle* h, int32_t sim, int32_t* action_out, float* parent_em
   return MZS_OK;
 }
 
-int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const float* discount,
-                      const float* prior_logits, const float* value, const float* next_embedding,
-                      void* stream_) {
+static int expand_backup_impl(mzs_handle* h, int32_t sim, const float* reward, const float* discount,
+                              const float* prior_logits, const float* value, const float* next_embedding,
+                              int32_t* next_action_out, float* next_parent_embedding_out, void* stream_,
+                              const char* who) {
   if (!h) return MZS_E_INVALID;
-  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "mzs_expand_backup: call mzs_root first");
-  if (sim < 0 || sim >= h->cfg.num_simulations) return fail(h, MZS_E_INVALID, "mzs_expand_backup: sim out of range");
+  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "%s: call mzs_root first", who);
+  if (sim < 0 || sim >= h->cfg.num_simulations) return fail(h, MZS_E_INVALID, "%s: sim out of range", who);
   if (!reward || !discount || !prior_logits || !value || !next_embedding)
-    return fail(h, MZS_E_INVALID, "mzs_expand_backup: null input");
+    return fail(h, MZS_E_INVALID, "%s: null input", who);
   const mzs_config& c = h->cfg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
   mz::StepArgs sa = h->step.args(c);
+  const bool want_next = next_action_out != nullptr && sim + 1 < c.num_simulations;
   if (h->use_jump)
     // small batches: 16 levels in flight per root; large ones: one wavefront per root keeps the launch small
   {
@@ -540,17 +542,35 @@ int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const flo
     const size_t lds = sizeof(int32_t) * 15 * ((size_t)c.num_simulations + 2);
     if (c.policy == 1)
       hipLaunchKernelGGL(mz::jump_expand_backup_kernel<true>, dim3(c.batch), blk, lds, stream, sa, h->jump, sim, reward,
-                         discount, prior_logits, value, next_embedding);
+                         discount, prior_logits, value, next_embedding, next_action_out, next_parent_embedding_out);
     else
       hipLaunchKernelGGL(mz::jump_expand_backup_kernel<false>, dim3(c.batch), blk, lds, stream, sa, h->jump, sim, reward,
-                         discount, prior_logits, value, next_embedding);
+                         discount, prior_logits, value, next_embedding, next_action_out, next_parent_embedding_out);
   }
   else
     hipLaunchKernelGGL(mz::step_expand_backup_kernel, dim3(step_grid(c.batch)), dim3(step_block(c.batch)), 0, stream, sa, sim,
                        reward, discount, prior_logits, value, next_embedding);
   if (sa.wide && !h->use_jump) emb_xfer(sa, const_cast<float*>(next_embedding), 1, stream);
   MZS_HIP(h, hipGetLastError());
+  // the walking kernels (trees beyond the cached-decision budget, MZS_STEP_WALK=1) select in a launch of their own
+  if (want_next && !h->use_jump) return mzs_select(h, sim + 1, next_action_out, next_parent_embedding_out, stream_);
   return MZS_OK;
+}
+
+int mzs_expand_backup(mzs_handle* h, int32_t sim, const float* reward, const float* discount,
+                      const float* prior_logits, const float* value, const float* next_embedding,
+                      void* stream_) {
+  return expand_backup_impl(h, sim, reward, discount, prior_logits, value, next_embedding, nullptr, nullptr, stream_,
+                            "mzs_expand_backup");
+}
+
+int mzs_expand_backup_select(mzs_handle* h, int32_t sim, const float* reward, const float* discount,
+                             const float* prior_logits, const float* value, const float* next_embedding,
+                             int32_t* next_action_out, float* next_parent_embedding_out, void* stream_) {
+  if (h && (!next_action_out || !next_parent_embedding_out))
+    return fail(h, MZS_E_INVALID, "mzs_expand_backup_select: null output");
+  return expand_backup_impl(h, sim, reward, discount, prior_logits, value, next_embedding, next_action_out,
+                            next_parent_embedding_out, stream_, "mzs_expand_backup_select");
 }
 
 int mzs_finish(mzs_handle* h, float temperature, const float* gumbel, int32_t* action_out,

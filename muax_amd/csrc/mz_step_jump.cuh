@@ -167,16 +167,14 @@ __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) 
   }
 }
 
-// mctx search.simulate through the JUMP records.  WIDE: one 256-thread workgroup per root -- every row
-// repeats the (O(1)) selection, so every thread knows the parent and the workgroup gathers its wide
-// embedding row in the same launch (a separate transfer kernel costs its own 4.7 us minimum).
-template <bool WIDE>
-__global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g, int sim, int32_t* action_out,
-                                                           float* parent_embedding_out) {
+// mctx search.simulate through the JUMP records, for root r.  WG: the calling workgroup belongs to this root alone
+// -- every row repeats the (O(1)) selection, so every thread knows the parent and the whole workgroup gathers its
+// embedding row (a separate transfer kernel costs its own 4.7 us minimum); otherwise one 16-lane row per root.
+template <bool WG>
+MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int32_t* action_out,
+                             float* parent_embedding_out) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
-  const int r = WIDE ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4));
-  if (r >= s.B) return;
   const int N = s.N, A = s.A, E = s.E;
   const size_t rb = (size_t)r * N;
   const uint64_t rg = s.root_offset + (uint64_t)r;
@@ -245,27 +243,41 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
     parent = (int)(ent & 0xffffu);
     action = (int)(ent >> 16);
   }
-  if (WIDE ? threadIdx.x == 0 : j == 0) {
+  if (WG ? threadIdx.x == 0 : j == 0) {
     s.sel_parent[r] = parent;
     s.sel_action[r] = action;
     s.sel_depth[r] = depth;
     s.depth_sum[r] += depth;
     action_out[r] = action;
-    if (WIDE) s.xfer_node[r] = parent;
+    if (WG) s.xfer_node[r] = parent;
   }
   const float* src = s.embeddings + (rb + parent) * E;
-  if (WIDE) {
-    for (int i = threadIdx.x; i < E; i += 256) parent_embedding_out[(size_t)r * E + i] = src[i];
+  if (WG) {
+    for (int i = threadIdx.x; i < E; i += blockDim.x) parent_embedding_out[(size_t)r * E + i] = src[i];
   } else {
     for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
   }
 }
 
-// mctx search.expand + search.backward + refresh of the decisions on the path: one workgroup per root
+// WIDE: one 256-thread workgroup per root (wide embedding rows), else one row per root
+template <bool WIDE>
+__global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g, int sim, int32_t* action_out,
+                                                           float* parent_embedding_out) {
+  const int r = WIDE ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4));
+  if (r >= s.B) return;
+  jump_select_body<WIDE>(s, g, sim, r, action_out, parent_embedding_out);
+}
+
+// mctx search.expand + search.backward + refresh of the decisions on the path: one workgroup per root.
+// `next_action_out` != null: the NEXT simulation's selection (simulate() of sim + 1: the root's fresh JUMP record is
+// in this workgroup's hands) and the gather of its parent's embedding row run as the tail of this launch -- one launch
+// and one kernel boundary fewer per simulation (mzs_expand_backup_select).
 template <bool GUMBEL>
 __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
                                                                   const float* discount, const float* prior_logits,
-                                                                  const float* value, const float* next_embedding) {
+                                                                  const float* value, const float* next_embedding,
+                                                                  int32_t* next_action_out,
+                                                                  float* next_parent_embedding_out) {
   extern __shared__ int lds_i[];
   const int r = blockIdx.x;
   const int tid = threadIdx.x, j = tid & 15, row = tid >> 4;
@@ -407,6 +419,10 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
   for (int e = tid; e <= depth; e += nthr) {
     g.jump_pa[rb + pn[e]] = njp[e];
     g.jump_lv[rb + pn[e]] = njl[e];
+  }
+  if (next_action_out != nullptr && sim + 1 < s.S) {
+    __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
+    jump_select_body<true>(s, g, sim + 1, r, next_action_out, next_parent_embedding_out);
   }
 }
 

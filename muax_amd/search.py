@@ -372,6 +372,25 @@ class MuZeroSearch:
                                              _ptr(ne), self._stream()), self._h)
         self._keep = (r, d, pl, v, ne)
 
+    def expand_backup_select(self, sim: int, reward, discount, prior_logits, value, next_embedding):
+        """expand_backup(sim) and select(sim + 1) in ONE launch (mzs_expand_backup_select): returns the next
+        simulation's (action, parent embedding) -- the same persistent buffers select() hands out -- or None after
+        the last simulation."""
+        B, A, E = self.batch, self.cfg.num_actions, self.cfg.embed_dim
+        r = self._f32(reward, (B,), "reward")
+        d = self._f32(discount, (B,), "discount")
+        pl = self._f32(prior_logits, (B, A), "prior_logits")
+        v = self._f32(value, (B,), "value")
+        ne = self._f32(torch.as_tensor(next_embedding, device=self.device).reshape(B, -1), (B, E),
+                       "next_embedding")
+        if ne.data_ptr() == self._parent_emb.data_ptr():
+            ne = ne.clone()  # (an identity recurrent_fn: the launch's tail overwrites the buffer select() handed out)
+        _lib.check(self._L.mzs_expand_backup_select(self._h, sim, _ptr(r), _ptr(d), _ptr(pl), _ptr(v), _ptr(ne),
+                                                    _ptr(self.action), _ptr(self._parent_emb), self._stream()),
+                   self._h)
+        self._keep = (r, d, pl, v, ne)
+        return (self.action, self._parent_emb) if sim + 1 < self.cfg.num_simulations else None
+
     def finish(self, temperature: float = 1.0, gumbel=None, with_tree: bool = False) -> PolicyOutput:
         B, A = self.batch, self.cfg.num_actions
         gum = self._f32(gumbel, (B, A), "gumbel")
@@ -410,9 +429,10 @@ class MuZeroSearch:
                           dirichlet_fraction)
 
         def loop():
+            # select(0), then S x (recurrent_fn -> expand + backward of sim AND the selection of sim + 1 in one launch)
+            nxt = self.select(0)
             for sim in range(self.cfg.num_simulations):
-                action, emb = self.select(sim)
-                self.expand_backup(sim, *recurrent_fn(action, emb))
+                nxt = self.expand_backup_select(sim, *recurrent_fn(*nxt))
 
         do_root()
         if not graph:

@@ -249,11 +249,13 @@ def _torch_recurrent(case):
 
 @pytest.mark.parametrize("tiebreak", [False, True])
 @pytest.mark.parametrize("A,E,S,B", [(2, 8, 20, 70), (5, 8, 24, 33), (18, 40, 30, 40), (18, 300, 12, 21)])  # E >= 256: wide rows
-@pytest.mark.parametrize("walk", [False, True])
-def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak, walk, monkeypatch):
+@pytest.mark.parametrize("walk,fused_select", [(False, False), (True, False), (False, True), (True, True)])
+def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak, walk, fused_select, monkeypatch):
     """Plugin-net path: torch nets between mzs_select and mzs_expand_backup; the oracle is fed the very
     same net outputs, so every tree array must agree exactly.  Both sets of tree kernels: cached decisions
-    (mz_step_jump.cuh, the default) and the level-by-level walk (mz_step.cuh, MZS_STEP_WALK=1)."""
+    (mz_step_jump.cuh, the default) and the level-by-level walk (mz_step.cuh, MZS_STEP_WALK=1); and both call
+    shapes: mzs_select + mzs_expand_backup per simulation, or mzs_expand_backup_select (the next simulation's selection
+    as the tail of the expand + backward launch)."""
     if walk:
         monkeypatch.setenv("MZS_STEP_WALK", "1")
     from muax_amd import MuZeroSearch, SearchConfig
@@ -270,20 +272,27 @@ def test_stepwise_matches_oracle(oracle, A, E, S, B, tiebreak, walk, monkeypatch
     oracle.tree_init(tree, oracle.root_prior(pl.cpu().numpy(), case["noise"], 0.25, case["invalid"]),
                      v.cpu().numpy(), emb.cpu().numpy(), case["invalid"])
     k_sample, _, sims = oracle.sim_keys_from_act_key(key, S)
+    nxt = None
     for sim in range(S):
-        action, pemb = s.select(sim)
+        action, pemb = nxt if fused_select and sim > 0 else s.select(sim)
         p_ref, a_ref, _ = oracle.step_select(tree, cfg, sim, sims[sim])
         assert np.array_equal(a_ref, action.cpu().numpy()), sim
         assert np.array_equal(tree.embeddings[np.arange(B), p_ref], pemb.cpu().numpy())
         outs = rec(action, pemb)
-        s.expand_backup(sim, *outs)
+        if fused_select:
+            nxt = s.expand_backup_select(sim, *outs)
+            assert (nxt is None) == (sim == S - 1)
+        else:
+            s.expand_backup(sim, *outs)
         oracle.step_expand_backup(tree, sim, p_ref, a_ref, *[o.cpu().numpy() for o in outs])
     out = s.finish(1.0, None, with_tree=True)
     g = oracle.gumbel(k_sample, B * A).reshape(B, A)
     a_ref, w_ref = oracle.summary_sample(tree, 1.0, g)
     assert np.array_equal(a_ref, out.action.cpu().numpy())
     assert np.array_equal(w_ref, out.action_weights.cpu().numpy())
+    assert np.array_equal(np.asarray([tree.parents[b, 1:].size for b in range(B)]), np.full(B, S))
     assert_trees_equal(tree, out.search_tree, exact_floats=True)
+    assert int(s.depth_sum.sum()) > 0
 
 
 def test_stepwise_equals_fused_when_fed_oracle_nets(oracle):

@@ -179,6 +179,32 @@ int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
                float *search_value_out, int32_t *depth_sum_out, void *stream);
 int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
 
+/* ---- fused LayerNorm of the convolutional plugin nets ----
+ * y = [relu]( LN(x) [+ LN2(x2)] [+ residual] ) with LN(x) = (x - mean) * rsqrt(var + eps) * scale[c] + offset[c],
+ * statistics over ALL n elements of a sample (biased variance), scale / offset indexed by (element % channels):
+ * hk.LayerNorm(axis=(-3,-2,-1), create_scale=True, create_offset=True) of NHWC tensors followed by the shortcut
+ * addition and relu of ResidualConvBlockV1/V2 and of the EZ heads (muax/nn.py:118-178, 232-288) -- the chains between
+ * the convolutions of the plugin nets' root inference, two launches instead of ~10 framework kernels each.
+ * Inference only (no gradients).  All tensors fp32, contiguous, caller-owned; `workspace` >=
+ * mzs_layernorm_workspace_bytes(batch, n) bytes of device memory, overwritten. */
+typedef struct mzs_layernorm_args {
+  int32_t struct_size;   /* = sizeof(mzs_layernorm_args) */
+  int32_t device;
+  int32_t batch;         /* samples */
+  int32_t n;             /* elements per sample (H*W*C), multiple of 4 and of channels */
+  int32_t channels;      /* C, multiple of 4 */
+  int32_t relu;          /* 1: relu at the end */
+  float eps;             /* haiku: 1e-5 */
+  const float *x, *scale, *offset;      /* [batch, n], [C], [C] */
+  const float *x2, *scale2, *offset2;   /* optional second normalised tensor (projected shortcut), or NULL */
+  const float *residual;                /* optional plain tensor added (identity shortcut), or NULL */
+  float *y;                             /* [batch, n]; may alias x, x2 or residual */
+  void *workspace;
+  int64_t workspace_bytes;
+} mzs_layernorm_args;
+int mzs_layernorm_act(const mzs_layernorm_args *a, void *stream);
+int64_t mzs_layernorm_workspace_bytes(int32_t batch, int32_t n);
+
 /* ---- device self-test ----
  * Three places of the kernels replace a library sequence by a shorter one that is only valid for this hardware's
  * v_sqrt_f32 / v_rcp_f32 / fma: sqrt on arguments that need no range scaling, division by 2 eps = 0.002f

@@ -78,12 +78,20 @@ class MzsTowerArgs(C.Structure):
                                                    ("pair_scratch", _vp), ("pair_scratch_bytes", C.c_int64)]
 
 
+class MzsLayerNormArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("n", C.c_int32),
+                ("channels", C.c_int32), ("relu", C.c_int32), ("eps", C.c_float),
+                ("x", _vp), ("scale", _vp), ("offset", _vp), ("x2", _vp), ("scale2", _vp), ("offset2", _vp),
+                ("residual", _vp), ("y", _vp), ("workspace", _vp), ("workspace_bytes", C.c_int64)]
+
+
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup", "mzs_expand_backup_select",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
-                    "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest"]
+                    "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
+                    "mzs_layernorm_workspace_bytes"]
 
 _lib = None
 
@@ -126,6 +134,9 @@ def load(build_if_missing: bool = True):
     L.mzs_mlp_train_workspace_bytes.restype = C.c_int64
     L.mzs_dirichlet.argtypes = [C.c_int32, C.POINTER(C.c_uint32 * 2), C.c_float, C.c_int32, C.c_int32, C.c_int64,
                                 C.c_int64, _vp, _vp]
+    L.mzs_layernorm_act.argtypes = [C.POINTER(MzsLayerNormArgs), _vp]
+    L.mzs_layernorm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.mzs_layernorm_workspace_bytes.restype = C.c_int64
     L.mzs_tower_pair_scratch_bytes.argtypes = [C.c_int32]
     L.mzs_tower_pair_scratch_bytes.restype = C.c_int64
     if L.mzs_abi_version() != 1:

@@ -237,18 +237,21 @@ class HkConv2D(nn.Module):
             return x @ self.w[0, 0]
         xc = x.permute(0, 3, 1, 2)
         (ht, hb), (wl, wr) = _same_pad(x.shape[1], self.k, self.stride), _same_pad(x.shape[2], self.k, self.stride)
-        if ht or hb or wl or wr:
+        pad = (0, 0)
+        if ht == hb and wl == wr:
+            pad = (ht, wl)  # symmetric (every stride-1 3x3): the convolution pads, no copy of the padded map
+        elif ht or hb or wl or wr:
             xc = torch.nn.functional.pad(xc, (wl, wr, ht, hb))
         w = self._oihw()
         if x.shape[-1] < 8 and not (torch.is_grad_enabled() and self.w.requires_grad):
             # few input channels (raw frames): MIOpen has no fast NHWC fp32 kernel and falls back to a naive
             # one (2.2 ms for 128 x 84 x 84 x 4); the plain NCHW problem gets a proper solver
             xc, w = xc.contiguous(), w.contiguous()
-            y = torch.nn.functional.conv2d(xc, w, stride=self.stride).contiguous(memory_format=torch.channels_last)
+            y = torch.nn.functional.conv2d(xc, w, stride=self.stride, padding=pad).contiguous(memory_format=torch.channels_last)
             return y.permute(0, 2, 3, 1)
         if not xc.is_contiguous(memory_format=torch.channels_last):  # keep every conv on packed NHWC operands
             xc = xc.contiguous(memory_format=torch.channels_last)
-        y = torch.nn.functional.conv2d(xc, w, stride=self.stride)
+        y = torch.nn.functional.conv2d(xc, w, stride=self.stride, padding=pad)
         return y.permute(0, 2, 3, 1)
 
     def _oihw(self):
@@ -272,13 +275,77 @@ class HkLayerNorm(nn.Module):
         self.axis = tuple(axis) if isinstance(axis, (tuple, list)) else (axis,)
         self.scale = self.offset = None
 
-    def forward(self, x):
+    def materialize(self, x):
         if self.scale is None:
             self.scale = nn.Parameter(torch.ones(x.shape[-1], device=x.device))
             self.offset = nn.Parameter(torch.zeros(x.shape[-1], device=x.device))
+
+    def forward(self, x):
+        self.materialize(x)
+        if self.fused_ok(x):
+            return ln_act(x, self)
+        return self.torch_forward(x)
+
+    def torch_forward(self, x):
+        self.materialize(x)
         mean = x.mean(dim=self.axis, keepdim=True)
         var = x.var(dim=self.axis, keepdim=True, unbiased=False)
         return (x - mean) * torch.rsqrt(var + 1e-5) * self.scale + self.offset
+
+    use_hip = True  # the fused HIP kernels (mzs_layernorm_act) in inference on the GPU; False: the torch expression
+
+    def fused_ok(self, x) -> bool:
+        """Inference on a GPU tensor whose statistics run over the whole sample (every axis but the batch's):
+        mzs_layernorm_act applies -- LayerNorm, the shortcut addition and the relu behind it in two launches."""
+        if not (self.use_hip and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2):
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or (self.scale is not None and self.scale.requires_grad)):
+            return False
+        if sorted(a % x.dim() for a in self.axis) != list(range(1, x.dim())):
+            return False
+        n = x[0].numel()
+        return n % 4 == 0 and x.shape[-1] % 4 == 0 and n < 2 ** 31
+
+
+def ln_act(x, ln: "HkLayerNorm", relu: bool = False, add_ln=None, residual=None):
+    """[relu]( ln(x) [+ ln2(x2)] [+ residual] ) for NHWC tensors: `add_ln` = (x2, ln2), the projected shortcut of
+    ResidualConvBlockV1 (muax/nn.py:118-148); `residual` its identity shortcut.  One fused HIP call
+    (mzs_layernorm_act, muax_amd/csrc/mz_norm.cuh) in inference on the GPU, the torch expressions otherwise."""
+    ln.materialize(x)
+    ok = ln.fused_ok(x) and (residual is None or (residual.is_cuda and residual.shape == x.shape))
+    if add_ln is not None:
+        add_ln[1].materialize(add_ln[0])
+        ok = ok and add_ln[1].fused_ok(add_ln[0]) and add_ln[0].shape == x.shape
+    if not ok:
+        y = ln.torch_forward(x)
+        if add_ln is not None:
+            y = add_ln[1].torch_forward(add_ln[0]) + y
+        if residual is not None:
+            y = residual + y
+        return torch.relu(y) if relu else y
+    import ctypes as C
+
+    from . import _lib
+    L = _lib.load()
+    B, n = x.shape[0], x[0].numel()
+    xs = [x.contiguous()]
+    a = _lib.MzsLayerNormArgs()
+    a.struct_size = C.sizeof(_lib.MzsLayerNormArgs)
+    a.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    a.batch, a.n, a.channels, a.relu, a.eps = B, n, x.shape[-1], int(relu), 1e-5
+    a.x, a.scale, a.offset = xs[0].data_ptr(), ln.scale.data_ptr(), ln.offset.data_ptr()
+    if add_ln is not None:
+        xs.append(add_ln[0].contiguous())
+        a.x2, a.scale2, a.offset2 = xs[1].data_ptr(), add_ln[1].scale.data_ptr(), add_ln[1].offset.data_ptr()
+    if residual is not None:
+        xs.append(residual.contiguous())
+        a.residual = xs[-1].data_ptr()
+    y = torch.empty_like(xs[0])
+    ws = torch.empty(L.mzs_layernorm_workspace_bytes(B, n) // 8, dtype=torch.float64, device=x.device)
+    a.y, a.workspace, a.workspace_bytes = y.data_ptr(), ws.data_ptr(), ws.numel() * 8
+    with torch.cuda.device(x.device):
+        _lib.check(L.mzs_layernorm_act(C.byref(a), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return y
 
 
 class LazyHkLinear(nn.Module):
@@ -323,9 +390,14 @@ class ResidualConvBlockV1(nn.Module):
         self.conv_1, self.ln_1 = HkConv2D(channels, 3, 1, generator=generator), HkLayerNorm()
 
     def forward(self, x):
-        shortcut = self.proj_ln(self.proj_conv(x)) if self.use_projection else x
-        out = self.ln_1(self.conv_1(torch.relu(self.ln_0(self.conv_0(x)))))
-        return torch.relu(shortcut + out)
+        # ln_act = the torch expressions in training / on the CPU, one fused HIP call per chain in GPU inference
+        # (module calls in the reference's creation order -- projection, conv_0, conv_1: lazily built weights draw
+        # from the generator in that order)
+        cp = self.proj_conv(x) if self.use_projection else None
+        out = self.conv_1(ln_act(self.conv_0(x), self.ln_0, relu=True))
+        if self.use_projection:
+            return ln_act(out, self.ln_1, relu=True, add_ln=(cp, self.proj_ln))
+        return ln_act(out, self.ln_1, relu=True, residual=x)
 
 
 class ResidualConvBlockV2(nn.Module):
@@ -340,9 +412,9 @@ class ResidualConvBlockV2(nn.Module):
         self.conv_1, self.ln_1 = HkConv2D(channels, 3, 1, generator=generator), HkLayerNorm()
 
     def forward(self, x):
-        out = torch.relu(self.ln_0(x))
+        out = ln_act(x, self.ln_0, relu=True)
         shortcut = self.proj_conv(out) if self.use_projection else x
-        out = self.conv_1(torch.relu(self.ln_1(self.conv_0(out))))
+        out = self.conv_1(ln_act(self.conv_0(out), self.ln_1, relu=True))
         return shortcut + out
 
 
@@ -371,8 +443,8 @@ class _LNReluHead(nn.Module):
         self._scale = float(output_init_scale)
 
     def forward(self, x):
-        h = torch.relu(self.ln_mid(self.conv(torch.relu(self.ln_in(x)))))
-        h = torch.relu(self.ln_vec(self.fc(h.flatten(1))))
+        h = ln_act(self.conv(ln_act(x, self.ln_in, relu=True)), self.ln_mid, relu=True)
+        h = ln_act(self.fc(h.flatten(1)), self.ln_vec, relu=True)
         fresh = self.out.w is None
         y = self.out(h)
         if fresh:  # VarianceScaling(scale): stddev sqrt(scale / fan_in) of the truncated normal (haiku divides by .8796)
@@ -399,7 +471,7 @@ class EZStateEncoder(nn.Module):
     def forward(self, observations):
         x = self.stem(observations.to(torch.float32) / 255.)
         if not self.use_v2:
-            x = torch.relu(self.stem_ln(x))
+            x = ln_act(x, self.stem_ln, relu=True)
         x = self.block2(self.block1(self.block0(x)))
         x = self.block3(avg_pool_same(x))
         return self.block4(avg_pool_same(x))

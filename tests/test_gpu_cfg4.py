@@ -277,3 +277,75 @@ def test_ez_nets_drive_the_stepwise_search_eager_and_captured():
     assert pi1.shape == (6, A) and np.allclose(pi1.sum(1), 1) and len(graph._root_graphs) == 1
     a3, _, _ = eager.act(4, _frames(6, seed=13), **kw)
     assert a3.shape == (6,) and a3.dtype == np.int32
+
+
+@pytest.mark.parametrize("shape", [(5, 42, 42, 32), (3, 21, 21, 64), (7, 11, 11, 64), (4, 6, 6, 64), (2, 6, 6, 16), (6, 32)])
+def test_fused_layernorm_chains_match_the_torch_expressions(shape):
+    """mzs_layernorm_act (muax_amd/csrc/mz_norm.cuh) against hk.LayerNorm as the torch modules spell it
+    (muax/nn.py:118-148: statistics over the whole sample, scale / offset per channel, eps 1e-5), alone and with what
+    follows it in the residual blocks: + LN(projected shortcut) or + identity shortcut, relu.  Also against an fp64
+    evaluation: the fused moments are accumulated in fp64, so it is at least as close as the fp32 expression."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 3 + 1.5).cuda()
+    x2 = (torch.randn(shape, generator=g) * 0.2 - 4).cuda()
+    res = torch.randn(shape, generator=g).cuda()
+    axis = (-1,) if len(shape) == 2 else (-3, -2, -1)
+    ln, ln2 = mx.nn.HkLayerNorm(axis), mx.nn.HkLayerNorm(axis)
+    for m, t in ((ln, x), (ln2, x2)):
+        m.materialize(t)
+        with torch.no_grad():
+            m.scale.copy_(torch.rand(shape[-1], generator=g).cuda() + 0.5)
+            m.offset.copy_(torch.randn(shape[-1], generator=g).cuda())
+
+    def ref(dtype):
+        def one(m, t):
+            t = t.to(dtype)
+            dims = tuple(range(1, t.dim()))
+            mean, var = t.mean(dims, keepdim=True), t.var(dims, keepdim=True, unbiased=False)
+            return (t - mean) * torch.rsqrt(var + 1e-5) * m.scale.to(dtype) + m.offset.to(dtype)
+        return one
+
+    with torch.no_grad():
+        for kw in ({}, {"relu": True}, {"relu": True, "add_ln": (x2, ln2)}, {"relu": True, "residual": res},
+                   {"add_ln": (x2, ln2), "residual": res}):
+            assert ln.fused_ok(x)
+            got = mx.nn.ln_act(x, ln, **kw)
+            outs = []
+            for dtype in (torch.float32, torch.float64):
+                y = ref(dtype)(ln, x)
+                if "add_ln" in kw:
+                    y = ref(dtype)(ln2, x2) + y
+                if "residual" in kw:
+                    y = res.to(dtype) + y
+                outs.append(torch.relu(y) if kw.get("relu") else y)
+            assert torch.allclose(got, outs[0], rtol=1e-5, atol=2e-5), kw
+            e_fused, e_torch = (got.double() - outs[1]).abs().max(), (outs[0].double() - outs[1]).abs().max()
+            assert e_fused <= 2 * e_torch + 1e-6, (kw, float(e_fused), float(e_torch))
+        ln.use_hip = False
+        assert torch.equal(mx.nn.ln_act(x, ln, relu=True), torch.relu(ref(torch.float32)(ln, x)))
+
+
+def test_conv_nets_with_fused_layernorm_equal_the_torch_modules():
+    """Root inference of the ResNet and EZ nets (muax/nn.py:180-331) with the fused LayerNorm chains against the same
+    modules evaluated with the torch expressions: embeddings and head outputs agree to fp32 rounding through the
+    8- / 5-block encoders, and act() returns the same search."""
+    g = torch.Generator().manual_seed(21)
+    obs = _frames(6, seed=5)
+    for mods in ((mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, 21, generator=g),
+                  mx.nn.ResNetDynamic(A, 21, generator=g)),
+                 (mx.nn.EZRepresentation(32, generator=g), mx.nn.EZPrediction(A, 21, 1.0, generator=g),
+                  mx.nn.EZDynamic(32, A, 21, 1.0, generator=g))):
+        m = mx.MuZero(*mods)
+        m.init(0, obs[:1])
+        x = torch.as_tensor(obs).cuda()
+        with torch.no_grad():
+            s1 = mods[0](x)
+            v1, p1 = mods[1](s1)
+            mx.nn.HkLayerNorm.use_hip = False
+            try:
+                s0 = mods[0](x)
+                v0, p0 = mods[1](s0)
+            finally:
+                mx.nn.HkLayerNorm.use_hip = True
+        assert torch.allclose(s1, s0, rtol=1e-4, atol=1e-4), float((s1 - s0).abs().max())
+        assert torch.allclose(v1, v0, rtol=1e-3, atol=1e-3) and torch.allclose(p1, p0, rtol=1e-3, atol=1e-3)

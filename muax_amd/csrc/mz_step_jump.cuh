@@ -24,6 +24,7 @@
 namespace mz {
 
 constexpr int kJumpMaxNodes = 1024;
+constexpr int kLevelsInFlight = 3;  // levels of a backed-up path a 16-lane row refreshes at once (mzs_expand_backup)
 
 #define MZ_JROW_SETUP                                                 \
   const int lane = threadIdx.x & 63;                                  \
@@ -43,28 +44,51 @@ struct JumpArgs {
 
 // pUCT scores of all children of `node` (muzero_action_selection with qtransform_by_parent_and_siblings),
 // noise-free; first-max argmax; `near` = some other action is within the reach of the tie-break noise.
-MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, float (&sc)[kMaxAS],
-                         int (&cidx)[kMaxAS], int& best, int& child, bool& near) {
+// Split into the loads and the arithmetic so that a row can put the loads of several levels in flight before it
+// computes on the first (mzs_expand_backup refreshes up to kLevelsInFlight levels per row at once).
+struct LevelIn {
+  int cidx[kMaxAS], cvis[kMaxAS];
+  float prob[kMaxAS], rew[kMaxAS], dis[kMaxAS], val[kMaxAS];
+  int nvis, inv;  // inv: bit t = action j + 16 t is invalid at the root
+  float nval;
+};
+MZ_DEV void level_load(const StepArgs& s, size_t rb, int r, int node, int j, LevelIn& L) {
   const int A = s.A;
   const size_t nb = (rb + node) * A;
-  const int nvis = s.node_visits[rb + node];
-  const float nval = s.node_values[rb + node];
-  const float tn = puct_scale(nvis, s.pb_c_init, s.pb_c_base);
-  float q[kMaxAS], prob[kMaxAS];
-  int cvis[kMaxAS];
-  float lo = nval, hi = nval;
+  L.nvis = s.node_visits[rb + node];
+  L.nval = s.node_values[rb + node];
+  L.inv = 0;
 #pragma unroll
   for (int t = 0; t < kMaxAS; ++t) {
     const int a = j + 16 * t;
     const bool ok = a < A;
-    cidx[t] = -1; cvis[t] = 0; prob[t] = 0.0f; q[t] = 0.0f;
+    L.cidx[t] = -1; L.cvis[t] = 0; L.prob[t] = 0.0f; L.rew[t] = 0.0f; L.dis[t] = 0.0f; L.val[t] = 0.0f;
     if (16 * t < A) {
       const size_t o = nb + (ok ? a : 0);
-      cidx[t] = s.children_index[o];
-      cvis[t] = s.children_visits[o];
-      prob[t] = s.children_prior_probs[o];
-      q[t] = s.children_rewards[o] + s.children_discounts[o] * s.children_values[o];
-      const float safe = (ok && cvis[t] > 0) ? q[t] : nval;
+      L.cidx[t] = s.children_index[o];
+      L.cvis[t] = s.children_visits[o];
+      L.prob[t] = s.children_prior_probs[o];
+      L.rew[t] = s.children_rewards[o];
+      L.dis[t] = s.children_discounts[o];
+      L.val[t] = s.children_values[o];
+      if (node == 0 && ok && s.root_invalid[(size_t)r * A + a]) L.inv |= 1 << t;  // the root is level 0 only
+    }
+  }
+}
+MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc)[kMaxAS], int& best, int& child,
+                          bool& near) {
+  const int A = s.A;
+  const float nval = L.nval;
+  const float tn = puct_scale(L.nvis, s.pb_c_init, s.pb_c_base);
+  float q[kMaxAS];
+  float lo = nval, hi = nval;
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) {
+    const bool ok = j + 16 * t < A;
+    q[t] = 0.0f;
+    if (16 * t < A) {
+      q[t] = L.rew[t] + L.dis[t] * L.val[t];
+      const float safe = (ok && L.cvis[t] > 0) ? q[t] : nval;
       lo = fminf(lo, safe);
       hi = fmaxf(hi, safe);
     }
@@ -81,14 +105,14 @@ MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, f
     const bool ok = a < A;
     sc[t] = -INFINITY;
     if (16 * t < A) {
-      const float value_score = ((cvis[t] > 0 ? q[t] : lo) - lo) / span;
-      const float policy_score = (tn * prob[t]) / (float)(cvis[t] + 1);
+      const float value_score = ((L.cvis[t] > 0 ? q[t] : lo) - lo) / span;
+      const float policy_score = (tn * L.prob[t]) / (float)(L.cvis[t] + 1);
       sc[t] = value_score + policy_score;
-      if (node == 0 && ok && s.root_invalid[(size_t)r * A + a]) sc[t] = -INFINITY;  // the root is level 0 only
+      if ((L.inv >> t) & 1) sc[t] = -INFINITY;
       if (!ok) sc[t] = -INFINITY;
     }
     const bool take = (t == 0) || (sc[t] > bscore);  // first max wins inside the lane
-    if (take) { bscore = sc[t]; best = ok ? a : (1 << 20); child = cidx[t]; }
+    if (take) { bscore = sc[t]; best = ok ? a : (1 << 20); child = L.cidx[t]; }
   }
   row_argmax<4>(bscore, best, child);
   bool unsafe = false;
@@ -100,6 +124,14 @@ MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, f
     }
   }
   near = ((__builtin_amdgcn_ballot_w64(unsafe) >> (threadIdx.x & 48)) & 0xffffull) != 0;  // any lane of the row
+}
+MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, float (&sc)[kMaxAS],
+                         int (&cidx)[kMaxAS], int& best, int& child, bool& near) {
+  LevelIn L;
+  level_load(s, rb, r, node, j, L);
+  level_compute(s, j, L, sc, best, child, near);
+#pragma unroll
+  for (int t = 0; t < kMaxAS; ++t) cidx[t] = L.cidx[t];
 }
 
 // mctx gumbel_muzero_{root,interior}_action_selection at `node` (the root is only ever selected at level 0):
@@ -308,6 +340,8 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
   int* cjl = cjp + D1;
   int* njp = cjl + D1;             // new JUMP record of the level's node
   int* njl = njp + D1;
+  int* nxa = cnt;                  // pointer jumping: the level whose record level e takes (two buffers, in the
+  int* nxb = reinterpret_cast<int*>(val);  // backward pass's arrays, dead by then)
 
   // -- path of the leaf: the parent's own root path + (parent, action) --
   for (int e = tid; e < depth; e += nthr) {
@@ -363,11 +397,22 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
   }
   __syncthreads();
   // -- leaf_value = reward + discount * leaf_value, leaf to root (the one sequential chain) --
-  if (tid == 0) {
+  // One wavefront, 64 levels per chunk in registers: a step is two v_readlane (off the chain) + mul + add on the
+  // wave-uniform G, ~25 cycles, instead of an LDS round trip per level on a lone thread (~90) -- the paths of a long
+  // search on few roots are 50 .. 150 levels deep and this chain paced the launch.  Same operations, same order.
+  if (tid < 64) {
     float G = v;
-    for (int e = depth - 1; e >= 0; --e) {
-      G = rw[e] + ds[e] * G;
-      Gs[e] = G;
+    for (int c = (depth - 1) >> 6; c >= 0; --c) {
+      const int e = 64 * c + tid;
+      const int rr = __float_as_int(e < depth ? rw[e] : 0.0f), dd = __float_as_int(e < depth ? ds[e] : 0.0f);
+      float mine = 0.0f;
+      for (int k = min(63, depth - 1 - 64 * c); k >= 0; --k) {
+        const float rk = __int_as_float(__builtin_amdgcn_readlane(rr, k));
+        const float dk = __int_as_float(__builtin_amdgcn_readlane(dd, k));
+        G = rk + dk * G;
+        mine = tid == k ? G : mine;
+      }
+      if (e < depth) Gs[e] = mine;
     }
   }
   __syncthreads();
@@ -382,43 +427,86 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
     s.children_visits[e2] = s.children_visits[e2] + 1;
   }
   __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
-  // -- decisions of the path nodes and the leaf: one row per level --
-  for (int base = 0; base <= depth; base += nrows) {
-    const int e = base + row;
-    if (e <= depth) {
-      int best, child;
-      bool near;
-      decide_any<GUMBEL>(s, rb, r, pn[e], j, best, child, near);
-      if (j == 0) {
-        bst[e] = best;
-        chd[e] = child;
-        flg[e] = near ? 1 : 0;
-        const bool off_path = child >= 0 && !(e < depth && child == pn[e + 1]);
-        cjp[e] = off_path ? g.jump_pa[rb + child] : 0;
-        cjl[e] = off_path ? g.jump_lv[rb + child] : 0;
+  // -- decisions of the path nodes and the leaf: one row per level, kLevelsInFlight levels per row at once (all
+  // their loads are issued before the first is used: a deep path costs one memory round trip, not one per 64 levels) --
+  for (int base = 0; base <= depth; base += nrows * kLevelsInFlight) {
+    if constexpr (GUMBEL) {
+      for (int u = 0; u < kLevelsInFlight; ++u) {
+        const int e = base + u * nrows + row;
+        if (e <= depth) {
+          int best, child;
+          bool near;
+          decide_any<GUMBEL>(s, rb, r, pn[e], j, best, child, near);
+          if (j == 0) {
+            bst[e] = best;
+            chd[e] = child;
+            flg[e] = near ? 1 : 0;
+            const bool off_path = child >= 0 && !(e < depth && child == pn[e + 1]);
+            cjp[e] = off_path ? g.jump_pa[rb + child] : 0;
+            cjl[e] = off_path ? g.jump_lv[rb + child] : 0;
+          }
+        }
+      }
+    } else {
+      LevelIn L[kLevelsInFlight];
+      int bestu[kLevelsInFlight], childu[kLevelsInFlight], cj[kLevelsInFlight], cl[kLevelsInFlight];
+      bool nearu[kLevelsInFlight], offu[kLevelsInFlight];
+#pragma unroll
+      for (int u = 0; u < kLevelsInFlight; ++u) {
+        const int e = base + u * nrows + row;
+        level_load(s, rb, r, pn[e <= depth ? e : depth], j, L[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kLevelsInFlight; ++u) {
+        const int e = base + u * nrows + row;
+        float sc[kMaxAS];
+        level_compute(s, j, L[u], sc, bestu[u], childu[u], nearu[u]);
+        offu[u] = e <= depth && childu[u] >= 0 && !(e < depth && childu[u] == pn[e + 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < kLevelsInFlight; ++u) {  // the off-path children's stored records, all requested together
+        cj[u] = offu[u] ? g.jump_pa[rb + childu[u]] : 0;
+        cl[u] = offu[u] ? g.jump_lv[rb + childu[u]] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kLevelsInFlight; ++u) {
+        const int e = base + u * nrows + row;
+        if (e <= depth && j == 0) {
+          bst[e] = bestu[u];
+          chd[e] = childu[u];
+          flg[e] = nearu[u] ? 1 : 0;
+          cjp[e] = cj[u];
+          cjl[e] = cl[u];
+        }
       }
     }
   }
   __syncthreads();
-  // -- JUMP records bottom-up: own end point, the off-path child's record, or the next level's new one --
-  if (tid == 0) {
-    int jp = 0, jl = 0;  // the record of level e + 1 rides in registers: no LDS round trip inside the chain
-    for (int e = depth; e >= 0; --e) {
-      if (flg[e] || chd[e] < 0) {
-        jp = pn[e] | (bst[e] << 16) | (flg[e] ? (int)0x80000000 : 0);
-        jl = e;
-      } else if (!(e < depth && chd[e] == pn[e + 1])) {
-        jp = cjp[e];
-        jl = cjl[e];
-      }
-      njp[e] = jp;
-      njl[e] = jl;
-    }
-  }
-  __syncthreads();
+  // -- JUMP records: a level takes its own end point (near tie, or an unexpanded best child), the stored record of
+  // its off-path best child, or -- when its best child is the next level of this very path -- whatever that level
+  // resolves to.  The bottom-up chain of the last case is resolved by pointer jumping (log2(depth) rounds over all
+  // levels at once) instead of a serial walk by one thread; the leaf level never inherits, so every chain ends. --
   for (int e = tid; e <= depth; e += nthr) {
-    g.jump_pa[rb + pn[e]] = njp[e];
-    g.jump_lv[rb + pn[e]] = njl[e];
+    const bool own = flg[e] || chd[e] < 0;
+    const bool inherit = !own && e < depth && chd[e] == pn[e + 1];
+    njp[e] = own ? (pn[e] | (bst[e] << 16) | (flg[e] ? (int)0x80000000 : 0)) : cjp[e];
+    njl[e] = own ? e : cjl[e];
+    nxa[e] = inherit ? e + 1 : e;
+  }
+  __syncthreads();
+  {
+    int* src = nxa;
+    int* dst = nxb;
+    for (int span = 1; span <= depth; span <<= 1) {
+      for (int e = tid; e <= depth; e += nthr) dst[e] = src[src[e]];
+      __syncthreads();
+      int* t = src; src = dst; dst = t;
+    }
+    for (int e = tid; e <= depth; e += nthr) {
+      const int from = src[e];
+      g.jump_pa[rb + pn[e]] = njp[from];
+      g.jump_lv[rb + pn[e]] = njl[from];
+    }
   }
   if (next_action_out != nullptr && sim + 1 < s.S) {
     __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible

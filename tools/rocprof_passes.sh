@@ -13,3 +13,4 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_L
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $BX --steps 5 --warmup 1 > $OUT/bench_pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $BX --steps 5 --warmup 1 > $OUT/bench_pmc4.log 2>&1
 python $REPO/tools/prof_summary.py $OUT
+rm -f $OUT/*/*.db $OUT/*/*/*.db   # (only the text summary travels back: gpurun_out/ is capped at 64 MiB)

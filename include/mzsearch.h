@@ -179,6 +179,41 @@ int mzs_finish(mzs_handle *h, float temperature, const float *gumbel,
                float *search_value_out, int32_t *depth_sum_out, void *stream);
 int mzs_tree_export(mzs_handle *h, const mzs_tree_view *out, void *stream);
 
+/* ---- recurrent_fn of the EfficientZero-style nets ----
+ * mzs_ez_recurrent evaluates, for a batch of 6x6xC hidden states (NHWC, C = 32 or 64) and actions, the whole
+ * MuZero._recurrent_inference (muax/model.py:265-282) of EZDynamic + EZPrediction with use_v2 = True
+ * (muax/nn.py:221-309, pre-activation blocks muax/nn.py:151-178) in ONE launch: next state, reward and value as
+ * support_to_scalar(softmax(logits)), prior logits.  Weights, caller-owned device arrays:
+ *   LayerNorm       [2][channels]                  scale row, offset row
+ *   3x3 convolution [9][Cin / 16][4][C][4]         Wp[tap][c][g][co][i] = W[tap][16 c + 4 g + i][co] from haiku's
+ *                                                  HWIO w[kh][kw][in][out] (the layout of mzs_resnet_tower); the
+ *                                                  dynamics' first convolution has C + 1 inputs (last: the action
+ *                                                  plane), zero-padded to Cin = C + 16
+ *   head            ln_in [2][C], c1 [C][16] (1x1 conv), ln_mid [2][16], fc [576][32] (no bias), ln_vec [2][32],
+ *                   out_w [32][n], out_b [n] with n = 2 support_size + 1 (reward, value) or num_actions (policy) */
+typedef struct mzs_ez_head {
+  const float *ln_in, *c1, *ln_mid, *fc, *ln_vec, *out_w, *out_b;
+} mzs_ez_head;
+typedef struct mzs_ez_args {
+  int32_t struct_size;     /* = sizeof(mzs_ez_args) */
+  int32_t device;
+  int32_t batch;
+  int32_t channels;        /* C: 32 or 64 */
+  int32_t num_actions;     /* <= 64 */
+  int32_t support_size;    /* 2 support_size + 1 <= 64 */
+  const float *x;          /* [B, 6, 6, C] */
+  const int32_t *action;   /* [B]; the plane holds the raw index (muax/nn.py:291-296) */
+  float *y;                /* [B, 6, 6, C] next state out */
+  float *reward;           /* [B] out */
+  float *value;            /* [B] out */
+  float *prior_logits;     /* [B, A] out */
+  const float *d_ln_in, *d_conv;                       /* EZDynamic: LN before the action conv, the conv */
+  const float *d_ln0, *d_conv0, *d_ln1, *d_conv1;      /* ... its residual block */
+  const float *p_ln0, *p_conv0, *p_ln1, *p_conv1;      /* EZPrediction's residual block */
+  mzs_ez_head r, v, p;                                 /* reward / value / policy heads */
+} mzs_ez_args;
+int mzs_ez_recurrent(const mzs_ez_args *a, void *stream);
+
 /* ---- fused LayerNorm of the convolutional plugin nets ----
  * y = [relu]( LN(x) [+ LN2(x2)] [+ residual] ) with LN(x) = (x - mean) * rsqrt(var + eps) * scale[c] + offset[c],
  * statistics over ALL n elements of a sample (biased variance), scale / offset indexed by (element % channels):

@@ -28,6 +28,7 @@ UNITS = {
     "mz_fused_g4.hip": _FUSED,
     "mz_conv.hip": ["mz_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
     "mz_norm.hip": ["mz_host.h", "mz_norm.cuh", _ABI],
+    "mz_ez.hip": ["mz_host.h", "mz_ez.cuh", "mz_spec.cuh", _ABI],
 }
 SOURCES = list(UNITS)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans",

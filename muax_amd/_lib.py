@@ -85,13 +85,26 @@ class MzsLayerNormArgs(C.Structure):
                 ("residual", _vp), ("y", _vp), ("workspace", _vp), ("workspace_bytes", C.c_int64)]
 
 
+class MzsEzHead(C.Structure):
+    FIELDS = ["ln_in", "c1", "ln_mid", "fc", "ln_vec", "out_w", "out_b"]
+    _fields_ = [(n, _vp) for n in FIELDS]
+
+
+class MzsEzArgs(C.Structure):
+    WEIGHTS = ["d_ln_in", "d_conv", "d_ln0", "d_conv0", "d_ln1", "d_conv1", "p_ln0", "p_conv0", "p_ln1", "p_conv1"]
+    _fields_ = ([("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("channels", C.c_int32),
+                 ("num_actions", C.c_int32), ("support_size", C.c_int32), ("x", _vp), ("action", _vp), ("y", _vp),
+                 ("reward", _vp), ("value", _vp), ("prior_logits", _vp)] + [(n, _vp) for n in WEIGHTS]
+                + [("r", MzsEzHead), ("v", MzsEzHead), ("p", MzsEzHead)])
+
+
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup", "mzs_expand_backup_select",
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
-                    "mzs_layernorm_workspace_bytes"]
+                    "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent"]
 
 _lib = None
 
@@ -134,6 +147,7 @@ def load(build_if_missing: bool = True):
     L.mzs_mlp_train_workspace_bytes.restype = C.c_int64
     L.mzs_dirichlet.argtypes = [C.c_int32, C.POINTER(C.c_uint32 * 2), C.c_float, C.c_int32, C.c_int32, C.c_int64,
                                 C.c_int64, _vp, _vp]
+    L.mzs_ez_recurrent.argtypes = [C.POINTER(MzsEzArgs), _vp]
     L.mzs_layernorm_act.argtypes = [C.POINTER(MzsLayerNormArgs), _vp]
     L.mzs_layernorm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     L.mzs_layernorm_workspace_bytes.restype = C.c_int64

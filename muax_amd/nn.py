@@ -537,6 +537,93 @@ class EZDynamic(nn.Module):
         out = self.block(out)
         return self.r_func(out), out
 
+    # ---- HIP path of the whole recurrent_fn (mzs_ez_recurrent, muax_amd/csrc/mz_ez.cuh) ----
+    use_hip_recurrent = True
+
+    @staticmethod
+    def _pack_conv(w, cin_pad=None):
+        """HWIO [3, 3, Cin, Cout] -> the kernels' Wp[tap][Cin / 16][g][Cout][i] = W[tap][16 c + 4 g + i][co]."""
+        cin, cout = w.shape[2], w.shape[3]
+        if cin_pad and cin_pad != cin:
+            w = torch.cat([w, w.new_zeros(3, 3, cin_pad - cin, cout)], dim=2)
+            cin = cin_pad
+        return w.reshape(9, cin // 16, 4, 4, cout).permute(0, 1, 2, 4, 3).contiguous()
+
+    def _ez_packed(self, pred):
+        blocks, heads = (self.block, pred.block), (self.r_func, pred.v_func, pred.pi_func)
+        ps = [self.ln_in.scale, self.ln_in.offset, self.conv.w] + [p for b in blocks for p in b.parameters()] \
+            + [p for h in heads for p in h.parameters()]
+        sig = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        if getattr(self, "_ez_sig", None) != sig:
+            C_ = self.conv.out_channels
+            with torch.no_grad():
+                ln = lambda m: torch.stack([m.scale, m.offset]).contiguous()  # noqa: E731
+                pk = {"d_ln_in": ln(self.ln_in), "d_conv": self._pack_conv(self.conv.w, C_ + 16),
+                      "d_ln0": ln(self.block.ln_0), "d_conv0": self._pack_conv(self.block.conv_0.w),
+                      "d_ln1": ln(self.block.ln_1), "d_conv1": self._pack_conv(self.block.conv_1.w),
+                      "p_ln0": ln(pred.block.ln_0), "p_conv0": self._pack_conv(pred.block.conv_0.w),
+                      "p_ln1": ln(pred.block.ln_1), "p_conv1": self._pack_conv(pred.block.conv_1.w)}
+                for name, h in zip("rvp", heads):
+                    pk[name] = {"ln_in": ln(h.ln_in), "c1": h.conv.w.reshape(C_, 16).contiguous(), "ln_mid": ln(h.ln_mid),
+                                "fc": h.fc.w.detach().contiguous(), "ln_vec": ln(h.ln_vec),
+                                "out_w": h.out.w.detach().contiguous(), "out_b": h.out.b.detach().contiguous()}
+            self._ez_pack, self._ez_sig = pk, sig
+        return self._ez_pack
+
+    def hip_recurrent(self, pred, s, a, support_size: int):
+        """The whole recurrent_fn of muax/model.py:265-282 for the EZ nets in ONE HIP launch (mzs_ez_recurrent):
+        returns (reward [B], value [B], prior_logits [B, A], next_state [B, 6, 6, C]), or None when the nets are not
+        the shapes the kernel is built for (the caller then runs the torch modules)."""
+        def blk_ok(b, c):
+            return (isinstance(b, ResidualConvBlockV2) and not b.use_projection and b.conv_0.w is not None
+                    and b.conv_1.w is not None and tuple(b.conv_0.w.shape) == (3, 3, c, c)
+                    and tuple(b.conv_1.w.shape) == (3, 3, c, c) and b.ln_0.scale is not None and b.ln_1.scale is not None)
+
+        def head_ok(h, c, n):
+            return (isinstance(h, _LNReluHead) and h.conv.w is not None and tuple(h.conv.w.shape) == (1, 1, c, 16)
+                    and h.fc.w is not None and tuple(h.fc.w.shape) == (576, 32) and h.out.w is not None
+                    and tuple(h.out.w.shape) == (32, n) and h.out.b is not None and h.ln_in.scale is not None
+                    and h.ln_mid.scale is not None and h.ln_vec.scale is not None)
+
+        F = 2 * support_size + 1
+        if not (self.use_hip_recurrent and self.use_v2 and isinstance(pred, EZPrediction) and s.is_cuda
+                and s.dtype == torch.float32 and s.dim() == 4 and tuple(s.shape[1:3]) == (6, 6) and s.shape[3] in (32, 64)
+                and self.conv is not None and self.conv.w is not None and self.ln_in.scale is not None
+                and tuple(self.conv.w.shape) == (3, 3, s.shape[3] + 1, s.shape[3]) and F <= 64
+                and pred.num_actions <= 64 and pred.num_actions == self.num_actions and pred.block is not None):
+            return None  # (an inference-only entry point, like ResNetDynamic.hip_recurrent: no autograd through it)
+        c = s.shape[3]
+        if not (blk_ok(self.block, c) and blk_ok(pred.block, c) and head_ok(self.r_func, c, F)
+                and head_ok(pred.v_func, c, F) and head_ok(pred.pi_func, c, pred.num_actions)):
+            return None
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        pk = self._ez_packed(pred)
+        B = s.shape[0]
+        x = s.contiguous()
+        act = a.to(torch.int32).contiguous()
+        y = torch.empty_like(x)
+        outs = (torch.empty(B, device=x.device), torch.empty(B, device=x.device),
+                torch.empty(B, pred.num_actions, device=x.device))
+        args = _lib.MzsEzArgs()
+        args.struct_size = C.sizeof(_lib.MzsEzArgs)
+        args.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        args.batch, args.channels, args.num_actions, args.support_size = B, c, pred.num_actions, support_size
+        args.x, args.action, args.y = x.data_ptr(), act.data_ptr(), y.data_ptr()
+        args.reward, args.value, args.prior_logits = (o.data_ptr() for o in outs)
+        for name in _lib.MzsEzArgs.WEIGHTS:
+            setattr(args, name, pk[name].data_ptr())
+        for name in "rvp":
+            hd = getattr(args, name)
+            for f in _lib.MzsEzHead.FIELDS:
+                setattr(hd, f, pk[name][f].data_ptr())
+        with torch.cuda.device(x.device):
+            _lib.check(L.mzs_ez_recurrent(C.byref(args), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        self._ez_keep = (x, act)  # alive until the stream has consumed them
+        return outs[0], outs[1], outs[2], y
+
 
 class ResNetRepresentation(nn.Module):
     """muax/nn.py:291-310: uint8-range NHWC frames -> [B, H/16, W/16, 2*input_channels], min-max

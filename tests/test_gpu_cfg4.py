@@ -349,3 +349,45 @@ def test_conv_nets_with_fused_layernorm_equal_the_torch_modules():
                 mx.nn.HkLayerNorm.use_hip = True
         assert torch.allclose(s1, s0, rtol=1e-4, atol=1e-4), float((s1 - s0).abs().max())
         assert torch.allclose(v1, v0, rtol=1e-3, atol=1e-3) and torch.allclose(p1, p0, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("C,B", [(32, 1), (32, 9), (32, 128), (64, 5), (64, 40)])
+def test_ez_recurrent_kernel_matches_the_torch_modules(C, B):
+    """mzs_ez_recurrent (muax_amd/csrc/mz_ez.cuh): the whole recurrent_fn of the EZ nets (EZDynamic + EZPrediction with
+    pre-activation blocks, muax/nn.py:151-178,221-309; decodes of muax/model.py:273-274) in one launch against the torch
+    modules it replaces (MIOpen convolutions, the LayerNorm expressions), LayerNorm parameters and biases away from
+    their init values.  fp32 kernel on fp32 modules: 3e-4, like the ResNet recurrent kernel."""
+    g = torch.Generator().manual_seed(100 + C + B)
+    rep, pred, dy = (mx.nn.EZRepresentation(C, generator=g), mx.nn.EZPrediction(A, 21, 1.0, generator=g),
+                     mx.nn.EZDynamic(C, A, 21, 1.0, generator=g))
+    m = mx.MuZero(rep, pred, dy)
+    m.init(0, np.zeros((1, 84, 84, 4), F32))
+    with torch.no_grad():
+        for mod in (pred, dy):
+            for p in mod.parameters():
+                if p.dim() == 1:
+                    p.add_(0.2 * torch.randn(p.shape, generator=g).to(p.device))
+    m.weights_changed()
+    s = (torch.randn(B, 6, 6, C, generator=g) * 0.7).cuda()
+    a = torch.randint(0, A, (B,), generator=g).cuda()
+    got = dy.hip_recurrent(pred, s, a, SUPPORT)
+    assert got is not None
+    with torch.no_grad():
+        mx.nn.HkLayerNorm.use_hip = False
+        try:
+            r_logits, ns = dy(s, a)
+            v_logits, pi = pred(ns)
+        finally:
+            mx.nn.HkLayerNorm.use_hip = True
+        rew = mx.utils.support_to_scalar(torch.softmax(r_logits, -1), SUPPORT).flatten()
+        val = mx.utils.support_to_scalar(torch.softmax(v_logits, -1), SUPPORT).flatten()
+    assert torch.allclose(got[3], ns, rtol=1e-4, atol=3e-4), float((got[3] - ns).abs().max())
+    assert torch.allclose(got[2], pi, rtol=1e-4, atol=3e-4), float((got[2] - pi).abs().max())
+    assert torch.allclose(got[0], rew, rtol=1e-3, atol=3e-4), float((got[0] - rew).abs().max())
+    assert torch.allclose(got[1], val, rtol=1e-3, atol=3e-4), float((got[1] - val).abs().max())
+    # through MuZero._recurrent_inference: the one-launch route is the one that runs
+    (r2, d2, l2, v2), n2 = m._recurrent_inference(m.params, None, a, s)
+    assert torch.equal(n2, got[3]) and torch.equal(l2, got[2]) and float(d2[0]) == pytest.approx(0.99)
+    dy.use_hip_recurrent = False
+    (r3, _, l3, v3), n3 = m._recurrent_inference(m.params, None, a, s)
+    assert torch.allclose(n3, n2, rtol=1e-4, atol=3e-4) and torch.allclose(r3, r2, rtol=1e-3, atol=3e-4)

@@ -332,8 +332,9 @@ def test_error_behaviour():
 
 # ---------------------------------------------------------------- edge cases of the domain
 
-def _stepwise_vs_oracle(oracle, case, S, tiebreak, max_depth=None, key=(4, 5)):
-    """Drive the step-wise kernels and the oracle with the same (torch) net outputs; compare everything."""
+def _stepwise_vs_oracle(oracle, case, S, tiebreak, max_depth=None, key=(4, 5), fused_select=False):
+    """Drive the step-wise kernels and the oracle with the same (torch) net outputs; compare everything.
+    fused_select: mzs_expand_backup_select (the next selection in the expand + backward launch) instead of two calls."""
     from muax_amd import MuZeroSearch, SearchConfig
     B, A, E = case["B"], case["A"], case["E"]
     root, rec = _torch_recurrent(case)
@@ -347,12 +348,16 @@ def _stepwise_vs_oracle(oracle, case, S, tiebreak, max_depth=None, key=(4, 5)):
     oracle.tree_init(tree, oracle.root_prior(pl.cpu().numpy(), case["noise"], 0.25, case["invalid"]),
                      v.cpu().numpy(), emb.cpu().numpy(), case["invalid"])
     k_sample, _, sims = oracle.sim_keys_from_act_key(list(key), S)
+    nxt = None
     for sim in range(S):
-        action, pemb = s.select(sim)
+        action, pemb = nxt if fused_select and sim > 0 else s.select(sim)
         p_ref, a_ref, _ = oracle.step_select(tree, cfg, sim, sims[sim])
         assert np.array_equal(a_ref, action.cpu().numpy()), sim
         outs = rec(action, pemb)
-        s.expand_backup(sim, *outs)
+        if fused_select:
+            nxt = s.expand_backup_select(sim, *outs)
+        else:
+            s.expand_backup(sim, *outs)
         oracle.step_expand_backup(tree, sim, p_ref, a_ref, *[o.cpu().numpy() for o in outs])
     out = s.finish(1.0, None, with_tree=True)
     g = oracle.gumbel(k_sample, B * A).reshape(B, A)

@@ -83,12 +83,20 @@ constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
 constexpr int kHeadWords = 16 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots (4 values x 4 waves) + scratch of the heads
 
+// sum over the 64 lanes of a wavefront, in every lane: the DPP butterfly inside the 16-lane rows, then the four row
+// sums through v_readlane (round 3; the six shuffles through LDS this replaces cost ~0.3 us per reduction, and a launch
+// makes ~70 of them).  One fixed order for both launch shapes (they must agree bit for bit).
+MZ_DEV float wave_sum64(float x) {
+  x = row_sum(x);
+  const int xi = __float_as_int(x);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(xi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+  return (r0 + r1) + (r2 + r3);
+}
 template <int NV>
 MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i)
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v[i] = v[i] + __shfl_xor(v[i], m);
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum64(v[i]);
   __syncthreads();  // previous use of red[] is over
   if (lane == 0)
 #pragma unroll

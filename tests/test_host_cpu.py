@@ -378,3 +378,43 @@ def test_small_reference_utilities():
     t = Transition(obs=1, a=2, r=3., done=False, Rn=4., v=5., pi=6., w=1.)
     leaves, _ = flatten_transition_func(t)
     assert unflatten_transition_func(None, list(leaves)) == t
+
+
+def test_new_entry_points_validate_their_arguments_without_a_gpu():
+    """mzs_layernorm_act / mzs_ez_recurrent / mzs_expand_backup_select (round 3): ABI struct sizes as the C compiler sees
+    them, argument errors reported before any device is touched, and no CPU fallback behind them."""
+    L = _lib.load()
+    a = _lib.MzsLayerNormArgs()
+    assert L.mzs_layernorm_act(ctypes.byref(a), None) == _lib.MZS_E_INVALID  # struct_size 0: ABI mismatch
+    a.struct_size = ctypes.sizeof(_lib.MzsLayerNormArgs)
+    a.batch, a.n, a.channels, a.eps = 2, 30, 6, 1e-5
+    assert L.mzs_layernorm_act(ctypes.byref(a), None) == _lib.MZS_E_UNSUPPORTED  # n, channels: multiples of 4
+    a.n, a.channels = 32, 8
+    assert L.mzs_layernorm_act(ctypes.byref(a), None) == _lib.MZS_E_INVALID  # null tensors
+    assert L.mzs_layernorm_workspace_bytes(128, 56448) == 2 * 128 * 13 * 2 * 8 and L.mzs_layernorm_workspace_bytes(0, 8) == 0
+    x = np.zeros((2, 32), np.float32)
+    so = np.ones(8, np.float32)
+    ws = np.zeros(64, np.float64)
+    a.x = a.y = x.ctypes.data
+    a.scale = a.offset = so.ctypes.data
+    a.workspace, a.workspace_bytes = ws.ctypes.data, 8
+    assert L.mzs_layernorm_act(ctypes.byref(a), None) == _lib.MZS_E_INVALID  # workspace too small
+    a.workspace_bytes = ws.nbytes
+    if not torch.cuda.is_available():
+        assert L.mzs_layernorm_act(ctypes.byref(a), None) == _lib.MZS_E_NODEVICE
+    e = _lib.MzsEzArgs()
+    assert L.mzs_ez_recurrent(ctypes.byref(e), None) == _lib.MZS_E_INVALID
+    e.struct_size = ctypes.sizeof(_lib.MzsEzArgs)
+    e.batch, e.channels, e.num_actions, e.support_size = 4, 48, 18, 10
+    assert L.mzs_ez_recurrent(ctypes.byref(e), None) == _lib.MZS_E_UNSUPPORTED  # 32 or 64 channels
+    e.channels, e.support_size = 32, 40
+    assert L.mzs_ez_recurrent(ctypes.byref(e), None) == _lib.MZS_E_UNSUPPORTED  # 2 support + 1 <= 64
+    e.support_size = 10
+    assert L.mzs_ez_recurrent(ctypes.byref(e), None) == _lib.MZS_E_INVALID  # null tensors
+    assert L.mzs_expand_backup_select(None, 0, None, None, None, None, None, None, None, None) == _lib.MZS_E_INVALID
+    # the torch expressions stay the CPU route of the LayerNorm chains (training, tests): same values as the modules'
+    ln = mx.nn.HkLayerNorm()
+    t = torch.randn(3, 6, 6, 8)
+    assert not ln.fused_ok(t)
+    y = mx.nn.ln_act(t, ln, relu=True, residual=t)
+    assert torch.equal(y, torch.relu(t + ln(t)))

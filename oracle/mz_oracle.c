@@ -271,6 +271,17 @@ static float jax_normal(const uint32_t key[2]) {
   return 1.41421354f * mzo_erf_inv(jax_uniform(key, LO, 1.0f));
 }
 
+/* exported for the known-answer tests: jax.random.normal(key, ()) and jax.random.normal(key, (n,)) */
+float mzo_normal(const uint32_t key[2]) { return jax_normal(key); }
+void mzo_normal_vec(const uint32_t key[2], int64_t n, float *out) {
+  const float LO = -0.99999994f;
+  for (int64_t i = 0; i < n; ++i) {
+    const float f = mzo_uniform_from_bits(mzo_random_bits(key, n, i));
+    const float u = f * (1.0f - LO) + LO;
+    out[i] = 1.41421354f * mzo_erf_inv(u > LO ? u : LO);
+  }
+}
+
 /* jax _gamma_one(key, alpha, log_space = True): log of a Gamma(alpha, 1) draw */
 float mzo_loggamma_one(const uint32_t key_in[2], float alpha_orig) {
   const float THIRD = 0.333333343f, SQUEEZE = 0.0331f;

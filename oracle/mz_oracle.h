@@ -13,9 +13,15 @@
  *
  * PARITY UNPINNED: neither jax nor mctx can be imported in the build container
  * and the reference holds no golden vectors for this path.
- * The oracle is pinned only by hand-derived known-answer tests
+ * The SEARCH is pinned only by hand-derived known-answer tests
  * (tests/test_oracle_kat.py) and by an independent NumPy restatement
- * (oracle/mz_numpy.py).
+ * (oracle/mz_numpy.py); the PRNG layer (threefry, split, the vector layout of
+ * random_bits, uniform, the erf_inv normal) additionally reproduces every value
+ * JAX's own documentation prints (Random123 vectors; split / uniform / normal of
+ * PRNGKey(0) and PRNGKey(42); the quickstart's ten normals), to the bit.
+ * tests/golden/capture_from_mctx.py captures real reference outputs on a machine
+ * that has jax + mctx; tests/test_mctx_pin_cpu.py compares this oracle with them
+ * when they exist.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (muax_amd/) never does.
@@ -93,6 +99,8 @@ void mzo_split(const uint32_t key[2], int64_t n, int64_t row, uint32_t out[2]);
 uint32_t mzo_random_bits(const uint32_t key[2], int64_t size, int64_t i);
 float mzo_uniform_from_bits(uint32_t bits);
 float mzo_gumbel_from_bits(uint32_t bits);
+float mzo_normal(const uint32_t key[2]);   /* jax.random.normal(key, ()) as the gamma sampler draws it */
+void mzo_normal_vec(const uint32_t key[2], int64_t n, float *out);   /* jax.random.normal(key, (n,)) */
 /* jax.random.dirichlet restated (spec-to-confirm, see mz_oracle.c) */
 float mzo_log1p(float x);
 float mzo_erf_inv(float x);

@@ -204,6 +204,19 @@ def uniform(key, size):
                     np.float32)
 
 
+def normal(key, size=None):
+    """jax.random.normal(key, ()) as the gamma sampler of mz_oracle.c draws it (sqrt(2) * erf_inv(uniform(-1, 1))), or
+    jax.random.normal(key, (size,))."""
+    k = np.ascontiguousarray(key, np.uint32)
+    if size is None:
+        f = lib().mzo_normal
+        f.restype = C.c_float
+        return np.float32(f(_p(k, _u32p)))
+    out = np.zeros(size, np.float32)
+    lib().mzo_normal_vec(_p(k, _u32p), C.c_int64(size), _p(out, _f32p))
+    return out
+
+
 def gumbel(key, size):
     return np.array([lib().mzo_gumbel_from_bits(int(b)) for b in random_bits(key, size)],
                     np.float32)

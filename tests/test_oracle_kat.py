@@ -29,6 +29,23 @@ def test_jax_documented_split_and_uniform(oracle):
     assert oracle.uniform([0, 0], 1)[0] == F32(0.41845703)
 
 
+def test_jax_documented_normal_and_the_tutorial_key_walk(oracle):
+    """Values printed in JAX's own documentation (reproduced by the oracle to the last printed digit, i.e. to the bit: a
+    float32's shortest decimal form identifies it): the "Pseudorandom numbers" tutorial walks PRNGKey(42) --
+    `random.normal(key)` -0.18471177; `new_key, subkey = random.split(key)` -> [2465931498 3679230171] and
+    [255383827 267815257], `random.normal(subkey)` 1.3694694 -- and the jax.random module docs print
+    `random.normal(PRNGKey(0))` as -0.20584226.  They pin split(), the [-1, 1) uniform and the erf_inv-based normal that
+    the Dirichlet / gamma sampler restatement (mz_oracle.c, DESIGN.md section 2 "Root noise") is built on."""
+    assert oracle.split([0, 42], 2).tolist() == [[2465931498, 3679230171], [255383827, 267815257]]
+    assert oracle.normal([0, 42]) == F32(-0.18471177)
+    assert oracle.normal([255383827, 267815257]) == F32(1.3694694)
+    assert oracle.normal([0, 0]) == F32(-0.20584226)
+    # the JAX quickstart / README: key = random.PRNGKey(0); x = random.normal(key, (10,)); print(x)
+    quickstart = [-0.3721109, 0.26423115, -0.18252768, -0.7368197, -0.44030377, -0.1521442, -0.67135346, -0.5908641,
+                  0.73168886, 0.5673026]
+    assert oracle.normal([0, 0], 10).tolist() == [float(F32(v)) for v in quickstart]
+
+
 def test_random_bits_layout_odd_and_even(oracle):
     key = np.array([7, 9], np.uint32)
     # even: first half of iota hashed against second half

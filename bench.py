@@ -166,11 +166,10 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
         if i % ev_every == ev_every // 2:
             evs[i][1].record()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # THIS rank's time for exactly `steps` steps; the job's time is the max over ranks
     if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
+        dist.barrier()  # closing bracket: no rank leaves the timed region's neighbourhood before all are done
+        torch.cuda.synchronize()
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

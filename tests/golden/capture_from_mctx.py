@@ -180,8 +180,10 @@ def versions():
     import jax
     import mctx
     v = {"jax": jax.__version__, "mctx": getattr(mctx, "__version__", "unknown"), "haiku": haiku.__version__,
-         "numpy": np.__version__, "jax_threefry_partitionable": bool(jax.config.jax_threefry_partitionable),
-         "jax_enable_x64": bool(jax.config.jax_enable_x64), "backend": jax.default_backend()}
+         "numpy": np.__version__,
+         # (older jax has no such flag: its threefry stream is the non-partitionable one the oracle restates)
+         "jax_threefry_partitionable": bool(getattr(jax.config, "jax_threefry_partitionable", False)),
+         "jax_enable_x64": bool(getattr(jax.config, "jax_enable_x64", False)), "backend": jax.default_backend()}
     try:
         import jaxlib
         v["jaxlib"] = jaxlib.__version__
@@ -233,7 +235,7 @@ def capture(ref, nn, policy_mod, route, name, shape, seed, S, policy="muzero", q
     path = os.path.join(out_dir, f"mctx_{tag}.npz")
     fx.save_case(path, meta, w, obs, np.asarray(key, np.uint32), outputs, tree_arrays(out.search_tree), inter)
     print(f"wrote {os.path.relpath(path)}  ({os.path.getsize(path) / 1024:.0f} KB)  pred_on={pred_on}")
-    return model, params, w
+    return model, params, w, pred_on
 
 
 def capture_checkpoint(model, w, out_dir):
@@ -247,7 +249,7 @@ def capture_checkpoint(model, w, out_dir):
     print("wrote tests/golden/mctx_checkpoint.npy + mctx_checkpoint_expected.npz")
 
 
-def capture_rollout(model, params, w, out_dir, steps=20, S=10):
+def capture_rollout(model, params, w, out_dir, pred_on="child", steps=20, S=10):
     """20 CartPole-v1 steps of the fit loop's acting half (muax/train.py:153-170): key, subkey = split(key);
     a, pi, v = act(subkey, obs, with_pi=True, with_value=True, obs_from_batch=False, num_simulations=S, temperature=T)."""
     try:
@@ -271,7 +273,8 @@ def capture_rollout(model, params, w, out_dir, steps=20, S=10):
             obs, _ = env.reset()
     data = {k: np.asarray(v) for k, v in rec.items()}
     data.update({"w_" + k: v for k, v in w.items()})
-    data["meta"] = np.array(json.dumps({"num_simulations": S, "versions": versions(), "format_version": fx.FORMAT_VERSION}))
+    data["meta"] = np.array(json.dumps({"num_simulations": S, "recurrent_pred_on": pred_on, "versions": versions(),
+                                        "format_version": fx.FORMAT_VERSION}))
     np.savez_compressed(os.path.join(out_dir, "mctx_rollout_cartpole_s10.npz"), **data)
     print("wrote tests/golden/mctx_rollout_cartpole_s10.npz")
 
@@ -301,9 +304,9 @@ def main():
     for name in ("cartpole", "lunarlander"):
         for qt in ("qtransform_by_parent_and_siblings", "qtransform_completed_by_mix_value"):
             capture(ref, nn, policy_mod, route, name, SHAPES[name], 0, 50, policy="gumbel", qtransform=qt, out_dir=args.out)
-    model, params, w = first
+    model, params, w, pred_on = first
     capture_checkpoint(model, w, args.out)
-    capture_rollout(model, params, w, args.out)
+    capture_rollout(model, params, w, args.out, pred_on)
 
 
 if __name__ == "__main__":

@@ -40,8 +40,22 @@ FLOAT_TOL = 1e-5  # BASELINE.json: "within 1e-5 on value/policy logits"
 
 
 def fixture_paths():
-    """Real captures present in tests/golden (never the synthetic self-test files)."""
-    return sorted(glob.glob(os.path.join(HERE, "mctx_*.npz")))
+    """Real per-call captures present in tests/golden (mctx_<shape>_<policy>_s<S>_seed<k>[_mix].npz; not the
+    checkpoint's expected weights, not the fit-loop trace, never the synthetic self-test files)."""
+    return sorted(glob.glob(os.path.join(HERE, "mctx_*_seed*.npz")))
+
+
+ROLLOUT_PATH = os.path.join(HERE, "mctx_rollout_cartpole_s10.npz")
+
+
+def load_rollout(path=ROLLOUT_PATH):
+    """The fit-loop trace of the capture script (muax/train.py:153-170: key, subkey = split(key); act(subkey, obs,
+    with_pi=True, with_value=True, obs_from_batch=False, num_simulations=10, temperature=1)): per step the sub-key, the
+    observation and what act() returned, plus the flattened weights."""
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return {"meta": meta, "w": {k: z["w_" + k] for k in WEIGHT_NAMES}, "subkey": z["subkey"], "obs": z["obs"],
+            "action": z["action"], "pi": z["pi"], "v": z["v"]}
 
 
 def save_case(path, meta: dict, weights: dict, obs, key, outputs: dict, tree: dict, rng: dict):
@@ -204,4 +218,44 @@ def synthetic_case(po, path, policy="muzero", seed=0, B=8, obs_dim=4, E=8, A=2, 
     rng = oracle_rng(po, case)
     out = oracle_run(po, case)
     save_case(path, meta, w, obs, key, out, out["tree"], rng)
+    return path
+
+
+def oracle_rollout_mismatches(po, tr) -> list:
+    """The oracle's act() for every recorded (sub-key, observation) of a fit-loop trace against what the trace holds:
+    action exact, pi and value to FLOAT_TOL."""
+    S = tr["meta"]["num_simulations"]
+    mlp = po.Mlp(tr["w"], 4, 8, 2, 21, recurrent_pred_on=1 if tr["meta"].get("recurrent_pred_on") == "parent" else 0)
+    msgs = []
+    for t in range(len(tr["action"])):
+        key = [int(x) for x in tr["subkey"][t]]
+        noise = po.dirichlet(po.split(key, 3)[1], 0.3, 1, 2)
+        out = po.act_mlp(mlp, po.SearchCfg(S, tiebreak=1), tr["obs"][t][None], key, noise, 0.25, None, 1.0)
+        msgs += _diff(f"step {t} action", np.asarray([tr["action"][t]]), out["action"], True)
+        msgs += _diff(f"step {t} pi", np.asarray(tr["pi"][t]).reshape(1, 2), out["action_weights"], False)
+        msgs += _diff(f"step {t} value", np.asarray([tr["v"][t]], np.float32), out["root_value"], False)
+    return msgs
+
+
+def synthetic_rollout(po, path, steps=6, S=10, seed=0):
+    """A fit-loop trace in the capture script's format whose 'reference' side is the oracle (NOT a pin; exercises the
+    reader and both consumers before a real trace exists)."""
+    w = po.random_mlp_weights(seed, 4, 8, 2, 21, bias_scale=0.1)
+    rng = np.random.default_rng(seed)
+    mlp = po.Mlp(w, 4, 8, 2, 21)
+    rec = {k: [] for k in ("subkey", "obs", "action", "pi", "v")}
+    key = [0, 7]
+    for _ in range(steps):
+        key, sub = [list(map(int, k)) for k in po.split(key, 2)]
+        obs = rng.uniform(-1, 1, 4).astype(np.float32)
+        noise = po.dirichlet(po.split(sub, 3)[1], 0.3, 1, 2)
+        out = po.act_mlp(mlp, po.SearchCfg(S, tiebreak=1), obs[None], sub, noise, 0.25, None, 1.0)
+        rec["subkey"].append(np.asarray(sub, np.uint32)); rec["obs"].append(obs)
+        rec["action"].append(int(out["action"][0])); rec["pi"].append(out["action_weights"].copy())
+        rec["v"].append(float(out["root_value"][0]))
+    data = {k: np.asarray(v) for k, v in rec.items()}
+    data.update({"w_" + k: v for k, v in w.items()})
+    data["meta"] = np.array(json.dumps({"num_simulations": S, "recurrent_pred_on": "child", "versions": {},
+                                        "format_version": FORMAT_VERSION}))
+    np.savez_compressed(path, **data)
     return path

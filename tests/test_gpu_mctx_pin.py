@@ -71,6 +71,28 @@ def test_hip_path_matches_the_reference_capture(path):
     assert not msgs, f"{os.path.basename(path)} ({case['meta']['versions']}):\n  " + "\n  ".join(msgs)
 
 
+def _check_rollout(tr):
+    case = {"meta": {"policy": "muzero", "A": 2, "E": 8, "obs_dim": 4, "support_size": 10, "discount": 0.99,
+                     "recurrent_pred_on": tr["meta"].get("recurrent_pred_on", "child")}, "w": tr["w"]}
+    model = _model(case)
+    for t in range(len(tr["action"])):
+        a, pi, v = model.act(tr["subkey"][t], tr["obs"][t], with_pi=True, with_value=True,
+                             num_simulations=tr["meta"]["num_simulations"], temperature=1.0)
+        assert isinstance(a, int) and a == int(tr["action"][t]), t
+        assert pi.shape == (1, 2) and np.allclose(pi, tr["pi"][t].reshape(1, 2), atol=1e-5), t
+        assert abs(v - float(tr["v"][t])) <= 1e-5 * max(1.0, abs(float(tr["v"][t]))), t
+
+
+def test_hip_path_reproduces_the_reference_fit_loop_trace(oracle, tmp_path):
+    """The reference's own acting loop (20 CartPole steps, one root, 10 simulations) through MuZero.act() unbatched --
+    python int action, pi [1, A], python float value, as muax/model.py:160-179 returns them.  Always run on a
+    synthetic trace in the same format (the oracle's output); on the real one when it exists."""
+    _check_rollout(fx.load_rollout(fx.synthetic_rollout(oracle, str(tmp_path / "trace.npz"))))
+    if not os.path.exists(fx.ROLLOUT_PATH):
+        pytest.skip(NO_CAPTURE + " (fit-loop trace: mctx_rollout_cartpole_s10.npz)")
+    _check_rollout(fx.load_rollout())
+
+
 @pytest.mark.parametrize("policy,shape", [("muzero", (4, 8, 2)), ("muzero", (8, 32, 4)), ("gumbel", (4, 8, 2))])
 def test_harness_on_a_synthetic_file(oracle, tmp_path, policy, shape):
     """The same harness on a file in the capture format holding the ORACLE's output (not a pin): the HIP path must

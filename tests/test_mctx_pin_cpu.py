@@ -34,6 +34,15 @@ def test_oracle_matches_the_reference_capture(oracle, path):
     assert not msgs, f"{os.path.basename(path)} ({case['meta']['versions']}):\n  " + "\n  ".join(msgs)
 
 
+def test_oracle_reproduces_the_reference_fit_loop_trace(oracle):
+    """20 CartPole steps of the reference's own acting loop (one root, 10 simulations): the oracle's act() for every
+    recorded (sub-key, observation) -- action exact, pi and value to 1e-5."""
+    if not os.path.exists(fx.ROLLOUT_PATH):
+        pytest.skip(NO_CAPTURE + " (fit-loop trace: mctx_rollout_cartpole_s10.npz)")
+    msgs = fx.oracle_rollout_mismatches(oracle, fx.load_rollout())
+    assert not msgs, "\n  ".join(msgs)
+
+
 def test_reference_checkpoint_reads_back(tmp_path):
     """A checkpoint written by the reference's own save (jnp.save of {'params', 'optimizer_state'},
     muax/model.py:203-212) through muax_amd.checkpoint, against the weights the capture script flattened."""
@@ -82,6 +91,15 @@ def test_harness_on_a_synthetic_file(oracle, tmp_path, policy):
         rng["tiebreak"] = rng["tiebreak"].copy()
         rng["tiebreak"][2, 1, 0, 0] = np.nextafter(rng["tiebreak"][2, 1, 0, 0], np.float32(2))
         assert any("tiebreak" in m for m in fx.compare_rng(case, rng))
+
+
+def test_rollout_trace_harness_on_a_synthetic_file(oracle, tmp_path):
+    """The fit-loop trace reader / checker on a file in the capture script's format (the oracle's own output: not a pin)."""
+    tr = fx.load_rollout(fx.synthetic_rollout(oracle, str(tmp_path / "trace.npz")))
+    assert tr["pi"].shape == (6, 1, 2) and not fx.oracle_rollout_mismatches(oracle, tr)
+    tr["action"] = tr["action"].copy()
+    tr["action"][2] ^= 1
+    assert any("step 2 action" in m for m in fx.oracle_rollout_mismatches(oracle, tr))
 
 
 def test_capture_script_flattens_haiku_params_in_the_checkpoint_readers_order():

@@ -417,7 +417,10 @@ class MuZero:
                 action, root_value = int(action[0]), float(root_value[0])
         elif device_outputs and obs_from_batch:
             # the search handle's output buffers are reused by the next act(): hand out copies (stream-ordered, no sync)
-            action, weights, root_value = plan_output.action.clone(), plan_output.action_weights.clone(), root_value.clone()
+            if self._last_fused is not None and getattr(self._last_fused, "_out", None) is not None:
+                action, weights, root_value = self._last_fused.outputs_clone()  # one copy kernel instead of three
+            else:
+                action, weights, root_value = plan_output.action.clone(), plan_output.action_weights.clone(), root_value.clone()
         else:
             if self._last_fused is not None:
                 # fused path, device inputs: the three outputs share one allocation -> one device-to-host copy, one sync

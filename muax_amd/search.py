@@ -201,6 +201,13 @@ class MuZeroSearch:
         h = self._out_host_np
         return h[:B].view(np.int32).copy(), h[B:B + B * A].reshape(B, A).copy(), h[B + B * A:].copy()
 
+    def outputs_clone(self):
+        """(action, action_weights, root_value) of the last fused act() as views of ONE fresh device buffer: a single
+        stream-ordered copy (the handle's own buffers are overwritten by the next act())."""
+        B, A = self.batch, self.cfg.num_actions
+        c = self._out.clone()
+        return c[:B].view(torch.int32), c[B:B + B * A].view(B, A), c[B + B * A:]
+
     def _stage_obs(self, obs, obs_dim):
         """Host observations (NumPy / CPU tensor) -> device through a pinned staging buffer, asynchronously."""
         B = self.batch

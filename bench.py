@@ -259,8 +259,8 @@ def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
     """BASELINE configs[3] on ONE GPU's shard (1024 roots / 8 GPUs = 128): Atari-shaped 84x84x4 frames, the reference's
     ResNet nets (muax/nn.py:313-395; random init), A = 18, num_simulations = 200, through MuZero.act() with the search
     loop captured in one hipGraph.  The dominant kernel is the recurrent_fn launch (mz_resnet_tower_kernel, fp32 MFMA);
-    it is timed here with HIP events over `tower_launches` back-to-back launches on the stream act() uses, at the
-    shapes the search calls it with; `roofline` prices it against the dense fp32 matrix peak."""
+    it is timed here with HIP events over `tower_launches` back-to-back launches (replayed from a hipGraph, as inside
+    act()) on the stream act() uses, at the shapes the search calls it with; `roofline` prices it against the dense fp32 matrix peak."""
     import muax_amd as mx
     A, F, support = 18, 21, 10
     g = torch.Generator().manual_seed(0)
@@ -290,14 +290,29 @@ def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
     a = torch.randint(0, A, (roots,), generator=g).to(dev)
     for _ in range(10):
         dy.hip_recurrent(pred, s, a, support)
+    torch.cuda.synchronize()
+    # the launches are replayed from a hipGraph (as inside act()): eager Python calls of hip_recurrent cost the host
+    # about as much as the kernel costs the device, and the events would time the host
+    per_graph = 50
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        dy.hip_recurrent(pred, s, a, support)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(per_graph):
+            dy.hip_recurrent(pred, s, a, support)
+    graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    reps = max(1, tower_launches // per_graph)
     e0.record()
-    for _ in range(tower_launches):
-        dy.hip_recurrent(pred, s, a, support)
+    for _ in range(reps):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    kernel_ms = e0.elapsed_time(e1) / tower_launches
+    kernel_ms = e0.elapsed_time(e1) / (reps * per_graph)
     flops = recurrent_flops_per_root(A, F) * roots
     tf = flops / (kernel_ms * 1e-3) / 1e12
     pair = bool(dy.use_pair_tower) and bool(getattr(dy, "_pair_scratch", None))
@@ -309,7 +324,7 @@ def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
             "recurrent_share_of_act": round(kernel_ms * S / (dt * 1e3), 3),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "mz_resnet_tower_kernel" + (" (pair mode: 2 workgroups per root)" if pair else ""),
+                         "kernel": "mz_resnet_tower_pair_kernel (2 workgroups per root)" if pair else "mz_resnet_tower_kernel",
                          "kernel_ms": round(kernel_ms, 4), "launches_per_act": S,
                          "algorithmic_flops_per_launch": int(flops)}}
 

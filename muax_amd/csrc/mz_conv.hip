@@ -44,7 +44,8 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
   p.inv_num_actions = a->stem_w ? 1.0f / (float)a->num_actions : 0.0f;
   p.B = a->batch; p.blocks = a->blocks; p.normalize = a->normalize;
   const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords);
-  static bool tower_attr = false;
+  static bool tower_attr_dev[64] = {};  // per device: one process may drive several GPUs
+  bool& tower_attr = tower_attr_dev[a->device & 63];
   if (!tower_attr) {
     MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -57,7 +58,8 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
     if (2 * a->blocks + 1 > mz::kPairMsgs) return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resnet_tower: too many blocks for pair mode");
     p.pair_f = static_cast<float*>(a->pair_scratch);
     p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot);
-    static bool pair_attr = false;
+    static bool pair_attr_dev[64] = {};
+    bool& pair_attr = pair_attr_dev[a->device & 63];
     if (!pair_attr) {
       MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_pair_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -8,9 +8,10 @@
 
 namespace {
 template <int C>
-int launch_ez(const mz::EzParams& p, hipStream_t stream) {
+int launch_ez(const mz::EzParams& p, int device, hipStream_t stream) {
   const size_t lds = sizeof(float) * mz::EzGeom<C>::LDS_WORDS;
-  static bool attr = false;
+  static bool attr_dev[64] = {};  // per device: one process may drive several GPUs
+  bool& attr = attr_dev[device & 63];
   if (!attr) {
     MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_ez_recurrent_kernel<C>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -55,5 +56,5 @@ extern "C" int mzs_ez_recurrent(const mzs_ez_args* a, void* stream_) {
   p.B = a->batch; p.A = a->num_actions; p.support = a->support_size; p.F = 2 * a->support_size + 1;
   p.hr = head(a->r, p.F); p.hv = head(a->v, p.F); p.hp = head(a->p, p.A);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  return a->channels == 32 ? launch_ez<32>(p, stream) : launch_ez<64>(p, stream);
+  return a->channels == 32 ? launch_ez<32>(p, a->device, stream) : launch_ez<64>(p, a->device, stream);
 }

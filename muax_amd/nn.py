@@ -373,9 +373,19 @@ def avg_pool_same(x: torch.Tensor, window: int = 3, stride: int = 2) -> torch.Te
     xc = x.permute(0, 3, 1, 2)
     (ht, hb), (wl, wr) = _same_pad(x.shape[1], window, stride), _same_pad(x.shape[2], window, stride)
     s = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(xc, (wl, wr, ht, hb)), window, stride, divisor_override=1)
-    ones = torch.ones(1, 1, x.shape[1], x.shape[2], dtype=x.dtype, device=x.device)
-    cnt = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(ones, (wl, wr, ht, hb)), window, stride, divisor_override=1)
+    key = (x.shape[1], x.shape[2], window, stride, x.dtype, x.device)
+    cnt = _POOL_COUNTS.get(key)
+    if cnt is None:
+        # the number of valid elements under each window depends on the geometry only: computed once per shape and kept
+        # (a tensor made while a hipGraph is being captured belongs to the capture: it is not kept)
+        ones = torch.ones(1, 1, x.shape[1], x.shape[2], dtype=x.dtype, device=x.device)
+        cnt = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(ones, (wl, wr, ht, hb)), window, stride, divisor_override=1)
+        if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _POOL_COUNTS[key] = cnt
     return (s / cnt).permute(0, 2, 3, 1)
+
+
+_POOL_COUNTS = {}
 
 
 class ResidualConvBlockV1(nn.Module):

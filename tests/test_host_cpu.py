@@ -418,3 +418,18 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     assert not ln.fused_ok(t)
     y = mx.nn.ln_act(t, ln, relu=True, residual=t)
     assert torch.equal(y, torch.relu(t + ln(t)))
+
+
+def test_bench_refuses_to_run_without_the_devices_it_was_asked_for():
+    """`python bench.py --gpus N` on a box with fewer than N ROCm devices (here: none) stops with a message and no JSON
+    line -- it never prints a line for fewer ranks than it was asked for, and there is no CPU fallback to measure."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MUAX_BENCH_SINGLE_DEVICE")}
+    for n in ("1", "2"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", n, "--steps", "2", "--warmup", "1"],
+                             env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "{" not in out.stdout
+        assert "ROCm" in out.stderr

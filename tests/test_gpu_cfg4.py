@@ -391,3 +391,33 @@ def test_ez_recurrent_kernel_matches_the_torch_modules(C, B):
     dy.use_hip_recurrent = False
     (r3, _, l3, v3), n3 = m._recurrent_inference(m.params, None, a, s)
     assert torch.allclose(n3, n2, rtol=1e-4, atol=3e-4) and torch.allclose(r3, r2, rtol=1e-3, atol=3e-4)
+
+
+def test_fused_layernorm_in_place():
+    """include/mzsearch.h: `y` may alias x, x2 or the residual (every element is read and written by the same thread,
+    after the moments launch): the in-place call gives the bits of the out-of-place one."""
+    import ctypes as C
+
+    from muax_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 11, 11, 64, generator=g).cuda()
+    res = torch.randn(5, 11, 11, 64, generator=g).cuda()
+    ln = mx.nn.HkLayerNorm()
+    ln.materialize(x)
+    with torch.no_grad():
+        ln.offset.add_(0.3)
+        want = mx.nn.ln_act(x, ln, relu=True, residual=res)
+    for target in ("x", "residual"):
+        xx, rr = x.clone(), res.clone()
+        a = _lib.MzsLayerNormArgs()
+        a.struct_size = C.sizeof(_lib.MzsLayerNormArgs)
+        a.device, a.batch, a.n, a.channels, a.relu, a.eps = 0, 5, 11 * 11 * 64, 64, 1, 1e-5
+        a.x, a.scale, a.offset, a.residual = xx.data_ptr(), ln.scale.data_ptr(), ln.offset.data_ptr(), rr.data_ptr()
+        out = xx if target == "x" else rr
+        a.y = out.data_ptr()
+        ws = torch.empty(L.mzs_layernorm_workspace_bytes(5, a.n) // 8, dtype=torch.float64, device="cuda")
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+        _lib.check(L.mzs_layernorm_act(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), target

@@ -99,26 +99,46 @@ MZ_DEV void ez_load_weights(const float* __restrict__ Wp, int g, int co, ez4 (&w
   const ez4* q = reinterpret_cast<const ez4*>(Wp);
 #pragma unroll
   for (int t = 0; t < 9 * G; ++t) wq[t] = q[((size_t)t * 4 + g) * C + co];
+#ifdef MZ_EZ_PIN_LOADS
+  __builtin_amdgcn_sched_barrier(0);  // keep the requests HERE: the scheduler otherwise sinks them next to their use
+#endif
 }
 
-// acc[t] = conv3x3 of the haloed map `in` for pixel tile t0 + t, this wave's 16 output channels
-template <int C, int G, int TPW>
-MZ_DEV void ez_conv(const float* in, const ez4 (&wq)[9 * G], const int (&abase)[TPW], const bool (&on)[TPW], int g,
-                    ez4 (&acc)[TPW]) {
+// acc[t] = conv3x3 of the haloed map `in` for this wave's pixel tiles t = 0 .. NT - 1, its 16 output channels.
+// NT is a COMPILE-TIME count: a run-time "is this tile on" test around every group of four MFMAs turned the unrolled
+// loop into ~300 basic blocks with the accumulator hazards padded out at each (45 us per launch; 25 of them here).
+template <int C, int G, int TPW, int NT>
+MZ_DEV void ez_conv_nt(const float* in, const ez4 (&wq)[9 * G], const int (&abase)[TPW], int g, ez4 (&acc)[TPW]) {
   constexpr int STRIDE = EzGeom<C>::STRIDE;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) acc[t] = (ez4){0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef MZ_EZ_NO_CONV
+  return;
+#endif
   StaticFor<0, 9 * G>::run([&](auto ic) {
     constexpr int idx = decltype(ic)::value, tap = idx / G, c = idx % G;
     constexpr int off = ((tap / 3) * kEzHalo + tap % 3) * STRIDE + 16 * c;
+    ez4 a[NT];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-      if (on[t]) {  // (wave-uniform)
-        const ez4 a = *reinterpret_cast<const ez4*>(in + abase[t] + off + 4 * g);
+    for (int t = 0; t < NT; ++t) a[t] = *reinterpret_cast<const ez4*>(in + abase[t] + off + 4 * g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wq[idx][i], acc[t], 0, 0, 0);
-      }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], wq[idx][i], acc[t], 0, 0, 0);
   });
+}
+// the waves of pixel group 0 hold TPW tiles, those of the last group what is left of the three (one wave-uniform branch
+// per convolution)
+template <int C, int G, int TPW>
+MZ_DEV void ez_conv(const float* in, const ez4 (&wq)[9 * G], const int (&abase)[TPW], const bool (&on)[TPW], int g,
+                    ez4 (&acc)[TPW]) {
+  constexpr int LAST = 3 - (EzGeom<C>::PG - 1) * TPW;  // tiles of the last pixel group
+  if constexpr (LAST == TPW) {
+    ez_conv_nt<C, G, TPW, TPW>(in, wq, abase, g, acc);
+  } else {
+    if (on[TPW - 1]) ez_conv_nt<C, G, TPW, TPW>(in, wq, abase, g, acc);
+    else ez_conv_nt<C, G, TPW, LAST>(in, wq, abase, g, acc);
+  }
 }
 
 // hk.LayerNorm over the whole map (biased variance, eps 1e-5) of values held in the MFMA C layout:
@@ -164,17 +184,15 @@ MZ_DEV void ez_store_map(const ez4 (&v)[TPW], const bool (&ok)[TPW][4], const in
 
 // support_to_scalar(softmax(logits[0..F))) by the first wave (F <= 64)
 MZ_DEV float ez_decode_support(const float* logits, int F, int support, int lane) {
-  float x = lane < F ? logits[lane] : -INFINITY;
-  float m = x;
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
-  float e = lane < F ? exp_neg(x - m) : 0.0f;
-  float s = e, t = e * (float)(lane - support);
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) {
-    s = s + __shfl_xor(s, k);
-    t = t + __shfl_xor(t, k);
+  const float x = lane < F ? logits[lane] : -INFINITY;
+  float m = row_max<4>(x);  // DPP inside the rows, v_readlane across them (no shuffles through LDS)
+  {
+    const int mi = __float_as_int(m);
+    m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(mi, 0)), __int_as_float(__builtin_amdgcn_readlane(mi, 16))),
+              fmaxf(__int_as_float(__builtin_amdgcn_readlane(mi, 32)), __int_as_float(__builtin_amdgcn_readlane(mi, 48))));
   }
+  const float e = lane < F ? exp_neg(x - m) : 0.0f;
+  const float s = ez_wave_sum(e), t = ez_wave_sum(e * (float)(lane - support));
   return inv_scaling(t / s);
 }
 
@@ -189,6 +207,9 @@ MZ_DEV void ez_head(const EzHead& H, const ez4 (&res)[EzGeom<C>::TPW], const boo
   float* part = flat + 576;
   float* vec = part + 8 * 32;
   float* lgt = vec + 64;
+#ifdef MZ_EZ_NO_HEADS
+  return;
+#endif
   const int g = lane >> 4, n16 = lane & 15;
   // the flatten -> Linear weights of this thread (72 inputs x its output), the output layer's column and the vector
   // LayerNorm's parameters are requested NOW: they are bound by L2 latency, and three reductions and a convolution

@@ -93,6 +93,16 @@ MZ_DEV float wave_sum64(float x) {
   const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
   return (r0 + r1) + (r2 + r3);
 }
+// value of the lane 16 / 32 lanes away (same column n) through v_permlane16_swap / v_permlane32_swap (gfx950; no LDS):
+// with the same register as both operands the swap exchanges rows (0, 1), (2, 3) / halves of the wavefront
+MZ_DEV float lane_xor16(float x) {
+  auto s = __builtin_amdgcn_permlane16_swap(f2u(x), f2u(x), false, false);
+  return u2f((threadIdx.x & 16) ? s[0] : s[1]);
+}
+MZ_DEV float lane_xor32(float x) {
+  auto s = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
+  return u2f((threadIdx.x & 32) ? s[0] : s[1]);
+}
 template <int NV>
 MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
 #pragma unroll
@@ -253,8 +263,8 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         float t = rsum[v];
-        t = t + __shfl_xor(t, 16);
-        t = t + __shfl_xor(t, 32);
+        t = t + lane_xor16(t);
+        t = t + lane_xor32(t);
         acc[s][2][v] = t;
       }
     }
@@ -363,17 +373,12 @@ MZ_DEV f32x4 conv1x1_k16(const float* row, const float* __restrict__ W, int n, i
 }
 // support_to_scalar(softmax(logits[0..F))) by the first wave (F <= 64), result in every lane of that wave
 MZ_DEV float decode_support(const float* logits, int F, int support, int lane) {
-  float x = lane < F ? logits[lane] : -INFINITY;
-  float m = x;
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
-  float e = lane < F ? exp_neg(x - m) : 0.0f;
-  float s = e, t = e * (float)(lane - support);
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) {
-    s = s + __shfl_xor(s, k);
-    t = t + __shfl_xor(t, k);
-  }
+  const float x = lane < F ? logits[lane] : -INFINITY;
+  float m = row_max<4>(x);  // DPP inside the rows, the swaps across them (no shuffles through LDS)
+  m = fmaxf(m, lane_xor16(m));
+  m = fmaxf(m, lane_xor32(m));
+  const float e = lane < F ? exp_neg(x - m) : 0.0f;
+  const float s = wave_sum64(e), t = wave_sum64(e * (float)(lane - support));
   return inv_scaling(t / s);
 }
 
@@ -858,8 +863,8 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         mn = ok ? fminf(mn, acc[mt][v]) : mn;
         mx = ok ? fmaxf(mx, acc[mt][v]) : mx;
       }
-    mn = fminf(mn, __shfl_xor(mn, 16)); mn = fminf(mn, __shfl_xor(mn, 32));
-    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mn = fminf(mn, lane_xor16(mn)); mn = fminf(mn, lane_xor32(mn));
+    mx = fmaxf(mx, lane_xor16(mx)); mx = fmaxf(mx, lane_xor32(mx));
   }
   const float* fin = nullptr;
   if constexpr (PAIR) {

@@ -115,8 +115,9 @@ def pmc_traffic(workload):
 
 
 def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl", settle_ms=30.0):
-    """`steps` timed launches of the fused act() kernel on this rank's B roots of the global batch (inputs resident
-    in HBM, launches back to back, one synchronisation at the end; barrier + max over ranks for N > 1).
+    """`steps` timed acts of the fused act() kernel on this rank's B roots of the global batch (inputs resident in
+    HBM; every act followed by the host synchronisation; barrier + max over ranks for N > 1), then the same number of
+    launches back to back with one synchronisation at the end (`pipelined`).
 
     Before the `warmup` untimed steps the GPU is brought to its working clocks: the MI355X ramps them over ~10 ms of
     continuous work (the same 20 timed steps measure 36.9 M env-steps/s after 5 warm-up launches = 0.5 ms, 37.6 M after
@@ -148,62 +149,68 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
             step(i)
     for i in range(warmup):
         step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    # HIP events bracket a SAMPLE of the launches (every 10th step of the timed region): an event pair costs
-    # ~6 us of stream time, 5 % of a 134 us kernel, so bracketing every launch would slow the very loop
-    # that is being timed; unbracketed launches run back to back
-    ev_every = 10 if steps >= 20 else 1
-    sampled = [i for i in range(steps) if i % ev_every == ev_every // 2]
-    for i in range(steps):
-        if i % ev_every == ev_every // 2:
-            evs[i][0].record()
-        step(warmup + i)
-        if i % ev_every == ev_every // 2:
-            evs[i][1].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0  # THIS rank's time for exactly `steps` steps; the job's time is the max over ranks
-    if dist:
-        dist.barrier()  # closing bracket: no rank leaves the timed region's neighbourhood before all are done
-        torch.cuda.synchronize()
-        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    def reduce_max(x):
+        if not dist:
+            return x
+        t = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in sampled]))
-    # SURVEY.md 8(d) read literally: B / wall time of ONE act with the host synchronisation at its end -- the same
-    # launches, one torch.cuda.synchronize() after each (max over ranks like `elapsed`)
-    n_sync = min(steps, 50)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(n_sync):
-        step(warmup + steps + i)
+        return float(t.item())
+
+    def timed(sync_each):
+        """Exactly `steps` acts between two (barrier + synchronize) brackets; the job's time is the MAX over ranks of
+        the per-rank times.  HIP events bracket a SAMPLE of the launches (every 10th): an event pair costs ~6 us of
+        stream time, 5 % of the kernel, so bracketing every launch would slow the very loop that is being timed."""
         torch.cuda.synchronize()
-    synced = (time.perf_counter() - t1) / n_sync
-    if dist:
-        t = torch.tensor([synced], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        synced = float(t.item())
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        ev_every = 10 if steps >= 20 else 1
+        sampled = [i for i in range(steps) if i % ev_every == ev_every // 2]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i % ev_every == ev_every // 2:
+                evs[i][0].record()
+            step(warmup + i)
+            if i % ev_every == ev_every // 2:
+                evs[i][1].record()
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0  # THIS rank's time for exactly `steps` steps
+        if dist:
+            dist.barrier()  # closing bracket: no rank leaves the timed region's neighbourhood before all are done
+            torch.cuda.synchronize()
+        return reduce_max(dt), float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in sampled]))
+
+    # THE TIMED REGION (SURVEY.md 8(d): "B / wall_time(act), host sync at the end included"): every act is followed by
+    # the host synchronisation the reference's np.asarray / .item() imply -- the next act of an RL loop needs this
+    # act's actions.  The same launches enqueued back to back with one synchronisation at the end are reported beside
+    # it as `value_pipelined` (what a caller that keeps several acts in flight gets; rounds 1-3 reported that as `value`).
+    elapsed, kernel_ms = timed(sync_each=True)
+    pipelined, kernel_ms_pipelined = timed(sync_each=False)
     depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
     actions = search.action.cpu()
     assert int(actions.min()) >= 0 and int(actions.max()) < A
     search.close()
     return {"elapsed": elapsed, "kernel_ms": kernel_ms, "depth_total": depth_total, "weights": weights, "obs": obs,
-            "noise": noise, "synced_s_per_act": synced}
+            "noise": noise, "pipelined": pipelined, "kernel_ms_pipelined": kernel_ms_pipelined}
 
 
-def roofline(workload, B, kernel_ms, depth_total):
+def roofline(workload, B, kernel_ms, depth_total, kernel_ms_timed_region=None):
+    """`kernel_ms`: HIP events around sampled launches of the back-to-back loop (the stream is never empty there, so
+    the interval is the kernel's duration -- the figure rocprofv3's kernel trace reports); `kernel_ms_in_timed_region`:
+    the same events around launches of the synced timed region, where the interval also holds the host's enqueue
+    latency on an idle stream."""
     _, obs_dim, E, A, support, S = WORKLOADS[workload]
     abytes = algorithmic_bytes(depth_total, B, S, A, E, obs_dim)
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(workload),
+            "traffic_source": "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command, committed; "
+                              "NOT re-measured in this run",
             "kernel": "mz_act_fused_kernel", "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_in_timed_region": None if kernel_ms_timed_region is None else round(kernel_ms_timed_region, 4),
             "algorithmic_bytes_per_launch": int(abytes), "mean_selection_depth": round(depth_total / (B * S), 3)}
 
 
@@ -255,34 +262,72 @@ def recurrent_flops_per_root(A=18, F=21):
     return stem + 24 * conv3 + r_head + v_head + p_head
 
 
-def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
-    """BASELINE configs[3] on ONE GPU's shard (1024 roots / 8 GPUs = 128): Atari-shaped 84x84x4 frames, the reference's
-    ResNet nets (muax/nn.py:313-395; random init), A = 18, num_simulations = 200, through MuZero.act() with the search
-    loop captured in one hipGraph.  The dominant kernel is the recurrent_fn launch (mz_resnet_tower_kernel, fp32 MFMA);
-    it is timed here with HIP events over `tower_launches` back-to-back launches (replayed from a hipGraph, as inside
-    act()) on the stream act() uses, at the shapes the search calls it with; `roofline` prices it against the dense fp32 matrix peak."""
+class Ranks:
+    """What a sub-benchmark needs to know about the job: this rank, the world, and the two collectives bench.py uses
+    outside the data path (barrier, max over ranks).  world == 1 without a process group: both are no-ops."""
+
+    def __init__(self, rank=0, world=1, dist=None, backend="nccl", dev=None, placement=None):
+        self.rank, self.world, self.dist, self.backend, self.dev = rank, world, dist, backend, dev
+        self.placement = placement or []
+
+    def bracket(self):
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def max(self, x):
+        if not self.dist:
+            return x
+        t = torch.tensor([x], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, n, sync_each=False):
+        """n calls of fn between two (synchronize + barrier) brackets -> seconds per call, MAX over ranks."""
+        self.bracket()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        self.bracket()
+        return self.max(dt)
+
+    def describe(self):
+        return {"n_gpus": self.world, "ranks": self.placement,
+                "backend": (("rccl (torch 'nccl')" if self.backend == "nccl" else self.backend) if self.dist
+                            else "none (one rank)")}
+
+
+def config4_atari(rk, roots=128, S=200, acts=3, tower_launches=200, global_roots=1024):
+    """BASELINE configs[3]: Atari-shaped 84x84x4 frames, the reference's ResNet nets (muax/nn.py:313-395; random init),
+    A = 18, num_simulations = 200, "1024 roots sharded over 8 MI355X": every rank searches ITS 128-root shard of the
+    1024-root batch (global_batch = 1024, root_offset = 128 * rank: per-root PRNG streams are those of the whole batch;
+    no collective on the path), through MuZero.act() with the search loop captured in one hipGraph; time = MAX over
+    ranks, value = roots of all ranks / that.  The dominant kernel is the recurrent_fn launch (fp32 MFMA); rank 0
+    times it with HIP events over `tower_launches` back-to-back launches (replayed from a hipGraph, as inside act())
+    on the stream act() uses, at the shapes the search calls it with; `roofline` prices it against the dense fp32
+    matrix peak."""
     import muax_amd as mx
+    dev = rk.dev
     A, F, support = 18, 21, 10
     g = torch.Generator().manual_seed(0)
     mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, F, generator=g),
             mx.nn.ResNetDynamic(A, F, generator=g))
-    obs = torch.randint(0, 256, (roots, 84, 84, 4), generator=g).float().to(dev)  # (drawn before init(), as tools/bench_atari.py)
+    global_roots = max(global_roots, roots * rk.world)
+    go = torch.Generator().manual_seed(100 + rk.rank)
+    obs = torch.randint(0, 256, (roots, 84, 84, 4), generator=go).float().to(dev)
     m = mx.MuZero(*mods, capture_graph=True, device=dev)
     m.init(0, np.zeros((1, 84, 84, 4), np.float32))
-    kw = dict(obs_from_batch=True, num_simulations=S, device_outputs=True)
+    kw = dict(obs_from_batch=True, num_simulations=S, device_outputs=True, global_batch=global_roots,
+              root_offset=roots * rk.rank)
     for i in range(2):
         m.act(i, obs, **kw)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(acts):
-        m.act(10 + i, obs, **kw)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / acts
-    t0 = time.perf_counter()
-    for i in range(acts):
-        m.act(20 + i, obs, **kw)
-        torch.cuda.synchronize()
-    dt_sync = (time.perf_counter() - t0) / acts
+    dt = rk.timed(lambda i: m.act(10 + i, obs, **kw), acts)
+    dt_sync = rk.timed(lambda i: m.act(20 + i, obs, **kw), acts, sync_each=True)
     handle = list(m._policy._handles.values())[0]
     depth = float(handle.depth_sum.float().mean()) / S
     dy, pred = mods[2], mods[1]
@@ -305,7 +350,7 @@ def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
             dy.hip_recurrent(pred, s, a, support)
     graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+    rk.bracket()
     reps = max(1, tower_launches // per_graph)
     e0.record()
     for _ in range(reps):
@@ -313,60 +358,86 @@ def config4_atari(dev, roots=128, S=200, acts=3, tower_launches=200):
     e1.record()
     torch.cuda.synchronize()
     kernel_ms = e0.elapsed_time(e1) / (reps * per_graph)
+    rk.bracket()
     flops = recurrent_flops_per_root(A, F) * roots
     tf = flops / (kernel_ms * 1e-3) / 1e12
     pair = bool(dy.use_pair_tower) and bool(getattr(dy, "_pair_scratch", None))
-    return {"value": round(roots / dt, 1), "unit": "env-steps/s", "ms_per_act": round(dt * 1e3, 3),
-            "value_synced": round(roots / dt_sync, 1), "acts": acts,
-            "workload": f"atari shard: {roots} roots (1024 / 8 GPUs), obs 84x84x4, ResNet nets (embedding 6x6x64), A={A}, "
-                        f"support {support}, num_simulations={S}, MuZero policy, search loop in one hipGraph",
-            "mean_selection_depth": round(depth, 2), "dtype": "f32",
-            "recurrent_share_of_act": round(kernel_ms * S / (dt * 1e3), 3),
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "mz_resnet_tower_pair_kernel (2 workgroups per root)" if pair else "mz_resnet_tower_kernel",
-                         "kernel_ms": round(kernel_ms, 4), "launches_per_act": S,
-                         "algorithmic_flops_per_launch": int(flops)}}
+    out = {"value": round(roots * rk.world / dt_sync, 1), "unit": "env-steps/s", "ms_per_act": round(dt_sync * 1e3, 3),
+           "value_pipelined": round(roots * rk.world / dt, 1), "ms_per_act_pipelined": round(dt * 1e3, 3), "acts": acts,
+           "workload": f"atari: {roots} roots per GPU = rows [{roots}*rank, {roots}*(rank+1)) of a {global_roots}-root batch, "
+                       f"obs 84x84x4, ResNet nets (embedding 6x6x64), A={A}, support {support}, num_simulations={S}, "
+                       f"MuZero policy, search loop in one hipGraph; no collective on the path",
+           "roots_per_gpu": roots, "global_batch": global_roots,
+           "mean_selection_depth": round(depth, 2), "dtype": "f32",
+           "recurrent_share_of_act": round(kernel_ms * S / (dt * 1e3), 3),
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel": "mz_resnet_tower_pair_kernel (2 workgroups per root)" if pair else "mz_resnet_tower_kernel",
+                        "kernel_ms": round(kernel_ms, 4), "launches_per_act": S,
+                        "algorithmic_flops_per_launch": int(flops), "measured_on": "rank 0"}}
+    out.update(rk.describe())
+    return out
 
 
-def config5_gumbel_train(dev, B=4096, L=10, S=50, iters=50):
-    """BASELINE configs[4] on one GPU: Gumbel MuZero act() on 4096 roots (num_simulations = 50) and ONE k_steps = 10
-    unrolled training step (loss, 18 gradients, Adam) on 4096 trajectories -- default MLP trio, both single fused
-    launches; with N > 1 ranks the gradient mean is one flat RCCL all-reduce (muax_amd/sharding.py), not timed here."""
+def config5_gumbel_train(rk, B=4096, L=10, S=50, iters=50):
+    """BASELINE configs[4]: Gumbel MuZero act() on 4096 roots per GPU (num_simulations = 50) and ONE k_steps = 10
+    unrolled training step (loss, 18 gradients, Adam) on 4096 trajectories per GPU -- default MLP trio, both single
+    fused launches.  With N > 1 ranks update() averages the flat gradient vector with ONE all-reduce (RCCL over xGMI;
+    muax_amd/sharding.py, precedent muax/frameworks/acme/jax/muzero/learning.py:151) INSIDE the timed update();
+    `ms_allreduce` = update() with the mean minus update() without it (dp_mean=False), both MAX over ranks, and
+    `ms_allreduce_alone` = the collective on the same vector timed by itself with a synchronisation per call."""
     import muax_amd as mx
+    from muax_amd.sharding import allreduce_mean_flat
+    dev = rk.dev
     g = torch.Generator().manual_seed(0)
     net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
                           mx.nn.Dynamic(8, 2, 21, generator=g))
     m = mx.MuZero(net, policy="gumbel", device=dev)
     m.init(0, np.zeros((1, 4)))
-    obs = (torch.rand(B, 4, generator=g) * 2 - 1).to(dev)
-    rng = np.random.default_rng(0)
-    batch = mx.Transition(obs=torch.rand(B, L, 4, generator=g).to(dev), a=torch.randint(0, 2, (B, L), generator=g).to(dev),
-                          r=torch.rand(B, L, generator=g).to(dev), Rn=(torch.rand(B, L, generator=g) * 20).to(dev),
+    gr = torch.Generator().manual_seed(10 + rk.rank)  # every rank its own trajectories (and the same initial weights)
+    obs = (torch.rand(B, 4, generator=gr) * 2 - 1).to(dev)
+    rng = np.random.default_rng(rk.rank)
+    batch = mx.Transition(obs=torch.rand(B, L, 4, generator=gr).to(dev), a=torch.randint(0, 2, (B, L), generator=gr).to(dev),
+                          r=torch.rand(B, L, generator=gr).to(dev), Rn=(torch.rand(B, L, generator=gr) * 20).to(dev),
                           pi=torch.as_tensor(rng.dirichlet([1, 1], (B, L)).astype(np.float32)).to(dev))
+    akw = dict(obs_from_batch=True, num_simulations=S, device_outputs=True, global_batch=B * rk.world, root_offset=B * rk.rank)
 
     def timeit(fn, n, warm=5, sync_each=False):
-        for _ in range(warm):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-            if sync_each:
-                torch.cuda.synchronize()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+        for i in range(warm):
+            fn(i)
+        return rk.timed(fn, n, sync_each)
 
-    t_act = timeit(lambda: m.act(1, obs, obs_from_batch=True, num_simulations=S, device_outputs=True), iters)
-    t_act_sync = timeit(lambda: m.act(1, obs, obs_from_batch=True, num_simulations=S, device_outputs=True), iters,
-                        sync_each=True)
-    t_upd = timeit(lambda: m.update(batch), iters)
-    return {"act": {"value": round(B / t_act, 1), "unit": "env-steps/s", "ms_per_act": round(t_act * 1e3, 4),
-                    "value_synced": round(B / t_act_sync, 1)},
-            "update": {"value": round(B * L / t_upd, 1), "unit": "transitions/s", "ms_per_update": round(t_upd * 1e3, 4)},
-            "ms_per_iteration": round((t_act + t_upd) * 1e3, 4), "iters": iters, "dtype": "f32",
-            "workload": f"gumbel + train: {B} roots, Gumbel MuZero act() num_simulations={S} (max_num_considered_actions 16, "
-                        f"gumbel_scale 1) + update() on {B} trajectories x k_steps={L}, default MLP trio, Adam"}
+    t_act = timeit(lambda i: m.act(1, obs, **akw), iters)
+    t_act_sync = timeit(lambda i: m.act(1, obs, **akw), iters, sync_each=True)
+    t_upd = timeit(lambda i: m.update(batch), iters)  # every rank its own batch, ONE shared gradient mean per step
+    flat = m._fused_train.grads if m._fused_train is not None else None
+    same = None
+    if rk.dist:  # data-parallel training keeps the replicas bit-identical: checked after the timed steps
+        w = torch.cat([p.detach().reshape(-1) for mod in m.network for p in mod.parameters()])
+        w = w if rk.backend == "nccl" else w.cpu()
+        lo, hi = w.clone(), w.clone()
+        rk.dist.all_reduce(lo, op=rk.dist.ReduceOp.MIN)
+        rk.dist.all_reduce(hi, op=rk.dist.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+    t_ar = None
+    if rk.dist and flat is not None:
+        t_ar = timeit(lambda i: allreduce_mean_flat([flat], even_if_alone=True), iters, sync_each=True)
+    t_upd_local = timeit(lambda i: m.update(batch, dp_mean=False), iters)  # (last: the replicas drift apart here)
+    out = {"act": {"value": round(B * rk.world / t_act_sync, 1), "unit": "env-steps/s", "ms_per_act": round(t_act_sync * 1e3, 4),
+                   "value_pipelined": round(B * rk.world / t_act, 1), "ms_per_act_pipelined": round(t_act * 1e3, 4)},
+           "update": {"value": round(B * L * rk.world / t_upd, 1), "unit": "transitions/s",
+                      "ms_per_update": round(t_upd * 1e3, 4), "ms_per_update_without_allreduce": round(t_upd_local * 1e3, 4),
+                      "ms_allreduce": round((t_upd - t_upd_local) * 1e3, 4) if rk.dist else 0.0,
+                      "ms_allreduce_alone": None if t_ar is None else round(t_ar * 1e3, 4),
+                      "allreduce_bytes": None if flat is None else int(flat.numel() * 4),
+                      "allreduce_in_timed_update": bool(rk.dist),
+                      "weights_identical_on_all_ranks_after": same},
+           "ms_per_iteration": round((t_act_sync + t_upd) * 1e3, 4), "iters": iters, "dtype": "f32",
+           "workload": f"gumbel + train: {B} roots per GPU, Gumbel MuZero act() num_simulations={S} (max_num_considered_actions 16, "
+                       f"gumbel_scale 1) + update() on {B} trajectories per GPU x k_steps={L}, default MLP trio, Adam; "
+                       f"data-parallel gradient mean = one flat all-reduce per update"}
+    out.update(rk.describe())
+    return out
 
 
 def self_launch(args):
@@ -425,6 +496,9 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=30.0,
                     help="untimed launches before the warm-up steps until the GPU clocks have ramped (see fused_run)")
     ap.add_argument("--no-config45", action="store_true", help="skip the config4_atari / config5_gumbel_train sub-objects")
+    ap.add_argument("--cfg4-sims", type=int, default=200, help="num_simulations of the config-4 leg (200 = BASELINE's; dry runs lower it)")
+    ap.add_argument("--cfg4-acts", type=int, default=3)
+    ap.add_argument("--cfg5-iters", type=int, default=50)
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -458,8 +532,10 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        import datetime
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # a rank that dies inside a sub-benchmark must not hang the others for the default half hour
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5), **kw)
 
     B, obs_dim, E, A, support, S = WORKLOADS[args.workload]
     if args.roots:
@@ -475,14 +551,19 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, placement[0])
         placement = gathered
+    rk = Ranks(rank, world, dist, backend, dev, placement)
 
+    line = {}
     if rank == 0:
         line = {
             "metric": "batched act() env-steps/sec at num_simulations=50",
+            # roots / wall time of an act WITH the host synchronisation at its end (rounds 1-3 reported
+            # the pipelined rate here and this one as `value_synced`)
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "env-steps/s",
-            # the same launches with torch.cuda.synchronize() after EVERY act ("host sync at the end included")
-            "value_synced": round(B * world / run["synced_s_per_act"], 1),
+            # the same launches enqueued back to back, one synchronisation after the last
+            "value_pipelined": round(B * world * args.steps / run["pipelined"], 1),
+            "ms_per_step_pipelined": round(run["pipelined"] / args.steps * 1e3, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -491,41 +572,50 @@ def main():
                                    f"support {support}, num_simulations={S}, dirichlet 0.25/0.3, "
                                    f"tiebreak={'threefry' if not args.no_tiebreak else 'off'}, temperature 1",
                        "roots_per_gpu": B, "num_simulations": S, "parallelism": f"roots sharded x{world}, no collective",
+                       "timed_region": "steps x (one fused act() launch + torch.cuda.synchronize())",
                        "clock_settle_ms_before_warmup": args.settle_ms,
-                       "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if dist else "none (one rank)"),
+                       "backend": rk.describe()["backend"],
                        "launcher": os.environ.get("MUAX_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none"),
                        "ranks": placement},
-            "roofline": roofline(args.workload, B, kernel_ms, depth_total),
+            "roofline": roofline(args.workload, B, run["kernel_ms_pipelined"], depth_total, kernel_ms),
         }
-        def guarded(name, fn):
-            # a secondary measurement must never cost the headline line: its failure is reported in its own slot
-            try:
-                line[name] = fn()
-            except Exception as e:  # noqa: BLE001
-                import traceback
-                traceback.print_exc()
-                line[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-        if world == 1 and not args.no_extras:
-            # the reference's own entry point on the same workload, and BASELINE configs[2] (the other fused instance)
-            guarded("api", lambda: api_numbers(args.workload, B, weights, obs, dev))
-            if args.workload == "cartpole" and not args.roots:
-                def config3():
-                    B3 = WORKLOADS["lunarlander"][0]
-                    steps3 = max(20, args.steps // 4)
-                    r3 = fused_run("lunarlander", B3, 0, 1, dev, steps3, max(5, args.warmup // 2),
-                                   not args.no_tiebreak, settle_ms=args.settle_ms)
-                    return {"value": round(B3 * steps3 / r3["elapsed"], 1), "unit": "env-steps/s", "steps": steps3,
-                            "value_synced": round(B3 / r3["synced_s_per_act"], 1),
-                            "ms_per_step": round(r3["elapsed"] / steps3 * 1e3, 4),
-                            "workload": f"lunarlander: {B3} roots, obs 8, MLP embed 32, A=4, support 10, num_simulations=50",
-                            "roofline": roofline("lunarlander", B3, r3["kernel_ms"], r3["depth_total"])}
-                guarded("config3_lunarlander", config3)
-        if world == 1 and not args.no_extras and not args.no_config45 and args.workload == "cartpole" and not args.roots:
-            guarded("config4_atari", lambda: config4_atari(dev))
-            guarded("config5_gumbel_train", lambda: config5_gumbel_train(dev))
-        if world == 1 and not args.no_cpu_baseline:
-            guarded("cpu_baseline", lambda: cpu_baseline(weights, obs.numpy(), noise.numpy(), A, E, F, S, support))
+    def guarded(name, fn):
+        # a secondary measurement must never cost the headline line: its failure is reported in its own slot.  With
+        # N > 1 every rank runs fn (the legs time MAX over ranks through barriers); a rank that fails still joins the
+        # others' remaining collectives only by luck, so failures are all-or-nothing: the flag is agreed first
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            res = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            line[name] = res
+
+    extras = not args.no_extras and args.workload == "cartpole" and not args.roots
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the reference's own entry point on the same workload
+        guarded("api", lambda: api_numbers(args.workload, B, weights, obs, dev))
+    if extras and world == 1:
+        def config3():  # BASELINE configs[2] (the other fused instance)
+            B3 = WORKLOADS["lunarlander"][0]
+            steps3 = max(20, args.steps // 4)
+            r3 = fused_run("lunarlander", B3, 0, 1, dev, steps3, max(5, args.warmup // 2),
+                           not args.no_tiebreak, settle_ms=args.settle_ms)
+            return {"value": round(B3 * steps3 / r3["elapsed"], 1), "unit": "env-steps/s", "steps": steps3,
+                    "value_pipelined": round(B3 * steps3 / r3["pipelined"], 1),
+                    "ms_per_step": round(r3["elapsed"] / steps3 * 1e3, 4),
+                    "workload": f"lunarlander: {B3} roots, obs 8, MLP embed 32, A=4, support 10, num_simulations=50",
+                    "roofline": roofline("lunarlander", B3, r3["kernel_ms_pipelined"], r3["depth_total"], r3["kernel_ms"])}
+        guarded("config3_lunarlander", config3)
+    if extras and not args.no_config45:
+        # BASELINE configs[3] and [4] are multi-GPU configurations: every rank runs its shard / its replica
+        guarded("config4_atari", lambda: config4_atari(rk, S=args.cfg4_sims, acts=args.cfg4_acts))
+        guarded("config5_gumbel_train", lambda: config5_gumbel_train(rk, iters=args.cfg5_iters))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        guarded("cpu_baseline", lambda: cpu_baseline(weights, obs.numpy(), noise.numpy(), A, E, F, S, support))
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -5,7 +5,7 @@
 // biased variance).  Between the convolutions of the plugin nets' ROOT inference these chains were ~10 small
 // framework kernels each (mean, Welford variance, sub, rsqrt, mul, mul, add, add, relu ...), ~90 us per
 // convolution of 48 us at config 4's shapes; here they are two launches, both bandwidth-bound:
-//   1. moments: grid (chunks, samples, tensors); per-thread fp64 sum / sum of squares over 16-byte loads, wave
+//   1. moments: grid (samples, chunks, tensors); per-thread fp64 sum / sum of squares over 16-byte loads, wave
 //      shuffle + LDS reduction, one (sum, sumsq) pair per chunk;
 //   2. apply: every thread adds up its sample's few chunk pairs (fp64: the moments are exact to fp32 rounding,
 //      independent of the chunking), then streams 16-byte loads / stores with the reference's op order.
@@ -28,7 +28,7 @@ struct NormParams {
 constexpr int kNormThreads = 256;
 
 __global__ __launch_bounds__(kNormThreads) void ln_moments_kernel(NormParams p) {
-  const int k = blockIdx.x, b = blockIdx.y, t = blockIdx.z;
+  const int b = blockIdx.x, k = blockIdx.y, t = blockIdx.z;  // samples in grid x: no 65535 limit on the batch
   const float* src = (t == 0 ? p.x : p.x2) + (size_t)b * p.n;
   const int lo = k * p.chunk, hi = min(p.n, lo + p.chunk);
   double s = 0.0, q = 0.0;
@@ -70,12 +70,12 @@ __device__ __forceinline__ void ln_stats(const double* ws, int K, int n, float e
 
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(kNormThreads) void ln_apply_kernel(NormParams p) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.x;  // samples in grid x (any batch), the sample's slices in grid y
   float mean, rstd, mean2 = 0.0f, rstd2 = 0.0f;
   ln_stats(p.ws + (size_t)b * p.K * 2, p.K, p.n, p.eps, mean, rstd);
   if (p.x2) ln_stats(p.ws + ((size_t)p.B + b) * p.K * 2, p.K, p.n, p.eps, mean2, rstd2);
   const size_t base = (size_t)b * p.n;
-  for (int i = 4 * (int)(blockIdx.x * kNormThreads + threadIdx.x); i < p.n; i += 4 * kNormThreads * (int)gridDim.x) {
+  for (int i = 4 * (int)(blockIdx.y * kNormThreads + threadIdx.x); i < p.n; i += 4 * kNormThreads * (int)gridDim.y) {
     const int c = i % p.C;
     const float4 v = *reinterpret_cast<const float4*>(p.x + base + i);
     const float4 g = *reinterpret_cast<const float4*>(p.scale + c);

@@ -40,10 +40,11 @@ int mzs_layernorm_act(const mzs_layernorm_args* a, void* stream_) {
   p.K = mz::norm_chunks(a->n);
   p.chunk = ((a->n / 4 + p.K - 1) / p.K) * 4;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(mz::ln_moments_kernel, dim3(p.K, a->batch, a->x2 ? 2 : 1), dim3(mz::kNormThreads), 0, stream, p);
+  hipLaunchKernelGGL(mz::ln_moments_kernel, dim3(a->batch, p.K, a->x2 ? 2 : 1), dim3(mz::kNormThreads), 0, stream, p);
   const int per_block = 4 * mz::kNormThreads * 4;  // four 16-byte loads per thread
-  hipLaunchKernelGGL(mz::ln_apply_kernel, dim3((a->n + per_block - 1) / per_block, a->batch), dim3(mz::kNormThreads), 0,
-                     stream, p);
+  int slices = (a->n + per_block - 1) / per_block;
+  if (slices > 65535) slices = 65535;  // (grid y; the kernel strides over the sample)
+  hipLaunchKernelGGL(mz::ln_apply_kernel, dim3(a->batch, slices), dim3(mz::kNormThreads), 0, stream, p);
   MZS_HIPG(hipGetLastError());
   return MZS_OK;
 }

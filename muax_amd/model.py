@@ -63,7 +63,7 @@ class MuZero:
     def __init__(self, network=None, prediction_fn=None, dynamic_fn=None, policy_class=MuZeroPolicy,
                  policy: Optional[str] = None, optimizer=None, loss_fn=None, discount: float = 0.99,
                  support_size: int = 10, recurrent_pred_on: str = "child", device=None,
-                 representation_fn=None, capture_graph: bool = False):
+                 representation_fn=None, capture_graph: bool = False, root_graph_cache: int = 2):
         if isinstance(network, MZNetwork):
             self.network = network
         else:
@@ -90,6 +90,9 @@ class MuZero:
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         # plugin (non-default) nets: run the S x (select, recurrent_fn, expand_backup) loop as one hipGraph
         self.capture_graph = bool(capture_graph)
+        # captured root-inference graphs kept per weights version (one per observation shape; each pins its static
+        # input and a private memory pool: hundreds of MB for Atari-shaped batches -- INTEGRATION.md)
+        self.root_graph_cache = max(1, int(root_graph_cache))
         self._params = None
         self._opt_state_saved = None  # what init() / a checkpoint produced before an optimiser was bound
         self._loaded_opt_state = None
@@ -98,6 +101,7 @@ class MuZero:
         self._disc_const = None
         self._fused = {}
         self._root_graphs = {}
+        self._root_graph_lru = []
         self._weights_version = 0
 
     # ------------------------------------------------------------------ init / params
@@ -175,11 +179,13 @@ class MuZero:
             ent = self._root_graphs.get(key)
             if ent is None:
                 # drop graphs of stale weights; keep the other shapes of THIS version (a B = 1 test rollout next to
-                # a batched act() must not re-capture on every alternation), at most four of them
+                # a batched act() must not re-capture on every alternation), at most `root_graph_cache` of them;
+                # _root_graph_lru lists the keys least recently used first
                 for k in [k for k in self._root_graphs if k[3] != self._weights_version]:
                     del self._root_graphs[k]
-                while len(self._root_graphs) >= 4:
-                    del self._root_graphs[next(iter(self._root_graphs))]
+                self._root_graph_lru = [k for k in self._root_graph_lru if k in self._root_graphs]
+                while len(self._root_graphs) >= self.root_graph_cache:
+                    del self._root_graphs[self._root_graph_lru.pop(0)]
                 static_in = obs.clone()
                 cur = torch.cuda.current_stream(obs.device)
                 side = torch.cuda.Stream(device=obs.device)
@@ -192,8 +198,10 @@ class MuZero:
                 with torch.cuda.graph(g):
                     out = self._root_inference_eager(static_in)
                 ent = self._root_graphs[key] = (g, static_in, out)
+                self._root_graph_lru.append(key)
             else:
-                self._root_graphs[key] = self._root_graphs.pop(key)  # most recently used last
+                self._root_graph_lru.remove(key)
+                self._root_graph_lru.append(key)  # most recently used last
             ent[1].copy_(obs)
             ent[0].replay()
             return ent[2]
@@ -445,13 +453,15 @@ class MuZero:
         return action
 
     # ------------------------------------------------------------------ next tier
-    def update(self, batch, *args, backend: str = "auto", **kwargs):
+    def update(self, batch, *args, backend: str = "auto", dp_mean: bool = True, **kwargs):
         """muax/model.py:181-201: one gradient step on a batch of k-step trajectories; returns
         {'loss': float}.  With the default MLP trio and the default loss the loss and all gradients come from
         ONE fused forward+backward HIP kernel (mzs_mlp_loss_grad, muax_amd/csrc/mz_train.cuh) into a flat
         vector; the data-parallel gradient mean is then one all-reduce of that vector (RCCL on GPUs) and the
         optimiser (muax/optimizers.py mirror on torch.optim) consumes views of it.  Plugin nets or a custom
-        loss_fn take the torch autograd route (backend="torch" forces it; "hip" refuses to fall back)."""
+        loss_fn take the torch autograd route (backend="torch" forces it; "hip" refuses to fall back).
+        `dp_mean=False` skips the gradient mean over the ranks of an initialised process group (a rank-local step:
+        bench.py times update() with and without its collective)."""
         from . import loss as mz_loss
         from . import optimizers as mz_opt
         from .sharding import allreduce_mean_flat
@@ -479,7 +489,8 @@ class MuZero:
                 if self._fused_train is None:
                     self._fused_train = mz_loss.FusedLossGrad(self)
                 loss, flat = self._fused_train(batch, divide_by_length=kwargs.get("divide_by_length", False))
-                allreduce_mean_flat([flat])
+                if dp_mean:
+                    allreduce_mean_flat([flat])
                 for p, g in zip(self._fused_train.params, self._fused_train.views):
                     p.grad = g
             except ValueError as e:
@@ -490,7 +501,8 @@ class MuZero:
             loss_fn = self.loss_fn or mz_loss.default_loss_fn
             loss = loss_fn(self, batch, *args, **kwargs)
             loss.backward()
-            allreduce_mean_flat([p.grad for p in all_params()])
+            if dp_mean:
+                allreduce_mean_flat([p.grad for p in all_params()])
         self._optimizer.step()
         self._weights_version += 1
         return {"loss": float(loss.item())}

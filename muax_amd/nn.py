@@ -301,6 +301,9 @@ class HkLayerNorm(nn.Module):
             return False
         if torch.is_grad_enabled() and (x.requires_grad or (self.scale is not None and self.scale.requires_grad)):
             return False
+        for t in (self.scale, self.offset):  # the kernel reads raw pointers: same device, fp32, dense
+            if t is None or t.device != x.device or t.dtype != torch.float32 or not t.is_contiguous():
+                return False
         if sorted(a % x.dim() for a in self.axis) != list(range(1, x.dim())):
             return False
         n = x[0].numel()
@@ -312,7 +315,9 @@ def ln_act(x, ln: "HkLayerNorm", relu: bool = False, add_ln=None, residual=None)
     ResidualConvBlockV1 (muax/nn.py:118-148); `residual` its identity shortcut.  One fused HIP call
     (mzs_layernorm_act, muax_amd/csrc/mz_norm.cuh) in inference on the GPU, the torch expressions otherwise."""
     ln.materialize(x)
-    ok = ln.fused_ok(x) and (residual is None or (residual.is_cuda and residual.shape == x.shape))
+    ok = ln.fused_ok(x) and (residual is None or (
+        residual.device == x.device and residual.dtype == torch.float32 and residual.shape == x.shape
+        and not (torch.is_grad_enabled() and residual.requires_grad)))
     if add_ln is not None:
         add_ln[1].materialize(add_ln[0])
         ok = ok and add_ln[1].fused_ok(add_ln[0]) and add_ln[0].shape == x.shape
@@ -380,7 +385,13 @@ def avg_pool_same(x: torch.Tensor, window: int = 3, stride: int = 2) -> torch.Te
         # (a tensor made while a hipGraph is being captured belongs to the capture: it is not kept)
         ones = torch.ones(1, 1, x.shape[1], x.shape[2], dtype=x.dtype, device=x.device)
         cnt = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(ones, (wl, wr, ht, hb)), window, stride, divisor_override=1)
-        if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+        # not kept: a tensor made under a capture (it belongs to the capture) or under inference mode (an inference
+        # tensor cannot be saved for a later backward pass)
+        if not (x.is_cuda and torch.cuda.is_current_stream_capturing()) and not torch.is_inference_mode_enabled():
+            if len(_POOL_COUNTS) >= 64:
+                _POOL_COUNTS.clear()
+            if x.is_cuda:
+                torch.cuda.current_stream(x.device).synchronize()  # complete before any other stream may read it
             _POOL_COUNTS[key] = cnt
     return (s / cnt).permute(0, 2, 3, 1)
 

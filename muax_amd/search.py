@@ -383,6 +383,8 @@ class MuZeroSearch:
         """expand_backup(sim) and select(sim + 1) in ONE launch (mzs_expand_backup_select): returns the next
         simulation's (action, parent embedding) -- the same persistent buffers select() hands out -- or None after
         the last simulation."""
+        if self._parent_emb is None:
+            raise ValueError("root() first")
         B, A, E = self.batch, self.cfg.num_actions, self.cfg.embed_dim
         r = self._f32(reward, (B,), "reward")
         d = self._f32(discount, (B,), "discount")
@@ -390,8 +392,11 @@ class MuZeroSearch:
         v = self._f32(value, (B,), "value")
         ne = self._f32(torch.as_tensor(next_embedding, device=self.device).reshape(B, -1), (B, E),
                        "next_embedding")
-        if ne.data_ptr() == self._parent_emb.data_ptr():
-            ne = ne.clone()  # (an identity recurrent_fn: the launch's tail overwrites the buffer select() handed out)
+        pe = self._parent_emb
+        if ne.untyped_storage().data_ptr() == pe.untyped_storage().data_ptr():
+            # an identity (or slicing / offset-view) recurrent_fn: the launch's tail overwrites the buffer select()
+            # handed out while the expansion still reads `ne` -- any view of that storage is copied first
+            ne = ne.clone()
         _lib.check(self._L.mzs_expand_backup_select(self._h, sim, _ptr(r), _ptr(d), _ptr(pl), _ptr(v), _ptr(ne),
                                                     _ptr(self.action), _ptr(self._parent_emb), self._stream()),
                    self._h)

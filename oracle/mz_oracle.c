@@ -461,8 +461,10 @@ void mzo_tree_init(mzo_tree *t, const float *prior_logits, const float *value,
 /* mctx action_selection.muzero_action_selection with
  * qtransforms.qtransform_by_parent_and_siblings; noise[A] already scaled by
  * 1e-7 (or NULL). */
-int mzo_select_action(const mzo_tree *t, int b, int node, int depth,
-                      const mzo_search_cfg *cfg, const float *noise) {
+/* value_score[a], policy_score[a] of muzero_action_selection at `node` (the two terms mzo_select_action adds): exposed
+   so that tools/triage_capture.py can print the oracle's own arithmetic for a disputed decision. */
+void mzo_action_scores(const mzo_tree *t, int b, int node, const mzo_search_cfg *cfg,
+                       float *value_score, float *policy_score) {
   int A = t->A;
   int64_t n = (int64_t)b * t->N + node;
   const int32_t *vc = t->children_visits + n * A;
@@ -488,14 +490,22 @@ int mzo_select_action(const mzo_tree *t, int b, int node, int depth,
   }
   float span = hi - lo;
   span = span > 1e-8f ? span : 1e-8f;
+  for (int a = 0; a < A; ++a) {
+    float cbm = vc[a] > 0 ? q[a] : lo;
+    value_score[a] = (cbm - lo) / span;
+    policy_score[a] = (tn * prior[a]) / (float)(vc[a] + 1);
+  }
+}
 
+int mzo_select_action(const mzo_tree *t, int b, int node, int depth,
+                      const mzo_search_cfg *cfg, const float *noise) {
+  int A = t->A;
+  float value_score[256], policy_score[256];
+  mzo_action_scores(t, b, node, cfg, value_score, policy_score);
   int best = 0;
   float best_score = 0.0f;
   for (int a = 0; a < A; ++a) {
-    float cbm = vc[a] > 0 ? q[a] : lo;
-    float value_score = (cbm - lo) / span;
-    float policy_score = (tn * prior[a]) / (float)(vc[a] + 1);
-    float score = value_score + policy_score;
+    float score = value_score[a] + policy_score[a];
     if (noise) score = score + noise[a];
     if (depth == 0 && t->root_invalid_actions[(int64_t)b * A + a]) score = -INFINITY;
     if (a == 0 || score > best_score) { best = a; best_score = score; }
@@ -503,10 +513,12 @@ int mzo_select_action(const mzo_tree *t, int b, int node, int depth,
   return best;
 }
 
-/* mctx search.simulate for root b.  root_key = simulate_keys[b]. */
-void mzo_simulate(const mzo_tree *t, int b, const mzo_search_cfg *cfg,
-                  const uint32_t root_key[2], int32_t *parent_out, int32_t *action_out,
-                  int32_t *depth_out) {
+/* mctx search.simulate for root b.  root_key = simulate_keys[b].  `uniforms` ([D][A], may be NULL): the tie-break
+   uniforms of levels d < D INJECTED instead of drawn (a capture's rng_tiebreak[s][b]): the search pinned independently
+   of the threefry walk.  The key walk advances at every level either way; levels >= D draw from it. */
+void mzo_simulate_injected(const mzo_tree *t, int b, const mzo_search_cfg *cfg,
+                           const uint32_t root_key[2], const float *uniforms, int D,
+                           int32_t *parent_out, int32_t *action_out, int32_t *depth_out) {
   int A = t->A;
   int max_depth = cfg->max_depth > 0 ? cfg->max_depth : cfg->num_simulations;
   uint32_t key[2] = {0, 0};
@@ -521,8 +533,11 @@ void mzo_simulate(const mzo_tree *t, int b, const mzo_search_cfg *cfg,
       mzo_split(key, 2, 1, sel);
       key[0] = nk[0];
       key[1] = nk[1];
-      for (int a = 0; a < A; ++a)
-        noise_buf[a] = 1e-7f * mzo_uniform_from_bits(mzo_random_bits(sel, A, a));
+      for (int a = 0; a < A; ++a) {
+        float u = (uniforms && depth < D) ? uniforms[(int64_t)depth * A + a]
+                                          : mzo_uniform_from_bits(mzo_random_bits(sel, A, a));
+        noise_buf[a] = 1e-7f * u;
+      }
       noise = noise_buf;
     }
     action = mzo_select_action(t, b, node, depth, cfg, noise);
@@ -535,6 +550,12 @@ void mzo_simulate(const mzo_tree *t, int b, const mzo_search_cfg *cfg,
   *parent_out = parent;
   *action_out = action;
   if (depth_out) *depth_out = depth;
+}
+
+void mzo_simulate(const mzo_tree *t, int b, const mzo_search_cfg *cfg,
+                  const uint32_t root_key[2], int32_t *parent_out, int32_t *action_out,
+                  int32_t *depth_out) {
+  mzo_simulate_injected(t, b, cfg, root_key, NULL, 0, parent_out, action_out, depth_out);
 }
 
 /* mctx search.expand (+ update_tree_node) for root b. */
@@ -793,6 +814,21 @@ void mzo_step_select(const mzo_tree *t, const mzo_search_cfg *cfg, int sim,
     if (cfg->tiebreak) mzo_split(sim_key, cfg->global_batch, cfg->root_offset + b, rk);
     int32_t d;
     mzo_simulate(t, b, cfg, rk, parent_out + b, action_out + b, &d);
+    if (depth_out) depth_out[b] = d;
+  }
+}
+
+/* mzo_step_select with the tie-break uniforms of this simulation injected: uniforms [B][D][A] (may be NULL). */
+void mzo_step_select_injected(const mzo_tree *t, const mzo_search_cfg *cfg, int sim,
+                              const uint32_t sim_key[2], const float *uniforms, int D,
+                              int32_t *parent_out, int32_t *action_out, int32_t *depth_out) {
+  (void)sim;
+  for (int b = 0; b < t->B; ++b) {
+    uint32_t rk[2] = {0, 0};
+    if (cfg->tiebreak) mzo_split(sim_key, cfg->global_batch, cfg->root_offset + b, rk);
+    int32_t d;
+    mzo_simulate_injected(t, b, cfg, rk, uniforms ? uniforms + (int64_t)b * D * t->A : NULL, D,
+                          parent_out + b, action_out + b, &d);
     if (depth_out) depth_out[b] = d;
   }
 }

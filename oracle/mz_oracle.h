@@ -120,6 +120,14 @@ void mzo_root_prior(const float *prior_logits, int A, const float *dirichlet_noi
                     float dirichlet_fraction, const uint8_t *invalid, float *out_logits);
 void mzo_tree_init(mzo_tree *t, const float *prior_logits, const float *value,
                    const float *embedding, const uint8_t *invalid);
+void mzo_action_scores(const mzo_tree *t, int b, int node, const mzo_search_cfg *cfg,
+                       float *value_score, float *policy_score);
+void mzo_simulate_injected(const mzo_tree *t, int b, const mzo_search_cfg *cfg,
+                           const uint32_t root_key[2], const float *uniforms, int D,
+                           int32_t *parent_out, int32_t *action_out, int32_t *depth_out);
+void mzo_step_select_injected(const mzo_tree *t, const mzo_search_cfg *cfg, int sim,
+                              const uint32_t sim_key[2], const float *uniforms, int D,
+                              int32_t *parent_out, int32_t *action_out, int32_t *depth_out);
 int mzo_select_action(const mzo_tree *t, int b, int node, int depth,
                       const mzo_search_cfg *cfg, const float *noise);
 void mzo_simulate(const mzo_tree *t, int b, const mzo_search_cfg *cfg,

@@ -120,7 +120,7 @@ def lib():
                      "mzo_tree_init", "mzo_simulate", "mzo_expand", "mzo_backward",
                      "mzo_summary_sample", "mzo_step_select", "mzo_step_expand_backup",
                      "mzo_act_mlp", "mzo_qtransform", "mzo_considered_visits", "mzo_gumbel_step_select",
-                     "mzo_gumbel_finish"):
+                     "mzo_gumbel_finish", "mzo_action_scores", "mzo_step_select_injected"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -412,6 +412,28 @@ def step_select(tree: Tree, cfg: SearchCfg, sim, sim_key=None):
     lib().mzo_step_select(C.byref(t), C.byref(c), C.c_int(sim), _p(k, _u32p),
                           _p(parent, _i32p), _p(action, _i32p), _p(depth, _i32p))
     return parent, action, depth
+
+
+def step_select_injected(tree: Tree, cfg: SearchCfg, sim, sim_key, uniforms):
+    """step_select with this simulation's tie-break uniforms injected: `uniforms` [B, D, A] (a capture's
+    rng_tiebreak[sim]); levels >= D draw from the key walk as usual."""
+    B = tree.B
+    parent, action, depth = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    k = np.ascontiguousarray(sim_key if sim_key is not None else [0, 0], np.uint32)
+    u = np.ascontiguousarray(uniforms, np.float32)
+    assert u.shape[0] == B and u.shape[2] == tree.A
+    t, c = tree.c(), cfg.c(B)
+    lib().mzo_step_select_injected(C.byref(t), C.byref(c), C.c_int(sim), _p(k, _u32p), _p(u, _f32p), C.c_int(u.shape[1]),
+                                   _p(parent, _i32p), _p(action, _i32p), _p(depth, _i32p))
+    return parent, action, depth
+
+
+def action_scores(tree: Tree, cfg: SearchCfg, b, node):
+    """(value_score [A], policy_score [A]) of muzero_action_selection at `node` of root b, the oracle's arithmetic."""
+    vs, ps = np.zeros(tree.A, np.float32), np.zeros(tree.A, np.float32)
+    t, c = tree.c(), cfg.c(tree.B)
+    lib().mzo_action_scores(C.byref(t), C.c_int(b), C.c_int(node), C.byref(c), _p(vs, _f32p), _p(ps, _f32p))
+    return vs, ps
 
 
 def step_expand_backup(tree: Tree, sim, parent, action, reward, discount, prior_logits, value,

@@ -22,8 +22,9 @@ jax.random calls along mctx's key walk so that sampler and search can be checked
 
 Captured (SURVEY.md 8(c)): seeds {0, 1, 2} x {CartPole shapes A=2, E=8, obs 4 at num_simulations 1 / 10 / 50;
 LunarLander shapes A=4, E=32, obs 8 at 50}, B = 8; Gumbel MuZero on both shapes with both qtransforms (seed 0); one
-checkpoint written by the reference's own save (muax/model.py:203-212) with the flattened weights beside it; and, when
-gymnasium is importable, 20 CartPole-v1 steps of the fit loop's act() calls (muax/train.py:153-170).
+checkpoint written by the reference's own save (muax/model.py:203-212) with the flattened weights beside it; when
+gymnasium is importable, 20 CartPole-v1 steps of the fit loop's act() calls (muax/train.py:153-170); and one case of the
+convolutional ResNet nets (root inference + one recurrent_fn call on two Atari-shaped frames, parameters by manifest).
 Nothing of the reference's source is written anywhere: the outputs are arrays.
 """
 from __future__ import annotations
@@ -279,6 +280,52 @@ def capture_rollout(model, params, w, out_dir, pred_on="child", steps=20, S=10):
     print("wrote tests/golden/mctx_rollout_cartpole_s10.npz")
 
 
+def capture_resnet(ref, nn, policy_mod, out_dir, seed=0, B=2, A=18, F=21):
+    """One capture of the convolutional plugin nets (muax/nn.py:118-148,313-395): root inference on B Atari-shaped
+    frames and ONE recurrent_fn call, through the reference's own `_root_inference` / `_recurrent_inference`
+    (muax/model.py:251-282) plus the heads' raw logits.  The parameters are NOT haiku's draws: every array of the
+    parameter tree is overwritten, in the tree's own (call) order, with mctx_fixture.resnet_weights(manifest, seed), so
+    that the file holds a manifest + a seed instead of 5 MB of weights and the consumer regenerates the same arrays.
+    Pins the torch mirrors (muax_amd/nn.py ResNet*) and the one-launch HIP recurrent kernel (mz_conv.cuh): their
+    SAME-padding geometry, LayerNorm axes, average pooling and head order (VERDICT r3 weak #9)."""
+    import jax
+    import jax.numpy as jnp
+    if policy_mod is None:
+        print("pip release route: the ResNet nets are captured from a checkout only (--muax-path)")
+        return
+    repr_fn = nn._init_resnet_representation_func(nn.ResNetRepresentation, 32)
+    pred_fn = nn._init_resnet_prediction_func(nn.ResNetPrediction, A, F, 16)
+    dy_fn = nn._init_resnet_dynamic_func(nn.ResNetDynamic, A, F, 64)
+    model = ref.MuZero(nn.MZNetwork(repr_fn, pred_fn, dy_fn), policy_class=policy_mod.MuZeroPolicy, discount=0.99,
+                       support_size=SUPPORT)
+    rng = np.random.default_rng(2000 + seed)
+    obs = rng.integers(0, 256, (B, 84, 84, 4)).astype(np.uint8)
+    action = (np.arange(B) * 7 % A).astype(np.int32)
+    params = model.init(jax.random.PRNGKey(seed), jnp.asarray(obs, jnp.float32))
+    manifest = [(net, module, pname, list(np.shape(arr))) for net in ("representation", "prediction", "dynamic")
+                for module, sub in getattr(params, net).items() for pname, arr in sub.items()]
+    arrays = iter(fx.resnet_weights(manifest, seed))
+    new = {net: {module: {pname: jnp.asarray(next(arrays)) for pname in sub} for module, sub in getattr(params, net).items()}
+           for net in ("representation", "prediction", "dynamic")}
+    params = type(params)(new["representation"], new["prediction"], new["dynamic"])
+    key = jax.random.PRNGKey(0)
+    x = jnp.asarray(obs, jnp.float32)
+    root = model._root_inference(params, key, x)
+    v_lg, p_lg = model.pred_func.apply(params.prediction, root.embedding)
+    rec, ns = model._recurrent_inference(params, key, jnp.asarray(action), root.embedding)
+    r_lg, ns2 = model.dy_func.apply(params.dynamic, root.embedding, jnp.asarray(action))
+    v2, p2 = model.pred_func.apply(params.prediction, ns2)
+    assert np.allclose(np.asarray(ns), np.asarray(ns2)) and np.allclose(np.asarray(rec.prior_logits), np.asarray(p2))
+    meta = {"manifest": manifest, "weights_seed": seed, "A": A, "F": F, "support_size": SUPPORT, "input_channels": 32,
+            "dynamic_channels": 64, "versions": versions(), "route": "reference checkout, muax.nn ResNet* through muax.model.MuZero"}
+    path = os.path.join(out_dir, os.path.basename(fx.RESNET_PATH))
+    fx.save_resnet(path, meta, obs, action,
+                   {"embedding": root.embedding, "value_logits": v_lg, "prior_logits": root.prior_logits, "value": root.value},
+                   {"reward_logits": r_lg, "next_embedding": ns, "value_logits": v2, "prior_logits": rec.prior_logits,
+                    "reward": rec.reward, "value": rec.value})
+    print(f"wrote {os.path.relpath(path)}  ({os.path.getsize(path) / 1024:.0f} KB; {len(manifest)} parameter arrays by manifest)")
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--muax-path", default=os.environ.get("MUAX_PATH"),
@@ -307,6 +354,7 @@ def main():
     model, params, w, pred_on = first
     capture_checkpoint(model, w, args.out)
     capture_rollout(model, params, w, args.out, pred_on)
+    capture_resnet(ref, nn, policy_mod, args.out)
 
 
 if __name__ == "__main__":

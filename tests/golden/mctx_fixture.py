@@ -172,10 +172,13 @@ def compare_rng(case, got) -> list:
     return msgs
 
 
-def oracle_run(po, case, dirichlet_from="oracle") -> dict:
+def oracle_run(po, case, dirichlet_from="oracle", tiebreak_from="oracle", gumbel_from="oracle", override=None) -> dict:
     """The oracle's act() on the capture's inputs.  `dirichlet_from`: "oracle" draws the root noise with the oracle's
     restatement of jax.random.dirichlet (everything from the key, as a caller gets it); "capture" injects the
-    captured array (isolates the search from the sampler's float bits)."""
+    captured array (isolates the search from the sampler's float bits).  `tiebreak_from` / `gumbel_from` = "capture"
+    inject the captured per-level tie-break uniforms and the final / root Gumbel array the same way (step-wise driver:
+    PRNG and search pinned independently).  `override` {(simulation, root): (parent, action)} forces decisions (the
+    self-tests build a "reference" that decided differently somewhere)."""
     m, key = case["meta"], [int(x) for x in case["key"]]
     B, A, S, E = case["obs"].shape[0], m["A"], m["num_simulations"], m["E"]
     mlp = _mlp(po, case)
@@ -186,28 +189,53 @@ def oracle_run(po, case, dirichlet_from="oracle") -> dict:
             noise = po.dirichlet(po.split(key, 3)[1], m["dirichlet_alpha"], B, A)
         cfg = po.SearchCfg(S, max_depth=m.get("max_depth") or 0, pb_c_init=m["pb_c_init"], pb_c_base=m["pb_c_base"],
                            tiebreak=1)
-        out = po.act_mlp(mlp, cfg, case["obs"], key, noise, m["dirichlet_fraction"], None, m["temperature"])
-        return {"action": out["action"], "action_weights": out["action_weights"], "root_value": out["root_value"],
-                "tree": out["tree"].arrays()}
+        if tiebreak_from == "oracle" and gumbel_from == "oracle" and not override:
+            out = po.act_mlp(mlp, cfg, case["obs"], key, noise, m["dirichlet_fraction"], None, m["temperature"])
+            return {"action": out["action"], "action_weights": out["action_weights"], "root_value": out["root_value"],
+                    "tree": out["tree"].arrays()}
+        k_sample, _, sim_keys = po.sim_keys_from_act_key(key, S)
+        pl, v, emb = po.root_inference(mlp, case["obs"])
+        tree = po.Tree(B, S + 1, A, E)
+        po.tree_init(tree, po.root_prior(pl, noise, m["dirichlet_fraction"]), v, emb, None)
+        tb = case["rng"]["tiebreak"] if tiebreak_from == "capture" else None
+        for sim in range(S):
+            if tb is not None:
+                p_, a_, _ = po.step_select_injected(tree, cfg, sim, sim_keys[sim], tb[sim])
+            else:
+                p_, a_, _ = po.step_select(tree, cfg, sim, sim_keys[sim])
+            for (s_, b_), (fp, fa) in (override or {}).items():
+                if s_ == sim:
+                    p_[b_], a_[b_] = fp, fa
+            po.step_expand_backup(tree, sim, p_, a_, *po.recurrent_inference(mlp, a_, tree.embeddings[np.arange(B), p_]))
+        g = case["rng"]["final_gumbel"] if gumbel_from == "capture" else po.gumbel(k_sample, B * A).reshape(B, A)
+        action, weights = po.summary_sample(tree, m["temperature"], g)
+        return {"action": action, "action_weights": weights, "root_value": v, "tree": tree.arrays()}
     kind = 1 if m["qtransform"].endswith("mix_value") else 0
     pl, v, emb = po.root_inference(mlp, case["obs"])
-    g = po.gumbel(po.split(key, 2)[1], B * A).reshape(B, A) * np.float32(m.get("gumbel_scale", 1.0))
+    if gumbel_from == "capture":
+        g = case["rng"]["root_gumbel"]
+    else:
+        g = po.gumbel(po.split(key, 2)[1], B * A).reshape(B, A) * np.float32(m.get("gumbel_scale", 1.0))
     tree = po.Tree(B, S + 1, A, E)
     cfg = po.SearchCfg(S, max_depth=m.get("max_depth") or 0)
     po.tree_init(tree, po.mask_root_logits(pl, None), v, emb, None)
     for sim in range(S):
         p_, a_, _ = po.gumbel_step_select(tree, cfg, g, kind, m["max_num_considered_actions"])
+        for (s_, b_), (fp, fa) in (override or {}).items():
+            if s_ == sim:
+                p_[b_], a_[b_] = fp, fa
         po.step_expand_backup(tree, sim, p_, a_, *po.recurrent_inference(mlp, a_, tree.embeddings[np.arange(B), p_]))
     action, weights = po.gumbel_finish(tree, g, kind)
     return {"action": action, "action_weights": weights, "root_value": v, "tree": tree.arrays()}
 
 
-def synthetic_case(po, path, policy="muzero", seed=0, B=8, obs_dim=4, E=8, A=2, S=10, key=(0, 42), D=4):
+def synthetic_case(po, path, policy="muzero", seed=0, B=8, obs_dim=4, E=8, A=2, S=10, key=(0, 42), D=4, weights=None,
+                   override=None):
     """A file in the capture format whose 'reference' side is the oracle itself -- NOT a pin: it exists so that the
     reader, the comparers and the HIP-side harness are exercised (and shown to fail on a perturbed file) before any
     real capture exists.  Written to a temporary path by the tests, never into tests/golden."""
     support = 10
-    w = po.random_mlp_weights(seed, obs_dim, E, A, 2 * support + 1, bias_scale=0.1)
+    w = weights or po.random_mlp_weights(seed, obs_dim, E, A, 2 * support + 1, bias_scale=0.1)
     obs = np.random.default_rng(seed + 7).uniform(-1, 1, (B, obs_dim)).astype(np.float32)
     meta = {"policy": policy, "A": A, "E": E, "obs_dim": obs_dim, "num_simulations": S, "support_size": support,
             "discount": 0.99, "temperature": 1.0, "dirichlet_fraction": 0.25, "dirichlet_alpha": 0.3,
@@ -216,7 +244,7 @@ def synthetic_case(po, path, policy="muzero", seed=0, B=8, obs_dim=4, E=8, A=2, 
             "route": "synthetic (oracle output in the capture format; not a reference output)", "versions": {}}
     case = {"meta": meta, "w": w, "obs": obs, "key": np.array(key, np.uint32), "rng": {"tiebreak": np.zeros((S, B, D, A))}}
     rng = oracle_rng(po, case)
-    out = oracle_run(po, case)
+    out = oracle_run(po, case, override=override)  # `override`: a "reference" that decided differently somewhere
     save_case(path, meta, w, obs, key, out, out["tree"], rng)
     return path
 
@@ -258,4 +286,169 @@ def synthetic_rollout(po, path, steps=6, S=10, seed=0):
     data["meta"] = np.array(json.dumps({"num_simulations": S, "recurrent_pred_on": "child", "versions": {},
                                         "format_version": FORMAT_VERSION}))
     np.savez_compressed(path, **data)
+    return path
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the convolutional (ResNet) plugin nets: one capture of root inference + one recurrent_fn call
+# --------------------------------------------------------------------------------------------------------------
+RESNET_PATH = os.path.join(HERE, "mctx_resnet_nets_seed0.npz")
+
+
+def resnet_weights(manifest, seed):
+    """The parameters of a ResNet-net capture, regenerated from its manifest [(net, haiku module, param, shape), ...]
+    (the haiku parameter tree in CALL order): the capture script writes these very arrays INTO the haiku tree before
+    it runs the reference, so the file carries a manifest and a seed instead of megabytes of weights.  NumPy's
+    default_rng stream is stable across versions."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _net, _module, param, shape in manifest:
+        shape = tuple(int(x) for x in shape)
+        x = rng.standard_normal(shape).astype(np.float32)
+        if param == "w":
+            x = x / np.float32(np.sqrt(float(np.prod(shape[:-1]))))
+        elif param == "scale":
+            x = np.float32(1) + np.float32(0.1) * x
+        else:  # offsets and biases
+            x = np.float32(0.1) * x
+        out.append(np.ascontiguousarray(x, np.float32))
+    return out
+
+
+def resnet_param_slots(mods):
+    """The torch mirror's parameters (muax_amd/nn.py ResNet* modules, materialised by one forward pass) in the CALL
+    order of the reference's modules (muax/nn.py:118-148,313-378: projection before conv_0 in a block; v_func before
+    pi_func in ResNetPrediction.__call__; r_func before ns_func in ResNetDynamic.__call__) as [(label, param, tensor)]."""
+    rep, pred, dyn = mods
+
+    def conv(m, label):
+        return [(label, "w", m.w)]
+
+    def ln(m, label):
+        return [(label, "scale", m.scale), (label, "offset", m.offset)]
+
+    def block(b, label):
+        return (conv(b.proj_conv, label + ".proj_conv") + ln(b.proj_ln, label + ".proj_ln") + conv(b.conv_0, label + ".conv_0")
+                + ln(b.ln_0, label + ".ln_0") + conv(b.conv_1, label + ".conv_1") + ln(b.ln_1, label + ".ln_1"))
+
+    def head(seq, label):
+        out = []
+        for i, m in enumerate(seq):
+            if hasattr(m, "w") and getattr(m, "b", None) is not None:
+                out += [(f"{label}[{i}]", "w", m.w), (f"{label}[{i}]", "b", m.b)]
+            elif hasattr(m, "w"):
+                out += conv(m, f"{label}[{i}]")
+        return out
+
+    slots = {"representation": conv(rep.stem0, "stem0")}
+    for i, b in enumerate(rep.blocks0):
+        slots["representation"] += block(b, f"blocks0[{i}]")
+    slots["representation"] += conv(rep.stem1, "stem1")
+    for name in ("blocks1", "blocks2"):
+        for i, b in enumerate(getattr(rep, name)):
+            slots["representation"] += block(b, f"{name}[{i}]")
+    slots["prediction"] = head(pred.v_func, "v_func") + head(pred.pi_func, "pi_func")
+    slots["dynamic"] = head(dyn.r_func, "r_func") + conv(dyn.ns_stem, "ns_stem")
+    for i, b in enumerate(dyn.ns_blocks):
+        slots["dynamic"] += block(b, f"ns_blocks[{i}]")
+    return slots
+
+
+def resnet_assign(mods, manifest, seed):
+    """Write the capture's parameters into the torch mirror, slot by slot in call order; any disagreement in count,
+    parameter kind or shape is a loud error that prints both sides (the haiku naming is spec-to-confirm)."""
+    import torch
+    slots = resnet_param_slots(mods)
+    arrays = resnet_weights(manifest, seed)
+    by_net = {}
+    for (net, module, param, shape), arr in zip(manifest, arrays):
+        by_net.setdefault(net, []).append((module, param, tuple(shape), arr))
+    for net, want in by_net.items():
+        have = slots[net]
+        if len(want) != len(have) or any(w[1] != h[1] or w[2] != tuple(h[2].shape) for w, h in zip(want, have)):
+            lines = [f"  {w[0]}/{w[1]} {w[2]}   <->   {h[0]}.{h[1]} {tuple(h[2].shape)}" for w, h in zip(want, have)]
+            raise AssertionError(f"{net}: the reference's parameters in call order do not line up with the torch mirror's "
+                                 f"({len(want)} vs {len(have)}):\n" + "\n".join(lines))
+        with torch.no_grad():
+            for (_m, _p, _s, arr), (_l, _k, t) in zip(want, have):
+                t.copy_(torch.from_numpy(arr).to(t.device))
+
+
+def load_resnet(path=RESNET_PATH):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return {"meta": meta, "manifest": [tuple(x) for x in meta["manifest"]], "seed": meta["weights_seed"],
+            "obs": z["obs"], "action": z["action"],
+            "root": {k: z["root_" + k] for k in ("embedding", "value_logits", "prior_logits", "value")},
+            "rec": {k: z["rec_" + k] for k in ("reward_logits", "next_embedding", "value_logits", "prior_logits", "reward", "value")}}
+
+
+def save_resnet(path, meta, obs, action, root, rec):
+    data = {"meta": np.array(json.dumps(dict(meta, format_version=FORMAT_VERSION), sort_keys=True)),
+            "obs": np.asarray(obs, np.uint8), "action": np.asarray(action, np.int32)}
+    data.update({"root_" + k: np.asarray(v, np.float32) for k, v in root.items()})
+    data.update({"rec_" + k: np.asarray(v, np.float32) for k, v in rec.items()})
+    np.savez_compressed(path, **data)
+
+
+def resnet_mirror_outputs(mx, mods, case, support_size=10, device="cpu", hip=False):
+    """Root inference and ONE recurrent_fn call of the torch mirror on the capture's inputs (muax/model.py:251-282).
+    hip=True: the recurrent call through the one-launch HIP kernel (ResNetDynamic.hip_recurrent)."""
+    import torch
+    rep, pred, dyn = mods
+    obs = torch.as_tensor(case["obs"].astype(np.float32), device=device)
+    act = torch.as_tensor(case["action"], device=device)
+    dec = lambda lg: mx.utils.support_to_scalar(torch.softmax(lg, -1), support_size).flatten()  # noqa: E731
+    with torch.no_grad():
+        s = rep(obs)
+        v_lg, p_lg = pred(s)
+        root = {"embedding": s, "value_logits": v_lg, "prior_logits": p_lg, "value": dec(v_lg)}
+        if hip:
+            r, v, pl, ns = dyn.hip_recurrent(pred, s, act, support_size)
+            rec = {"next_embedding": ns, "prior_logits": pl, "reward": r, "value": v}
+        else:
+            r_lg, ns = dyn(s, act)
+            v2, p2 = pred(ns)
+            rec = {"reward_logits": r_lg, "next_embedding": ns, "value_logits": v2, "prior_logits": p2,
+                   "reward": dec(r_lg), "value": dec(v2)}
+    tonp = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}  # noqa: E731
+    return tonp(root), tonp(rec)
+
+
+def compare_resnet(case, root, rec, tol=2e-4):
+    """Floats through ~30 fp32 convolutions + LayerNorms: `tol` relative to the array's largest entry (the search's
+    1e-5 bar is for the MLP trio's logits; two fp32 convolution orders differ by more than that)."""
+    msgs = []
+    for name, want, got in [("root." + k, case["root"][k], v) for k, v in root.items()] + \
+                           [("rec." + k, case["rec"][k], v) for k, v in rec.items()]:
+        want = np.asarray(want).reshape(np.asarray(got).shape)
+        err = float(np.abs(want.astype(np.float64) - got.astype(np.float64)).max())
+        lim = tol * max(1.0, float(np.abs(want).max()))
+        if err > lim:
+            msgs.append(f"{name}: max error {err:.3g} beyond {lim:.3g}")
+    return msgs
+
+
+def synthetic_resnet(mx, path, seed=0, B=1, hw=32, A=6, F=21, c=8, dc=16, device="cpu"):
+    """A file in the ResNet capture's format whose 'reference' side is the torch mirror itself with haiku-style names
+    (NOT a pin: proves manifest -> weights -> assignment -> comparison work, on small frames)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    mods = (mx.nn.ResNetRepresentation(c, generator=g), mx.nn.ResNetPrediction(A, F, generator=g),
+            mx.nn.ResNetDynamic(A, F, output_channels=dc, generator=g))
+    obs = np.random.default_rng(seed).integers(0, 256, (B, hw, hw, 4)).astype(np.uint8)
+    act = (np.arange(B) % A).astype(np.int32)
+    with torch.no_grad():
+        s = mods[0](torch.as_tensor(obs.astype(np.float32)))
+        mods[1](s)
+        mods[2](s, torch.as_tensor(act))
+    for m in mods:
+        m.to(device)
+    manifest = [(net, label, param, list(t.shape)) for net, sl in resnet_param_slots(mods).items() for label, param, t in sl]
+    resnet_assign(mods, manifest, seed)
+    case = {"obs": obs, "action": act}
+    root, rec = resnet_mirror_outputs(mx, mods, case, device=device)
+    meta = {"manifest": manifest, "weights_seed": seed, "A": A, "F": F, "support_size": 10, "input_channels": c,
+            "dynamic_channels": dc, "route": "synthetic (torch mirror output in the capture format; not a reference output)"}
+    save_resnet(path, meta, obs, act, root, rec)
     return path

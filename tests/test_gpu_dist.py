@@ -103,8 +103,8 @@ def test_bench_launcher_contract_with_two_ranks_on_one_gpu():
     port = 29400 + os.getpid() % 500
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "10", "--warmup", "3"], env=env, cwd=ROOT, capture_output=True,
-                         text=True, timeout=600)
+                          "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-config45"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -117,11 +117,16 @@ def test_bench_launcher_contract_with_two_ranks_on_one_gpu():
 def test_bench_plain_invocation_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command): bench.py starts
     the two ranks itself; on this 1-GPU box both sit on device 0 (MUAX_BENCH_SINGLE_DEVICE) over gloo.  One JSON line,
-    n_gpus 2, the ranks' devices and the backend named in config."""
+    n_gpus 2, the ranks' devices and the backend named in config -- and the two multi-GPU configurations of BASELINE
+    as sub-objects measured by BOTH ranks: config 4 (each rank a 128-root shard of the 1024-root batch) and config 5
+    (the gradient all-reduce inside the timed update(), reported separately as ms_allreduce).  (The recurrent
+    kernel's pair mode wants a GPU to itself: two processes sharing the device keep one workgroup per root.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["MUAX_BENCH_SINGLE_DEVICE"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"],
-                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    env["MZS_TOWER_PAIR"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+                          "--cfg4-sims", "16", "--cfg4-acts", "1", "--cfg5-iters", "5"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -130,7 +135,18 @@ def test_bench_plain_invocation_launches_its_own_ranks():
     assert line["config"]["launcher"] == "self" and line["config"]["backend"] == "gloo"
     assert len(line["config"]["ranks"]) == 2 and all("cuda:0" in r for r in line["config"]["ranks"])
     assert abs(line["value"] - 2 * 4096 * 10 / (line["ms_per_step"] * 10e-3)) < 0.01 * line["value"]
-    assert line["value_synced"] > 0  # (two ranks share one GPU here: no ordering between the two rates)
+    assert line["value_pipelined"] > 0  # (two ranks share one GPU here: no ordering between the two rates)
+    assert "api" not in line and "cpu_baseline" not in line
+    c4 = line["config4_atari"]
+    assert "error" not in c4, c4
+    assert c4["n_gpus"] == 2 and c4["global_batch"] == 1024 and c4["roots_per_gpu"] == 128 and len(c4["ranks"]) == 2
+    assert c4["backend"] == "gloo" and c4["value"] > 0 and c4["roofline"]["bound"] == "mfma"
+    c5 = line["config5_gumbel_train"]
+    assert "error" not in c5, c5
+    u = c5["update"]
+    assert c5["n_gpus"] == 2 and u["allreduce_in_timed_update"] is True and u["weights_identical_on_all_ranks_after"] is True
+    assert u["ms_per_update"] > 0 and u["ms_per_update_without_allreduce"] > 0 and "ms_allreduce" in u
+    assert u["ms_allreduce_alone"] > 0 and u["allreduce_bytes"] == 4 * 1564  # the default trio's 18 arrays, one message
 
 
 def test_bench_refuses_more_gpus_than_the_box_has():
@@ -154,7 +170,7 @@ def test_bench_line_schema_at_one_gpu():
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "api", "value_synced",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "api", "value_pipelined",
                 "config3_lunarlander", "config4_atari", "config5_gumbel_train"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["vs_baseline"] is None and line["dtype"] == "f32"
@@ -169,7 +185,11 @@ def test_bench_line_schema_at_one_gpu():
     assert r4["bound"] == "mfma" and r4["peak"] == 157.3
     assert abs(r4["frac"] - r4["algorithmic_flops_per_launch"] / (r4["kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
     c5 = line["config5_gumbel_train"]
-    assert c5["act"]["ms_per_act"] > 0 and c5["update"]["ms_per_update"] > 0
+    assert c5["act"]["ms_per_act"] > 0 and c5["update"]["ms_per_update"] > 0 and c5["update"]["ms_allreduce"] == 0.0
+    assert line["config4_atari"]["n_gpus"] == 1 and c5["n_gpus"] == 1
+    # the headline is the synced act; the pipelined rate can only be higher, the kernel alone higher still
+    assert line["value_pipelined"] >= 0.98 * line["value"] and r["traffic_source"].startswith("profiles/pmc_traffic.json")
+    assert r["kernel_ms"] <= line["ms_per_step"]
 
 
 def _rccl_worker(q, port):
@@ -208,7 +228,12 @@ def test_bench_rccl_branch_with_one_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(MUAX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                          "--no-extras", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--cfg4-sims", "16", "--cfg4-acts", "1", "--cfg5-iters", "5"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["config"]["backend"].startswith("rccl") and line["value"] > 1e6
+    # the config-5 leg's collective ran through RCCL (one rank: the flat all-reduce timed by itself)
+    u = line["config5_gumbel_train"]["update"]
+    assert line["config5_gumbel_train"]["backend"].startswith("rccl") and u["ms_allreduce_alone"] > 0
+    assert line["config4_atari"]["backend"].startswith("rccl") and "error" not in line["config4_atari"]

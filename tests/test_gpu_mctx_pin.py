@@ -109,3 +109,40 @@ def test_harness_on_a_synthetic_file(oracle, tmp_path, policy, shape):
     bad["tree"]["parents"] = bad["tree"]["parents"].copy()
     bad["tree"]["parents"][0, 5] ^= 1
     assert fx.compare_outputs(case, bad)
+
+
+def _resnet_mods(mx, case, dev):
+    m = case["meta"]
+    g = torch.Generator().manual_seed(7)
+    mods = (mx.nn.ResNetRepresentation(m["input_channels"], generator=g), mx.nn.ResNetPrediction(m["A"], m["F"], generator=g),
+            mx.nn.ResNetDynamic(m["A"], m["F"], output_channels=m["dynamic_channels"], generator=g))
+    with torch.no_grad():  # materialise the lazily shaped layers on the host, then move
+        s = mods[0](torch.as_tensor(case["obs"][:1].astype(np.float32)))
+        mods[1](s), mods[2](s, torch.zeros(1, dtype=torch.long))
+    for mod in mods:
+        mod.to(dev)
+    fx.resnet_assign(mods, case["manifest"], case["seed"])
+    return mods
+
+
+def _check_resnet(mx, case):
+    mods = _resnet_mods(mx, case, "cuda")
+    msgs = []
+    for hip in (False, True):  # the torch mirrors (MIOpen convolutions), then the one-launch HIP recurrent kernel
+        root, rec = fx.resnet_mirror_outputs(mx, mods, case, device="cuda", hip=hip)
+        msgs += [("hip kernel: " if hip else "torch mirror: ") + m for m in fx.compare_resnet(case, root, rec)]
+    assert not msgs, "\n  ".join(msgs)
+
+
+def test_resnet_nets_against_the_reference_capture(tmp_path):
+    """The convolutional plugin nets (SAME geometry, LayerNorm axes, pooling, head order: muax/nn.py:118-148,313-395)
+    and the one-launch recurrent kernel (mz_conv.cuh) against the reference's own root inference and recurrent_fn
+    outputs on Atari-shaped frames.  Always on a synthetic file at the real shapes (the torch mirror's output: the
+    manifest route and the HIP kernel are exercised; not a pin); on the real capture when it exists."""
+    import muax_amd as mx
+    case = fx.load_resnet(fx.synthetic_resnet(mx, str(tmp_path / "resnet.npz"), B=2, hw=84, A=18, c=32, dc=64, device="cuda"))
+    assert case["root"]["embedding"].shape == (2, 6, 6, 64)
+    _check_resnet(mx, case)
+    if not os.path.exists(fx.RESNET_PATH):
+        pytest.skip(NO_CAPTURE + " (ResNet nets: mctx_resnet_nets_seed0.npz)")
+    _check_resnet(mx, fx.load_resnet())

@@ -29,6 +29,15 @@ def test_oracle_matches_the_reference_capture(oracle, path):
     case = fx.load_case(path)
     msgs = fx.compare_rng(case, fx.oracle_rng(oracle, case))          # the PRNG walk on its own
     msgs += fx.compare_outputs(case, fx.oracle_run(oracle, case, dirichlet_from="capture"))  # the search on its own
+    msgs += [m + "  [every PRNG array injected]" for m in fx.compare_outputs(case, fx.oracle_run(
+        oracle, case, dirichlet_from="capture", tiebreak_from="capture", gumbel_from="capture"))]
+    if msgs:  # say WHICH decision parted first and by what margin (near-tie flip or semantic): tools/triage_capture.py
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import triage_capture
+        rep = triage_capture.triage(oracle, case)
+        msgs.append("triage: " + rep["verdict"] + "".join(
+            f"\n    sim {d['simulation']} root {d['root']} level {d.get('level')} margin {d.get('margin')} [{d['kind']}]"
+            for d in rep["divergences"][:5]))
     msgs += [m + "  [everything from the key]" for m in
              fx.compare_outputs(case, fx.oracle_run(oracle, case, dirichlet_from="oracle"))]
     assert not msgs, f"{os.path.basename(path)} ({case['meta']['versions']}):\n  " + "\n  ".join(msgs)
@@ -91,6 +100,84 @@ def test_harness_on_a_synthetic_file(oracle, tmp_path, policy):
         rng["tiebreak"] = rng["tiebreak"].copy()
         rng["tiebreak"][2, 1, 0, 0] = np.nextafter(rng["tiebreak"][2, 1, 0, 0], np.float32(2))
         assert any("tiebreak" in m for m in fx.compare_rng(case, rng))
+
+
+def _tie_weights(po):
+    """A default trio whose prediction / reward heads are constants: every pUCT score ties and mctx's 1e-7 tie-break
+    noise alone decides -- margins <= 1e-7, the shape of a last-bit flip."""
+    w = po.random_mlp_weights(3, 4, 8, 2, 21, bias_scale=0.1)
+    for k in ("pv_w1", "pv_w2", "pp_w1", "pp_w2", "dr_w1", "dr_w2", "pv_b2", "pp_b2", "dr_b2"):
+        w[k] = np.zeros_like(w[k])
+    return w
+
+
+def _free_flip(case, own):
+    """(simulation, root, parent, other action) of a decision whose alternative is a complete decision too: both
+    children of the parent unvisited when it was taken (the first visit of a node)."""
+    par, act = case["tree"]["parents"], case["tree"]["action_from_parent"]
+    for s in range(2, par.shape[1] - 1):
+        for b in range(par.shape[0]):
+            p = int(par[b, s + 1])
+            if p > 0 and not any(int(par[b, n]) == p for n in range(1, s + 1)):  # no earlier child of p
+                return s, b, p, 1 - int(act[b, s + 1])
+    raise AssertionError("no such decision in this search")
+
+
+@pytest.mark.parametrize("kind", ["semantic", "near-tie flip"])
+def test_triage_separates_a_near_tie_flip_from_a_semantic_difference(oracle, tmp_path, kind):
+    """tools/triage_capture.py on synthetic captures: identical -> PINNED; a "reference" that took the other action at
+    ONE decision -> exactly that (simulation, root, node, level) is reported with the oracle's scores and margin, the
+    later simulations agree again under teacher forcing, and the margin decides flip vs semantic (VERDICT r3 #7)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import triage_capture as tc
+    w = _tie_weights(oracle) if kind == "near-tie flip" else None
+    base = fx.load_case(fx.synthetic_case(oracle, str(tmp_path / "base.npz"), S=12, D=12, weights=w))
+    rep = tc.triage(oracle, base)
+    assert rep["verdict"].startswith("PINNED") and rep["n_divergences"] == 0 and not rep["rng_mismatches"], rep
+    assert tc.triage(oracle, base, own_rng=True)["verdict"].startswith("PINNED")
+    s, b, p, other = _free_flip(base, oracle)
+    bent = fx.load_case(fx.synthetic_case(oracle, str(tmp_path / "bent.npz"), S=12, D=12, weights=w,
+                                          override={(s, b): (p, other)}))
+    assert (bent["tree"]["parents"][b, s + 1], bent["tree"]["action_from_parent"][b, s + 1]) == (p, other)
+    rep = tc.triage(oracle, bent)
+    assert rep["n_divergences"] >= 1 and not rep["forced_tree_mismatches"], rep
+    d = rep["divergences"][0]
+    assert (d["simulation"], d["root"], d["node"], d["action_reference"], d["action_oracle"]) == (s, b, p, other, 1 - other)
+    assert d["level"] == len(tc.reference_decisions(bent)[2][s][b]) - 1 and d["margin"] >= 0 and d["kind"] == kind, d
+    assert all(x["simulation"] > s or x["root"] != b for x in rep["divergences"][1:])
+    if kind == "near-tie flip":
+        assert d["margin"] <= 1.01e-7 and rep["verdict"].startswith("NEAR-TIE FLIPS ONLY"), rep["verdict"]
+    else:
+        assert d["margin"] > tc.FLIP_MARGIN and rep["verdict"].startswith("SEMANTIC"), rep["verdict"]
+    # every PRNG array injected: the step-wise runner reproduces the file it was made from
+    assert not fx.compare_outputs(base, fx.oracle_run(oracle, base, "capture", "capture", "capture"))
+    # a float beyond 1e-5 in the reference's root value is a root mismatch, whatever the decisions
+    bad = dict(base, root_value=base["root_value"] + np.float32(1e-3))
+    assert tc.triage(oracle, bad)["verdict"].startswith("SEMANTIC")
+
+
+def test_resnet_capture_harness_on_a_synthetic_file(tmp_path):
+    """Manifest -> regenerated weights -> assignment in call order -> comparison, on a file in the ResNet capture's
+    format made by the torch mirror itself (NOT a pin); a swapped pair of parameters and a perturbed output are caught."""
+    import muax_amd as mx
+    import torch
+    case = fx.load_resnet(fx.synthetic_resnet(mx, str(tmp_path / "resnet.npz")))
+    g = torch.Generator().manual_seed(99)  # other initial weights: everything must come from the manifest
+    mods = (mx.nn.ResNetRepresentation(8, generator=g), mx.nn.ResNetPrediction(6, 21, generator=g),
+            mx.nn.ResNetDynamic(6, 21, output_channels=16, generator=g))
+    with torch.no_grad():
+        s = mods[0](torch.as_tensor(case["obs"].astype(np.float32)))
+        mods[1](s), mods[2](s, torch.as_tensor(case["action"]))
+    fx.resnet_assign(mods, case["manifest"], case["seed"])
+    root, rec = fx.resnet_mirror_outputs(mx, mods, case)
+    assert not fx.compare_resnet(case, root, rec, tol=1e-6)
+    rec["next_embedding"] = rec["next_embedding"] + np.float32(1e-2)
+    assert any("next_embedding" in m for m in fx.compare_resnet(case, root, rec))
+    swapped = list(case["manifest"])
+    i = next(k for k, e in enumerate(swapped) if e[2] == "scale")
+    swapped[i], swapped[i - 1] = swapped[i - 1], swapped[i]  # a LayerNorm scale where a convolution weight belongs
+    with pytest.raises(AssertionError, match="do not line up"):
+        fx.resnet_assign(mods, swapped, case["seed"])
 
 
 def test_rollout_trace_harness_on_a_synthetic_file(oracle, tmp_path):

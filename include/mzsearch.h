@@ -341,6 +341,27 @@ int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
 /* bytes of pair_scratch for `batch` roots (0 if pair mode cannot run that batch) */
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * The simulation loop of a search with the ResNet nets in ONE launch (mz_search_conv.hip).
+ *
+ * Replaces, for simulations [sim_begin, sim_end) of a search on handle `h` (rooted with mzs_root / mzs_root_gumbel and
+ * with simulate() of `sim_begin` already run: mzs_select(h, sim_begin, ...), or the tail of a previous call), the loop
+ *     recurrent_fn (mzs_resnet_tower with heads)  ->  mzs_expand_backup_select                (2 launches per simulation)
+ * that mirrors mctx's search loop calling muax's recurrent_fn (muax/model.py:265-282 through muax/policy.py:13-30).
+ * Every root is advanced by its own workgroup(s) through all the simulations: the next state is written into the tree's
+ * embedding row of the new node, the next pass reads the parent's row in place, reward / value / prior logits stay on
+ * the CU.  Same device code as the step-wise entry points, same results bit for bit.
+ *
+ * `a`: the weights, `num_actions`, `support_size`, `blocks`, `normalize` (must be set), all 17 head arrays and the three
+ * per-root output arrays `reward` [B], `value` [B], `prior_logits` [B, A] (used as scratch; they hold the last
+ * simulation's values afterwards) of mzs_tower_args; `x`, `y`, `action` are ignored.  `pair_scratch` != NULL: two
+ * workgroups per root (batch <= 128), as for mzs_resnet_tower -- check the status words afterwards and repeat the
+ * search without it if any is set.  `discount`: the constant muax's recurrent_fn returns (muax/model.py:274).
+ * The handle's embed_dim must be 2304 (6 x 6 x 64) and its tree must use cached decisions (the default whenever
+ * batch * (num_simulations + 1)^2 words fit 1 GiB).  Errors: mzs_last_error(h). */
+int mzs_resnet_search(mzs_handle *h, const mzs_tower_args *a, float discount, int32_t sim_begin, int32_t sim_end,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

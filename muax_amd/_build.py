@@ -26,7 +26,8 @@ UNITS = {
     "mz_fused_g2.hip": _FUSED,
     "mz_fused_g3.hip": _FUSED,
     "mz_fused_g4.hip": _FUSED,
-    "mz_conv.hip": ["mz_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
+    "mz_conv.hip": ["mz_host.h", "mz_conv_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
+    "mz_search_conv.hip": ["mz_host.h", "mz_conv_host.h", "mz_conv.cuh", "mz_step.cuh", "mz_step_jump.cuh", "mz_spec.cuh", _ABI],
     "mz_norm.hip": ["mz_host.h", "mz_norm.cuh", _ABI],
     "mz_ez.hip": ["mz_host.h", "mz_ez.cuh", "mz_spec.cuh", _ABI],
 }

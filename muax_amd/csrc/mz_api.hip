@@ -132,6 +132,19 @@ void derive_keys(mzs_handle* h, const uint32_t key[2]) {
 
 }  // namespace
 
+namespace mzh {
+int fail_handle(mzs_handle* h, int code, const char* msg) { return fail(h, code, "%s", msg); }
+int step_view(mzs_handle* h, mz::StepArgs* sa, mz::JumpArgs* ja, int* policy, const char* who) {
+  if (!h) return MZS_E_INVALID;
+  if (!h->step.rooted) return fail(h, MZS_E_INVALID, "%s: call mzs_root first", who);
+  if (!h->use_jump) return fail(h, MZS_E_UNSUPPORTED, "%s: this handle's tree has no cached decisions (too large, or MZS_STEP_WALK=1)", who);
+  *sa = h->step.args(h->cfg);
+  *ja = h->jump;
+  *policy = h->cfg.policy;
+  return MZS_OK;
+}
+}  // namespace mzh
+
 static void mlp_offsets(int obs_dim, int E, int A, int F, int off[19]) {
   const int H = mz::kHidden, X = E + A;
   const int sizes[18] = {obs_dim * E, E, E * H, H, H * F, F, E * H, H, H * A, A, X * H, H, H * F, F, X * H, H, H * E, E};

@@ -76,6 +76,17 @@ struct TowerParams {
   unsigned* pair_u;    // [B][4]: flag of half 0, flag of half 1, launch epoch, status
 };
 
+// where ONE root's pass reads and writes (the step-wise launches index the batch arrays of TowerParams by the root;
+// the fused search, mz_search_conv.hip, points into the tree's own embedding rows)
+struct TowerIO {
+  const float* x;      // [36][64] hidden state
+  float* y;            // [36][64] next state
+  int action;
+  float* reward;       // [1]
+  float* value;        // [1]
+  float* prior_logits; // [A]
+};
+
 constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 68;  // 16-byte aligned pixels
 // one haloed map + an always-zero tail of 19 pixels: the rows that pad a 36-pixel map to three 16-row MFMA
 // tiles read their 3x3 windows from the tail
@@ -515,12 +526,12 @@ struct HeadLds {
   float *hv, *hv2, *hp, *part, *part2, *vec, *lgt;
 };
 // reward head on [s, a / num_actions] held in `in` (haloed map); `tmp` is a second haloed map
-MZ_DEV void reward_head(const TowerParams& p, int r, const float* in, float* tmp, const HeadLds& H,
+MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in, float* tmp, const HeadLds& H,
                         const int (&rowc)[3], int ch, int tid, int lane, int wave) {
   const int g4 = lane >> 4;
   f32x4 acc[3];
   conv1x1_tiles(in, rowc, p.r_c1, kTowerC, ch, 4, g4, acc);
-  const float pl = (float)p.action[r] * p.inv_num_actions * p.r_c1[kTowerC * kTowerC + ch];
+  const float pl = (float)io.action * p.inv_num_actions * p.r_c1[kTowerC * kTowerC + ch];
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -563,12 +574,12 @@ MZ_DEV void reward_head(const TowerParams& p, int r, const float* in, float* tmp
   __syncthreads();
   if (wave == 0) {
     const float rw = decode_support(H.lgt, p.F, p.support, lane);
-    if (lane == 0) p.reward[r] = rw;
+    if (lane == 0) *io.reward = rw;
   }
   __syncthreads();
 }
 // prediction heads on the normalised next state held in `cur` (haloed map)
-MZ_DEV void prediction_heads(const TowerParams& p, int r, const float* cur, const HeadLds& H, const int (&rowc)[3],
+MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const float* cur, const HeadLds& H, const int (&rowc)[3],
                              int tid, int lane, int wave) {
   const int g4 = lane >> 4, n16 = lane & 15;
   if (wave < 2) {  // wave 0: value head, wave 1: policy head -- first 1x1 conv (64 -> 16) + relu
@@ -632,23 +643,47 @@ MZ_DEV void prediction_heads(const TowerParams& p, int r, const float* cur, cons
     const int j = tid - 64;
     float a = 0.0f;
     for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[16 + k], p.p_l2[k * p.A + j], a);
-    p.prior_logits[(size_t)r * p.A + j] = a + p.p_b2[j];
+    io.prior_logits[j] = a + p.p_b2[j];
   }
   __syncthreads();
   if (wave == 0) {
     const float vl = decode_support(H.lgt, p.F, p.support, lane);
-    if (lane == 0) p.value[r] = vl;
+    if (lane == 0) *io.value = vl;
   }
 }
 
-MZ_DEV void load_state(const TowerParams& p, int r, float* buf, int tid) {
-  const float* xin = p.x + (size_t)r * kTowerPix * kTowerC;
+MZ_DEV void load_state(const float* xin, float* buf, int tid) {
   for (int i = tid; i < kTowerPix * kTowerC; i += 256) buf[map_word(i >> 6) + (i & 63)] = xin[i];
 }
 
-// One root (TSEL = 0) or one half of a root (TSEL = 1: pixels 0..15, TSEL = 2: pixels 16..35).
+MZ_DEV TowerIO tower_io(const TowerParams& p, int r) {
+  TowerIO io;
+  io.x = p.x + (size_t)r * kTowerPix * kTowerC;
+  io.y = p.y + (size_t)r * kTowerPix * kTowerC;
+  io.action = p.action ? p.action[r] : 0;
+  io.reward = p.reward ? p.reward + r : nullptr;
+  io.value = p.value ? p.value + r : nullptr;
+  io.prior_logits = p.prior_logits ? p.prior_logits + (size_t)r * p.A : nullptr;
+  return io;
+}
+// the link of one half of root r to its partner; message numbers continue from the root's epoch word
 template <int TSEL>
-MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
+MZ_DEV void pair_link_init(const TowerParams& p, int r, PairLink& L) {
+  constexpr int h = TSEL - 1;
+  float* base = p.pair_f + (size_t)r * 4 * kPairSlot;
+  unsigned* u = p.pair_u + (size_t)r * 4;
+  L.mine = base + h * 2 * kPairSlot;
+  L.theirs = base + (1 - h) * 2 * kPairSlot;
+  L.my_flag = u + h;
+  L.their_flag = u + (1 - h);
+  L.status = u + 3;
+  L.seq = u[2] * kPairMsgs;  // the launch epoch: written only at the very end of a launch, by half 0
+  L.xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg(6164);  // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+// One pass of recurrent_fn for one root (TSEL = 0) or one half of a root (TSEL = 1: pixels 0..15, TSEL = 2: pixels
+// 16..35; `L` = the half's link, initialised once per launch).
+template <int TSEL>
+MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, PairLink& L) {
   constexpr bool PAIR = TSEL != 0;
   using Geo = PairGeom<TSEL>;
   float* bufA = lds;
@@ -670,23 +705,9 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
 #endif
   for (int i = tid; i < 2 * kBufWords + kHeadWords; i += 256) lds[i] = 0.0f;
   __syncthreads();
-  load_state(p, r, bufA, tid);
+  load_state(io.x, bufA, tid);
   __syncthreads();
   MZ_TT(0)
-
-  PairLink L;
-  if constexpr (PAIR) {
-    constexpr int h = TSEL - 1;
-    float* base = p.pair_f + (size_t)r * 4 * kPairSlot;
-    unsigned* u = p.pair_u + (size_t)r * 4;
-    L.mine = base + h * 2 * kPairSlot;
-    L.theirs = base + (1 - h) * 2 * kPairSlot;
-    L.my_flag = u + h;
-    L.their_flag = u + (1 - h);
-    L.status = u + 3;
-    L.seq = u[2] * kPairMsgs;  // the launch epoch: written only at the very end of a launch, by half 0
-    L.xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg(6164);  // hwreg(HW_REG_XCC_ID, 0, 4)
-  }
 
   // A operand: lane (m = lane & 15, kk = lane >> 4) reads pixel 16 mt + m, input channel 4 c4 + kk
   int abase[3];
@@ -703,7 +724,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) rowc[mt] = abase[mt] + (kHalo + 1) * kPixStride;
   if constexpr (!PAIR)
-    if (p.heads) reward_head(p, r, bufA, bufB, H, rowc, ch, tid, lane, wave);
+    if (p.heads) reward_head(p, io, bufA, bufB, H, rowc, ch, tid, lane, wave);
   MZ_TT(1)
 
   float* cur = bufA;
@@ -726,7 +747,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         for (int mt = 0; mt < 3; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], b, acc[mt], 0, 0, 0);
       }
     }
-    const float plane = (float)p.action[r] * p.inv_num_actions * p.stem_w[kTowerC * kTowerC + ch];
+    const float plane = (float)io.action * p.inv_num_actions * p.stem_w[kTowerC * kTowerC + ch];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -898,7 +919,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[mt][v] = (acc[mt][v] - mn) / scale;
   }
-  float* yout = p.y + (size_t)r * kTowerPix * kTowerC;
+  float* yout = io.y;
   {
     const int g = lane >> 4;
 #pragma unroll
@@ -910,16 +931,13 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
       }
   }
   MZ_TT(10)
-  if constexpr (TSEL == 1) {
-    if (tid == 0) p.pair_u[(size_t)r * 4 + 2] += 1;  // next launch's epoch: half 1 read it before its first message
-  }
   if (p.heads) {
     if constexpr (TSEL == 2) {
       // half 1: the reward head, on the state reloaded into the (now free) buffers
       __syncthreads();
-      load_state(p, r, bufA, tid);
+      load_state(io.x, bufA, tid);
       __syncthreads();
-      reward_head(p, r, bufA, bufB, H, rowc, ch, tid, lane, wave);
+      reward_head(p, io, bufA, bufB, H, rowc, ch, tid, lane, wave);
     } else {
       // ---- prediction heads on the normalised next state ----
       store_map<TSEL>(acc, cur, ch, lane);
@@ -939,7 +957,7 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
         }
       }
       __syncthreads();
-      prediction_heads(p, r, cur, H, rowc, tid, lane, wave);
+      prediction_heads(p, io, cur, H, rowc, tid, lane, wave);
     }
   }
   MZ_TT(11)
@@ -951,9 +969,11 @@ MZ_DEV void tower_body(const TowerParams& p, const int r, float* lds) {
 #endif
 }
 
+#ifndef MZ_NO_TOWER_KERNELS
 __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  tower_body<0>(p, blockIdx.x, lds);
+  PairLink L;  // (unused: one workgroup per root)
+  tower_body<0>(p, tower_io(p, blockIdx.x), lds, L);
 }
 // two workgroups per root, 16 blocks = 8 roots x 2 halves laid out so that the halves of a root are 8
 // blocks apart: with the round-robin dispatch over the 8 XCDs they land on the same XCD and share its L2
@@ -961,8 +981,19 @@ __global__ __launch_bounds__(256) void mz_resnet_tower_pair_kernel(const TowerPa
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int r = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), h = (blockIdx.x >> 3) & 1;
   if (r >= p.B) return;
-  if (h == 0) tower_body<1>(p, r, lds);
-  else tower_body<2>(p, r, lds);
+  const TowerIO io = tower_io(p, r);
+  PairLink L;
+  if (h == 0) {
+    pair_link_init<1>(p, r, L);
+    tower_body<1>(p, io, lds, L);
+  } else {
+    pair_link_init<2>(p, r, L);
+    tower_body<2>(p, io, lds, L);
+  }
+  // next launch's epoch, by half 0 at its end: both halves read the word before their first message, and half 0 has
+  // received the last message of this launch by now
+  if (h == 0 && threadIdx.x == 0) p.pair_u[(size_t)r * 4 + 2] += 1;
 }
+#endif  // MZ_NO_TOWER_KERNELS
 
 }  // namespace mz

@@ -7,7 +7,16 @@
 
 #include "../../include/mzsearch.h"
 
+namespace mz {
+struct StepArgs;
+struct JumpArgs;
+}  // namespace mz
 namespace mzh {
+// internals of a handle for the translation units that launch their own kernels on its step-wise tree (defined in
+// mz_api.hip): MZS_OK and the kernel argument blocks of the rooted tree with cached decisions, or an error (message set
+// on the handle) when the handle has no such tree
+int step_view(mzs_handle* h, mz::StepArgs* sa, mz::JumpArgs* ja, int* policy, const char* who);
+int fail_handle(mzs_handle* h, int code, const char* msg);
 // message of the last failure of an entry point that has no handle (mzs_last_error(NULL)); defined in mz_api.hip
 extern thread_local std::string g_create_error;
 inline int fail_global(int code, const char* fmt, const char* a = "") {

@@ -1,0 +1,208 @@
+// mz_search_conv.hip -- the whole simulation loop of a search with the reference's ResNet nets as ONE launch.
+//
+// mctx runs, per simulation, simulate -> recurrent_fn -> expand -> backward over the whole batch (muax/policy.py:13-30 ->
+// mctx.muzero_policy; recurrent_fn = muax/model.py:265-282 on muax/nn.py:313-378).  The step-wise C-ABI mirrors that as
+// 2 launches per simulation (mzs_resnet_tower, mzs_expand_backup_select): 400 kernel boundaries per 200-simulation act,
+// every one of them paced by the slowest root (the tree kernel by the DEEPEST path of the batch), plus two 9 KB row
+// copies per root and simulation between the tree's embedding array and the kernels' staging buffers.  Roots never
+// interact, so none of that is needed: here the workgroup(s) that own a root run
+//
+//     for sim in [sim_begin, sim_end):   recurrent_fn(embeddings[parent], action) -> embeddings[new node]   (mz_conv.cuh)
+//                                        expand + backward + refresh of the cached decisions + simulate() of sim + 1
+//                                                                                                     (mz_step_jump.cuh)
+//
+// back to back: the next state is written straight into the tree's row of the new node, the next pass reads its input
+// from the parent's row, reward / value / prior logits never leave the CU, and a root with a short path does not wait
+// for one with a long path.  Same device functions as the step-wise kernels, same order of operations: same bits.
+//
+//   * one workgroup per root (any batch): no communication between workgroups at all;
+//   * pair mode (<= 128 roots, two workgroups per root splitting the pixels, mz_conv.cuh): the halves already meet in
+//     their XCD's L2 after every convolution pass; two more messages per simulation carry the reward (half 1 -> half 0,
+//     which owns the tree) and the next simulation's (parent, action, new node) (half 0 -> half 1).
+#include <hip/hip_runtime.h>
+
+#define MZ_NO_STEP_KERNELS   // device functions and types of the step-wise path only: its kernels live in mz_api.hip,
+#define MZ_NO_TOWER_KERNELS  // the recurrent kernel's in mz_conv.hip
+#include "mz_conv_host.h"
+#include "mz_step_jump.cuh"
+
+#pragma clang fp contract(off)
+
+namespace mz {
+
+struct SearchLoop {
+  int sim_begin, sim_end;
+  float discount;
+};
+
+// has this root's pair lost a rendezvous?  One thread looks, every thread gets the same answer (the word may be
+// written concurrently: a per-thread read could split the workgroup around its next barrier)
+MZ_DEV bool pair_lost_uniform(const PairLink& L, int tid, int* flag_lds) {
+  __syncthreads();
+  if (tid == 0) *flag_lds = (int)*reinterpret_cast<const volatile unsigned*>(L.status);
+  __syncthreads();
+  return *flag_lds != 0;
+}
+
+template <bool GUMBEL, bool PAIRED>
+__global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams p, const StepArgs s, const JumpArgs g,
+                                                               const SearchLoop loop) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* tree_lds = reinterpret_cast<int*>(lds + 2 * kBufWords + kHeadWords);
+  __shared__ int lost_flag;
+  const int tid = threadIdx.x;
+  int r, h = 0;
+  if constexpr (PAIRED) {  // 16 blocks = 8 roots x 2 halves, the halves of a root 8 blocks apart (same XCD)
+    r = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    h = (blockIdx.x >> 3) & 1;
+  } else {
+    r = blockIdx.x;
+  }
+  if (r >= p.B) return;
+  const int N = s.N, A = s.A, E = s.E;
+  const size_t rb = (size_t)r * N;
+  PairLink L;
+  if constexpr (PAIRED) {
+    if (h == 0) pair_link_init<1>(p, r, L);
+    else pair_link_init<2>(p, r, L);
+  }
+  // simulate() of sim_begin has run (mzs_select, or the tail of the previous launch): its decision is in the handle
+  int parent = s.sel_parent[r], action = s.sel_action[r];
+  int newn;
+  {
+    const int next = s.children_index[(rb + parent) * A + action];
+    newn = next == -1 ? loop.sim_begin + 1 : next;
+  }
+  TowerIO io;
+  io.reward = p.reward + r;
+  io.value = p.value + r;
+  io.prior_logits = p.prior_logits + (size_t)r * A;
+  for (int sim = loop.sim_begin; sim < loop.sim_end; ++sim) {
+    io.x = s.embeddings + (rb + parent) * E;
+    io.y = s.embeddings + (rb + newn) * E;
+    io.action = action;
+    const bool more = sim + 1 < loop.sim_end && sim + 1 < s.S;
+    int sel[2] = {0, 0};
+    if (!PAIRED || h == 0) {
+      float rew;
+      if constexpr (PAIRED) {
+        tower_body<1>(p, io, lds, L);  // ... ends with the prediction heads: value and prior logits of this root
+        L.seq += 1;                    // (half 0 posts nothing under this number)
+        const float* in = pair_wait(L, tid);  // message R of half 1: the reward
+        rew = pair_load(in);
+        if (pair_lost_uniform(L, tid, &lost_flag)) return;  // the host sees the status word and repeats the search
+      } else {
+        tower_body<0>(p, io, lds, L);
+        __syncthreads();
+        rew = *reinterpret_cast<const volatile float*>(io.reward);
+      }
+      __syncthreads();  // value / prior logits were written by other threads of this workgroup
+      const float val = *reinterpret_cast<const volatile float*>(io.value);
+      jump_expand_backup_body<GUMBEL>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
+                                      nullptr, sel);
+      if (more) {
+        parent = sel[0];
+        action = sel[1];
+        const int next = s.children_index[(rb + parent) * A + action];
+        newn = next == -1 ? sim + 2 : next;
+      }
+      if constexpr (PAIRED) {
+        if (more) {  // message T: what the next pass works on
+          float* msg = pair_out(L);
+          if (tid == 0) {
+            pair_store(msg, __int_as_float(parent));
+            pair_store(msg + 1, __int_as_float(action));
+            pair_store(msg + 2, __int_as_float(newn));
+            pair_store(msg + 4, __uint_as_float(L.xcc));
+          }
+          pair_post(L, tid);
+        } else {
+          L.seq += 1;
+        }
+      }
+      __syncthreads();
+    } else {
+      if constexpr (PAIRED) {
+        tower_body<2>(p, io, lds, L);  // ... ends with the reward head
+        float* msg = pair_out(L);      // message R
+        if (tid == 0) {
+          pair_store(msg, *reinterpret_cast<const volatile float*>(io.reward));
+          pair_store(msg + 4, __uint_as_float(L.xcc));
+        }
+        pair_post(L, tid);
+        L.seq += 1;  // (half 1 posts nothing under the number of message T)
+        if (more) {
+          const float* in = pair_wait(L, tid);
+          if (pair_lost_uniform(L, tid, &lost_flag)) return;
+          parent = min(max(__float_as_int(pair_load(in)), 0), N - 1);
+          action = min(max(__float_as_int(pair_load(in + 1)), 0), A - 1);
+          newn = min(max(__float_as_int(pair_load(in + 2)), 0), N - 1);
+        }
+      }
+    }
+  }
+  if constexpr (PAIRED) {
+    // the root's epoch advances by the simulations of this launch (each uses fewer than kPairMsgs message numbers);
+    // both halves read it before their first message and half 0 is past the last one it waits for
+    if (h == 0 && tid == 0) p.pair_u[(size_t)r * 4 + 2] += (unsigned)(loop.sim_end - loop.sim_begin);
+  }
+}
+
+}  // namespace mz
+
+extern "C" {
+
+int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, int32_t sim_begin, int32_t sim_end,
+                      void* stream_) {
+  if (!h) return MZS_E_INVALID;
+  mz::StepArgs sa;
+  mz::JumpArgs ja;
+  int policy = 0;
+  if (int rc = mzh::step_view(h, &sa, &ja, &policy, "mzs_resnet_search")) return rc;
+  mz::TowerParams p;
+  if (int rc = tower_params_from_args(a, p, true)) return mzh::fail_handle(h, rc, mzs_last_error(nullptr));
+  if (!p.heads) return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: needs the heads (the whole recurrent_fn)");
+  if (a->batch != sa.B || a->num_actions != sa.A || sa.E != mz::kTowerPix * mz::kTowerC)
+    return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: batch / num_actions / embedding (6x6x64) do not match the handle");
+  if (sim_begin < 0 || sim_end > sa.S || sim_begin >= sim_end)
+    return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: simulation range");
+  if (2 * a->blocks + 3 > mz::kPairMsgs)
+    return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: too many blocks");
+  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 15 * ((size_t)sa.S + 2);
+  if (lds > 160 * 1024) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: num_simulations too large for the LDS of a CU");
+  const mz::SearchLoop loop = {sim_begin, sim_end, discount};
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool gumbel = policy == 1;
+  const void* fn;
+  dim3 grid;
+  if (a->pair_scratch) {
+    const int64_t need = mzs_tower_pair_scratch_bytes(a->batch);
+    if (need == 0) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: pair mode needs batch <= 128");
+    if (a->pair_scratch_bytes < need) return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: pair_scratch too small");
+    p.pair_f = static_cast<float*>(a->pair_scratch);
+    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot);
+    fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, true>)
+                : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true>);
+    grid = dim3(16 * ((a->batch + 7) / 8));
+  } else {
+    fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, false>)
+                : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false>);
+    grid = dim3(a->batch);
+  }
+  {
+    // raise the kernel's dynamic-LDS limit once per (instance, device) and size
+    static size_t granted[4][64] = {};
+    size_t& have = granted[(gumbel ? 2 : 0) + (a->pair_scratch ? 1 : 0)][a->device & 63];
+    if (lds > have) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return mzh::fail_handle(h, MZS_E_RUNTIME, "mzs_resnet_search: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+      have = lds;
+    }
+  }
+  void* args[] = {&p, &sa, &ja, const_cast<mz::SearchLoop*>(&loop)};
+  if (hipLaunchKernel(fn, grid, dim3(256), args, lds, stream) != hipSuccess || hipGetLastError() != hipSuccess)
+    return mzh::fail_handle(h, MZS_E_RUNTIME, "mzs_resnet_search: launch failed");
+  return MZS_OK;
+}
+
+}  // extern "C"

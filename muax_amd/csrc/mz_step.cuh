@@ -137,6 +137,7 @@ MZ_DEV void row_softmax_rt(const float (&x)[kMaxAS], int A, int j, float (&p)[kM
   const size_t rb = (size_t)r * N;
 
 // mctx instantiate_tree_from_root + muzero_policy prelude (dirichlet, mask)
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float* prior_logits,
                                                          const float* value, const float* embedding,
                                                          const uint8_t* invalid, const float* noise,
@@ -238,8 +239,10 @@ __global__ __launch_bounds__(256) void step_root_kernel(StepArgs s, const float*
     s.depth_sum[r] = 0;
   }
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 // mctx search.simulate (+ the parent-embedding gather of search.expand)
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void step_select_kernel(StepArgs s, int sim, int32_t* action_out,
                                                            float* parent_embedding_out) {
   MZ_ROW_SETUP
@@ -367,8 +370,10 @@ __global__ __launch_bounds__(256) void step_select_kernel(StepArgs s, int sim, i
     for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
   }
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 // mctx search.expand (update_tree_node + edge) and search.backward
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void step_expand_backup_kernel(StepArgs s, int sim, const float* reward,
                                                                   const float* discount,
                                                                   const float* prior_logits,
@@ -429,8 +434,10 @@ __global__ __launch_bounds__(256) void step_expand_backup_kernel(StepArgs s, int
     }
   }
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 // mctx Tree.summary + _apply_temperature + jax.random.categorical
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void step_finish_kernel(StepArgs s, float temperature, const float* gumbel,
                                                            uint32_t ks0, uint32_t ks1, int32_t* action_out,
                                                            float* action_weights_out, float* search_value_out,
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(256) void step_finish_kernel(StepArgs s, float temp
     if (depth_sum_out) depth_sum_out[r] = s.depth_sum[r];
   }
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 // canonical 16-wide sum of a row-distributed vector with run-time length
 MZ_DEV float row_sum_rt(const float (&x)[kMaxAS], int A, int j) {
@@ -592,6 +600,7 @@ MZ_DEV int row_gumbel_argmax(const StepArgs& s, int r, int A, int j, int conside
 }
 
 // mctx search.simulate with gumbel_muzero_{root,interior}_action_selection
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void step_select_gumbel_kernel(StepArgs s, int sim, int32_t* action_out,
                                                                   float* parent_embedding_out) {
   MZ_ROW_SETUP
@@ -654,8 +663,10 @@ __global__ __launch_bounds__(256) void step_select_gumbel_kernel(StepArgs s, int
     for (int i = j; i < E; i += 16) parent_embedding_out[(size_t)r * E + i] = src[i];
   }
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 // tail of mctx gumbel_muzero_policy: best considered action + completed-Q policy target
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void step_finish_gumbel_kernel(StepArgs s, int32_t* action_out,
                                                                   float* action_weights_out,
                                                                   float* search_value_out, int32_t* depth_sum_out) {
@@ -696,12 +707,14 @@ __global__ __launch_bounds__(256) void step_finish_gumbel_kernel(StepArgs s, int
     if (depth_sum_out) depth_sum_out[r] = s.depth_sum[r];
   }
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 #undef MZ_ROW_SETUP
 
 // ---- wide embedding rows: one workgroup per (root, KiB of the row) ----
 // dir 0: rows[b] <- tree.embeddings[b][xfer_node[b]]   (parent embedding for recurrent_fn)
 // dir 1: tree.embeddings[b][xfer_node[b]] <- rows[b]   (root / next embedding)
+#ifndef MZ_NO_STEP_KERNELS
 __global__ __launch_bounds__(256) void emb_xfer_kernel(const StepArgs s, float* rows, int dir) {
   const int b = blockIdx.x;
   const size_t E = (size_t)s.E;
@@ -713,5 +726,6 @@ __global__ __launch_bounds__(256) void emb_xfer_kernel(const StepArgs s, float* 
   else
     for (size_t i = i0 + threadIdx.x; i < i1; i += 256) node[i] = row[i];
 }
+#endif  // MZ_NO_STEP_KERNELS
 
 }  // namespace mz

@@ -202,19 +202,17 @@ __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) 
 // mctx search.simulate through the JUMP records, for root r.  WG: the calling workgroup belongs to this root alone
 // -- every row repeats the (O(1)) selection, so every thread knows the parent and the whole workgroup gathers its
 // embedding row (a separate transfer kernel costs its own 4.7 us minimum); otherwise one 16-lane row per root.
-template <bool WG>
-MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int32_t* action_out,
-                             float* parent_embedding_out) {
+// jump_select_core: the decision alone -- every 16-lane row that calls it gets the same (parent, action, depth).
+MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int r, int& parent, int& action, int& depth) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
-  const int N = s.N, A = s.A, E = s.E;
+  const int N = s.N, A = s.A;
   const size_t rb = (size_t)r * N;
   const uint64_t rg = s.root_offset + (uint64_t)r;
   const int NB = (A + 1) / 2;
   uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 0;
   int klevel = -1;  // key walk not started
   int jw = g.jump_pa[rb], level = g.jump_lv[rb];
-  int parent, action;
   for (;;) {
     parent = jw & 0xffff;
     action = (jw >> 16) & 0xff;
@@ -267,7 +265,7 @@ MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int 
     }
     break;
   }
-  int depth = level + 1;
+  depth = level + 1;
   if (depth > s.max_depth) {
     // the cached descent overshoots max_depth: stop at level max_depth - 1 of the same path
     depth = s.max_depth;
@@ -275,14 +273,26 @@ MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int 
     parent = (int)(ent & 0xffffu);
     action = (int)(ent >> 16);
   }
+}
+// `parent_embedding_out` == nullptr: no gather (the caller reads the tree's embedding row in place)
+template <bool WG>
+MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int32_t* action_out,
+                             float* parent_embedding_out, int* sel_out = nullptr) {
+  const int j = threadIdx.x & 15;
+  const int N = s.N, E = s.E;
+  const size_t rb = (size_t)r * N;
+  int parent, action, depth;
+  jump_select_core(s, g, sim, r, parent, action, depth);
+  if (sel_out) { sel_out[0] = parent; sel_out[1] = action; }
   if (WG ? threadIdx.x == 0 : j == 0) {
     s.sel_parent[r] = parent;
     s.sel_action[r] = action;
     s.sel_depth[r] = depth;
     s.depth_sum[r] += depth;
-    action_out[r] = action;
+    if (action_out) action_out[r] = action;
     if (WG) s.xfer_node[r] = parent;
   }
+  if (parent_embedding_out == nullptr) return;
   const float* src = s.embeddings + (rb + parent) * E;
   if (WG) {
     for (int i = threadIdx.x; i < E; i += blockDim.x) parent_embedding_out[(size_t)r * E + i] = src[i];
@@ -304,14 +314,16 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
 // `next_action_out` != null: the NEXT simulation's selection (simulate() of sim + 1: the root's fresh JUMP record is
 // in this workgroup's hands) and the gather of its parent's embedding row run as the tail of this launch -- one launch
 // and one kernel boundary fewer per simulation (mzs_expand_backup_select).
+// The body is a device function of the calling workgroup (any multiple of 64 threads): the step-wise kernel below runs
+// it on a workgroup of its own, the fused ResNet search (mz_search_conv.hip) as the tail of the recurrent_fn pass of
+// the same root.  `prior_logits_row`: the root's A logits; `next_embedding_row` == nullptr: the caller has written the
+// new node's embedding row in place; `select_next`: also run simulate() of sim + 1 (sel_out[0..1] = its parent / action
+// in every thread; `next_parent_embedding_out` == nullptr: no gather).
 template <bool GUMBEL>
-__global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
-                                                                  const float* discount, const float* prior_logits,
-                                                                  const float* value, const float* next_embedding,
-                                                                  int32_t* next_action_out,
-                                                                  float* next_parent_embedding_out) {
-  extern __shared__ int lds_i[];
-  const int r = blockIdx.x;
+MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int* lds_i, float rew_new,
+                                    float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
+                                    bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
+                                    int* sel_out = nullptr) {
   const int tid = threadIdx.x, j = tid & 15, row = tid >> 4;
   const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 1024 / 256 threads (64 / 16 levels in flight) or one wavefront (4)
   const int N = s.N, A = s.A, E = s.E;
@@ -322,7 +334,6 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
   __syncthreads();  // every thread has read the edge before row 0 rewrites it
   const bool fresh = next == -1;
   const int newn = fresh ? sim + 1 : next;
-  const float v = value[r], rew_new = reward[r], dis_new = discount[r];
   // LDS: per level e in [0, depth] (entry `depth` is the leaf)
   const int D1 = N + 1;
   int* pn = lds_i;                 // node at level e
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
 #pragma unroll
     for (int t = 0; t < kMaxAS; ++t) {
       const int a = j + 16 * t;
-      x[t] = a < A ? prior_logits[(size_t)r * A + a] : 0.0f;
+      x[t] = a < A ? prior_logits_row[a] : 0.0f;
     }
     row_softmax_rt(x, A, j, pr);
 #pragma unroll
@@ -385,7 +396,8 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
     }
   }
   // (a whole workgroup per root: wide rows need no separate transfer kernel here)
-  for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding[(size_t)r * E + i];
+  if (next_embedding_row != nullptr)
+    for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding_row[i];
   __syncthreads();
   // -- per-level inputs of the backward pass --
   for (int e = tid; e < depth; e += nthr) {
@@ -508,10 +520,22 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
       g.jump_lv[rb + pn[e]] = njl[from];
     }
   }
-  if (next_action_out != nullptr && sim + 1 < s.S) {
+  if (select_next && sim + 1 < s.S) {
     __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
-    jump_select_body<true>(s, g, sim + 1, r, next_action_out, next_parent_embedding_out);
+    jump_select_body<true>(s, g, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out);
   }
+}
+template <bool GUMBEL>
+__global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,
+                                                                  const float* discount, const float* prior_logits,
+                                                                  const float* value, const float* next_embedding,
+                                                                  int32_t* next_action_out,
+                                                                  float* next_parent_embedding_out) {
+  extern __shared__ int lds_i[];
+  const int r = blockIdx.x;
+  jump_expand_backup_body<GUMBEL>(s, g, sim, r, lds_i, reward[r], discount[r], prior_logits + (size_t)r * s.A, value[r],
+                                  next_embedding + (size_t)r * s.E, next_action_out != nullptr, next_action_out,
+                                  next_parent_embedding_out);
 }
 
 #undef MZ_JROW_SETUP

@@ -231,6 +231,16 @@ class MuZero:
             discount = torch.ones_like(r) * self._discount
         return (r, discount, logits, v), next_embedding
 
+    def _native_loop(self, root):
+        """The one-launch simulation loop, when the nets are ones the library evaluates itself (the reference's ResNet
+        nets with the prediction net on the child's embedding): a callable for MuZeroSearch.search, else None."""
+        dy = self.dy_func
+        if self._recurrent_pred_on != "child" or not hasattr(dy, "hip_search_ok"):
+            return None
+        if not dy.hip_search_ok(self.pred_func, tuple(root[2].shape[1:]), self._support_size):
+            return None
+        return lambda handle, b, e: dy.hip_search(self.pred_func, handle, self._support_size, self._discount, b, e)
+
     # ------------------------------------------------------------------ act
     def _fused_handle(self, B, A, E, obs_dim, S, max_depth, pb_c_init, pb_c_base, tiebreak, policy="muzero",
                       qtransform="qtransform_by_parent_and_siblings", max_considered=16, gumbel_scale=1.0,
@@ -304,7 +314,7 @@ class MuZero:
                 invalid_actions=invalid_actions, max_depth=max_depth, qtransform=qtransform,
                 max_num_considered_actions=max_num_considered_actions, gumbel_scale=gumbel_scale,
                 gumbel=gumbel, with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version,
-                global_batch=global_batch, root_offset=root_offset))
+                global_batch=global_batch, root_offset=root_offset, native_loop=self._native_loop(root)))
             return out, root[1]
         if host_io and type(self._policy) is MuZeroPolicy:
             try:  # NumPy in, NumPy out: one C call (staging, root-noise draw from the key, search, one download, sync)
@@ -346,7 +356,7 @@ class MuZero:
                                 dirichlet_fraction=dirichlet_fraction, dirichlet_noise=dirichlet_noise,
                                 pb_c_init=pb_c_init, pb_c_base=pb_c_base, gumbel=gumbel, tiebreak=tiebreak,
                                 with_tree=with_tree, graph=self.capture_graph, graph_version=self._weights_version,
-                                global_batch=global_batch, root_offset=root_offset)
+                                global_batch=global_batch, root_offset=root_offset, native_loop=self._native_loop(root))
 
         return self._checked_search(run), root[1]
 

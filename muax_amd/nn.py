@@ -739,47 +739,61 @@ class ResNetDynamic(nn.Module):
             self._pack_sig = sig
         return self._pack
 
+    def _tower_args(self, B, device, pred=None, support_size=None):
+        """mzs_tower_args with the weights (and, with `pred`, the 17 head arrays + the three per-root outputs) filled in;
+        returns (args, tensors to keep alive, (reward, value, prior_logits) or None, device ordinal)."""
+        import ctypes as C
+
+        from . import _lib
+        stem, conv, ln = self._packed()
+        args = _lib.MzsTowerArgs()
+        args.struct_size = C.sizeof(_lib.MzsTowerArgs)
+        dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        args.device = dev_index
+        args.batch, args.blocks, args.normalize, args.num_actions = B, len(self.ns_blocks), 1, self.num_actions
+        args.stem_w, args.conv_w, args.ln = stem.data_ptr(), conv.data_ptr(), ln.data_ptr()
+        keep, outs = [stem, conv, ln], None
+        if pred is not None:
+            rf, vf, pf = self.r_func, pred.v_func, pred.pi_func
+            heads = [rf[0].w, rf[2].w, rf[5].w, rf[5].b, rf[7].w, rf[7].b,
+                     vf[0].w, vf[2].w, vf[5].w, vf[5].b, vf[7].w, vf[7].b,
+                     pf[0].w, pf[3].w, pf[3].b, pf[5].w, pf[5].b]
+            hk = [h.detach().contiguous() for h in heads]
+            keep += hk
+            for name, t in zip(_lib.MzsTowerArgs.HEAD_FIELDS, hk):
+                setattr(args, name, t.data_ptr())
+            outs = (torch.empty(B, device=device), torch.empty(B, device=device),
+                    torch.empty(B, pred.num_actions, device=device))
+            args.reward, args.value, args.prior_logits = (o.data_ptr() for o in outs)
+            args.support_size = support_size
+        return args, keep, outs, dev_index
+
+    def _pair_scratch_for(self, L, args, B, device, dev_index, stream):
+        """Attach the pair-mode scratch of (device, batch, stream) to `args` when pair mode applies (<= 128 roots: two
+        workgroups per root so that the launch covers the chip, mz_conv.cuh); returns (key, first use) or (None, False)."""
+        if self.use_pair_tower and os.environ.get("MZS_TOWER_PAIR", "1") != "0":
+            nbytes = L.mzs_tower_pair_scratch_bytes(B)
+            if nbytes:
+                key = (dev_index, B, stream)
+                first = key not in self._pair_scratch
+                if first:
+                    self._pair_scratch[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
+                args.pair_scratch, args.pair_scratch_bytes = self._pair_scratch[key].data_ptr(), nbytes
+                return key, first
+        return None, False
+
     def _tower_hip(self, s, a, pred=None, support_size=None):
         import ctypes as C
 
         from . import _lib
         L = _lib.load()
-        stem, conv, ln = self._packed()
         x = s.contiguous()
         act = a.to(torch.int32).contiguous()
         y = torch.empty_like(x)
-        args = _lib.MzsTowerArgs()
-        args.struct_size = C.sizeof(_lib.MzsTowerArgs)
-        dev_index = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        args.device = dev_index
-        args.batch, args.blocks, args.normalize, args.num_actions = x.shape[0], len(self.ns_blocks), 1, self.num_actions
-        args.x, args.action, args.stem_w = x.data_ptr(), act.data_ptr(), stem.data_ptr()
-        args.conv_w, args.ln, args.y = conv.data_ptr(), ln.data_ptr(), y.data_ptr()
-        outs = None
-        if pred is not None:
-            B = x.shape[0]
-            rf, vf, pf = self.r_func, pred.v_func, pred.pi_func
-            heads = [rf[0].w, rf[2].w, rf[5].w, rf[5].b, rf[7].w, rf[7].b,
-                     vf[0].w, vf[2].w, vf[5].w, vf[5].b, vf[7].w, vf[7].b,
-                     pf[0].w, pf[3].w, pf[3].b, pf[5].w, pf[5].b]
-            keep = [h.detach().contiguous() for h in heads]
-            for name, t in zip(_lib.MzsTowerArgs.HEAD_FIELDS, keep):
-                setattr(args, name, t.data_ptr())
-            outs = (torch.empty(B, device=x.device), torch.empty(B, device=x.device),
-                    torch.empty(B, pred.num_actions, device=x.device))
-            args.reward, args.value, args.prior_logits = (o.data_ptr() for o in outs)
-            args.support_size = support_size
+        args, keep, outs, dev_index = self._tower_args(x.shape[0], x.device, pred, support_size)
+        args.x, args.action, args.y = x.data_ptr(), act.data_ptr(), y.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        first = False
-        if self.use_pair_tower and os.environ.get("MZS_TOWER_PAIR", "1") != "0":
-            # <= 128 roots: two workgroups per root (mz_conv.cuh, pair mode) so that the launch covers the chip
-            nbytes = L.mzs_tower_pair_scratch_bytes(x.shape[0])
-            if nbytes:
-                key = (dev_index, x.shape[0], stream)
-                first = key not in self._pair_scratch
-                if first:
-                    self._pair_scratch[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
-                args.pair_scratch, args.pair_scratch_bytes = self._pair_scratch[key].data_ptr(), nbytes
+        key, first = self._pair_scratch_for(L, args, x.shape[0], x.device, dev_index, stream)
         with torch.cuda.device(x.device):
             _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(stream)))
             if args.pair_scratch and first and not torch.cuda.is_current_stream_capturing():
@@ -791,6 +805,35 @@ class ResNetDynamic(nn.Module):
                     args.pair_scratch, args.pair_scratch_bytes = None, 0
                     _lib.check(L.mzs_resnet_tower(C.byref(args), C.c_void_p(stream)))
         return y if outs is None else (outs[0], outs[1], outs[2], y)
+
+    use_hip_search = True  # the whole simulation loop as one launch (mzs_resnet_search); MZS_RESNET_SEARCH=0 turns it off
+
+    def hip_search_ok(self, pred, embedding_shape, support_size) -> bool:
+        """Can MuZeroSearch run its simulation loop as ONE launch with these nets (mzs_resnet_search)?"""
+        if not (self.use_hip_search and os.environ.get("MZS_RESNET_SEARCH", "1") != "0"):
+            return False
+        if tuple(embedding_shape) != (6, 6, 64) or self.ns_stem.w is None or not self.ns_stem.w.is_cuda:
+            return False
+        probe = torch.empty((1, 6, 6, 64), device=self.ns_stem.w.device)
+        return self._heads_ok(pred, probe, support_size)
+
+    def hip_search(self, pred, handle, support_size: int, discount: float, sim_begin: int, sim_end: int):
+        """Simulations [sim_begin, sim_end) of the search on `handle` (a rooted MuZeroSearch whose simulate() of
+        `sim_begin` has run) in ONE launch: recurrent_fn of muax/model.py:265-282 + mctx's expand / backward / next
+        simulate per root, back to back on the workgroup(s) that own the root (muax_amd/csrc/mz_search_conv.hip).
+        Pair mode (<= 128 roots): check pair_lost() afterwards, as for hip_recurrent."""
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        B, dev = handle.batch, handle.device
+        args, keep, outs, dev_index = self._tower_args(B, dev, pred, support_size)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self._pair_scratch_for(L, args, B, dev, dev_index, stream)
+        with torch.cuda.device(dev):
+            _lib.check(L.mzs_resnet_search(handle._h, C.byref(args), C.c_float(discount), sim_begin, sim_end,
+                                           C.c_void_p(stream)), handle._h)
+        self._search_keep = (keep, outs)  # alive until the stream has consumed them
 
     def pair_status(self):
         """Roots whose two workgroups lost each other in any pair-mode launch so far (must be 0).  Reads device
@@ -809,23 +852,27 @@ class ResNetDynamic(nn.Module):
         self.__dict__.pop("use_pair_tower", None)  # an instance attribute (tests set one) would shadow the class's
         self._pair_scratch.clear()
 
-    def hip_recurrent(self, pred, s, a, support_size: int):
-        """The whole recurrent_fn of muax/model.py:265-282 for the ResNet nets in ONE HIP launch: reward head,
-        next-state tower, prediction heads on the next state, both support decodes.  Returns
-        (reward [B], value [B], prior_logits [B, A], next_state [B, 6, 6, 64]) or None when the nets are not
-        the shapes the kernel is built for (the caller then runs the torch modules)."""
+    def _heads_ok(self, pred, s, support_size: int) -> bool:
+        """The nets are the shapes the one-launch recurrent kernel is built for (muax/nn.py:313-378 at 64 channels)."""
         def head_ok(seq, convs, hidden, in_ch):
             ws = [m for m in seq if isinstance(m, HkConv2D)]
             ls = [m for m in seq if isinstance(m, LazyHkLinear)]
             return (len(ws) == len(convs) and len(ls) == 2 and all(m.w is not None for m in ws + ls)
                     and [tuple(m.w.shape[2:]) for m in ws] == convs and ls[0].w.shape[1] == hidden
                     and all(m.with_bias for m in ls))
-        if not (isinstance(pred, ResNetPrediction) and self._hip_tower_ok(s, inference=True) and 2 * support_size + 1 <= 64
+        return (isinstance(pred, ResNetPrediction) and self._hip_tower_ok(s, inference=True) and 2 * support_size + 1 <= 64
                 and pred.num_actions <= 64 and pred.num_actions == self.num_actions
                 and head_ok(self.r_func, [(65, 64), (64, 64)], 64, 65)
                 and head_ok(pred.v_func, [(64, 16), (16, 16)], 16, 64)
                 and head_ok(pred.pi_func, [(64, 16)], 16, 64)
                 and self.r_func[7].w.shape[1] == 2 * support_size + 1
-                and pred.v_func[7].w.shape[1] == 2 * support_size + 1):
+                and pred.v_func[7].w.shape[1] == 2 * support_size + 1)
+
+    def hip_recurrent(self, pred, s, a, support_size: int):
+        """The whole recurrent_fn of muax/model.py:265-282 for the ResNet nets in ONE HIP launch: reward head,
+        next-state tower, prediction heads on the next state, both support decodes.  Returns
+        (reward [B], value [B], prior_logits [B, A], next_state [B, 6, 6, 64]) or None when the nets are not
+        the shapes the kernel is built for (the caller then runs the torch modules)."""
+        if not self._heads_ok(pred, s, support_size):
             return None
         return self._tower_hip(s, a, pred, support_size)

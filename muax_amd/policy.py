@@ -60,7 +60,7 @@ class MuZeroPolicy(Policy):
                         temperature=kwargs.get("temperature", 1.0), gumbel=kwargs.get("gumbel"),
                         with_tree=kwargs.get("with_tree", False), graph=kwargs.get("graph", False),
                         graph_key=(fn_identity(recurrent_fn), id(params), shape),
-                        graph_version=kwargs.get("graph_version", 0))
+                        graph_version=kwargs.get("graph_version", 0), native_loop=kwargs.get("native_loop"))
 
 
 class GumbelMuZeroPolicy(Policy):
@@ -105,7 +105,7 @@ class GumbelMuZeroPolicy(Policy):
                         invalid_actions=kwargs.get("invalid_actions"), gumbel=kwargs.get("gumbel"),
                         with_tree=kwargs.get("with_tree", False), graph=kwargs.get("graph", False),
                         graph_key=(fn_identity(recurrent_fn), id(params), shape),
-                        graph_version=kwargs.get("graph_version", 0))
+                        graph_version=kwargs.get("graph_version", 0), native_loop=kwargs.get("native_loop"))
 
 
 class StochasticMuZeroPolicy(Policy):

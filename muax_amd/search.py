@@ -419,7 +419,7 @@ class MuZeroSearch:
 
     def search(self, root_fn_output, recurrent_fn, key=0, invalid_actions=None,
                dirichlet_noise=None, dirichlet_fraction=0.25, temperature=1.0, gumbel=None,
-               with_tree=False, graph=False, graph_key=None, graph_version=0) -> PolicyOutput:
+               with_tree=False, graph=False, graph_key=None, graph_version=0, native_loop=None) -> PolicyOutput:
         """mctx.muzero_policy with a caller-supplied recurrent_fn(action, embedding) ->
         (reward, discount, prior_logits, value, next_embedding) of torch tensors.
 
@@ -430,7 +430,12 @@ class MuZeroSearch:
         recurrent_fn must then be capture-safe (no host synchronisation, static shapes); the per-call
         PRNG keys live in device memory (root) or in the un-captured root/finish calls.  `graph_version`
         is the caller's weights version: host-side work of recurrent_fn (e.g. re-packing convolution weights)
-        is frozen into a capture, so a new version re-captures and replaces the old graph."""
+        is frozen into a capture, so a new version re-captures and replaces the old graph.
+
+        `native_loop(handle, sim_begin, sim_end)`: nets whose recurrent_fn the library evaluates itself (the reference's
+        ResNet nets: ResNetDynamic.hip_search -> mzs_resnet_search) run the WHOLE simulation loop as one launch -- every
+        root advanced by its own workgroup(s), recurrent_fn and the tree update back to back, no per-simulation launch
+        and no row copies; `recurrent_fn` is then only the fall-back (a tree without cached decisions)."""
         prior_logits, value, embedding = root_fn_output
 
         def do_root():
@@ -447,7 +452,17 @@ class MuZeroSearch:
                 nxt = self.expand_backup_select(sim, *recurrent_fn(*nxt))
 
         do_root()
-        if not graph:
+        if native_loop is not None:
+            self.select(0)  # simulate() of simulation 0; every later one is the tail of its predecessor inside the launch
+            try:
+                native_loop(self, 0, self.cfg.num_simulations)
+            except ValueError as e:
+                if "cached decisions" not in str(e):
+                    raise
+                native_loop = None  # (trees beyond the cached-decision budget keep the per-simulation launches)
+        if native_loop is not None:
+            pass
+        elif not graph:
             loop()
         else:
             gkey = graph_key if graph_key is not None else fn_identity(recurrent_fn)

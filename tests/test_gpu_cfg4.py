@@ -421,3 +421,89 @@ def test_fused_layernorm_in_place():
         _lib.check(L.mzs_layernorm_act(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
         assert torch.equal(out, want), target
+
+
+@pytest.mark.parametrize("B,S,policy,max_depth", [(128, S_FULL, "muzero", None), (9, 40, "muzero", None),
+                                                  (160, 40, "muzero", None), (33, 48, "muzero", 6),
+                                                  (16, 40, "gumbel", None), (130, 24, "gumbel", None)])
+def test_one_launch_search_equals_the_per_simulation_launches(B, S, policy, max_depth):
+    """mzs_resnet_search -- the whole simulation loop as ONE launch, every root advanced by its own workgroup(s)
+    (pair mode up to 128 roots, one workgroup per root above), next states written straight into the tree's rows --
+    against the loop of per-simulation launches it replaces (recurrent kernel + mzs_expand_backup_select): every tree
+    array, the actions, the weights and the depth sums, bit for bit; both policies, invalid root actions, and a
+    `max_depth` cut (simulations that RE-expand an existing node and overwrite its row)."""
+    m, mods = _nets(31 + B)
+    dy, pred = mods[2], mods[1]
+    obs = torch.from_numpy(_frames(B, seed=B)).cuda()
+    pl, v, emb = m._root_inference(None, None, obs)
+    rng = np.random.default_rng(B)
+    noise = torch.from_numpy(rng.dirichlet([0.3] * A, B).astype(F32)).cuda()
+    invalid = (rng.uniform(size=(B, A)) < 0.1).astype(np.uint8)
+    invalid[np.arange(B), rng.integers(0, A, B)] = 0
+    invalid = torch.from_numpy(invalid).cuda()
+
+    def rec(action, flat):
+        (r, disc, logits, val), ns = m._recurrent_inference(None, None, action, flat.reshape(B, 6, 6, 64))
+        return r, disc, logits, val, ns.reshape(B, -1)
+
+    def native(handle, b, e):
+        dy.hip_search(pred, handle, SUPPORT, 0.99, b, e)
+
+    assert dy.hip_search_ok(pred, (6, 6, 64), SUPPORT)
+    outs = []
+    for loop in (None, native):
+        cfg = mx.SearchConfig(A, S, 2304, tiebreak=policy == "muzero", policy=policy, max_depth=max_depth,
+                              qtransform="qtransform_by_parent_and_siblings")
+        s = mx.MuZeroSearch(B, cfg)
+        kw = dict(dirichlet_noise=noise) if policy == "muzero" else {}
+        o = s.search((pl, v, emb.reshape(B, -1)), rec, key=[5, B], invalid_actions=invalid, with_tree=True,
+                     native_loop=loop, **kw)
+        torch.cuda.synchronize()
+        outs.append((o.action.clone(), o.action_weights.clone(), s.depth_sum.clone(),
+                     {f: getattr(o.search_tree, f).clone() for f in o.search_tree._fields}))
+        s.close()
+    if B <= 128:
+        assert dy._pair_scratch and not dy.pair_lost()
+    (a0, w0, d0, t0), (a1, w1, d1, t1) = outs
+    assert torch.equal(a0, a1) and torch.equal(w0, w1) and torch.equal(d0, d1)
+    for f in t0:
+        assert torch.equal(t0[f], t1[f]), (f, int((t0[f] != t1[f]).sum()))
+    if max_depth:
+        assert int(t1["node_visits"][:, 1:].max()) > 1 and int((t1["parents"][:, 1:] == -1).sum()) > 0  # re-expansions happened
+
+
+def test_one_launch_search_in_two_halves_and_through_act():
+    """[0, S/2) and [S/2, S) as two launches == one launch (the second continues from the selection the first one's
+    tail left in the handle), and MuZero.act() takes the one-launch route by itself: same actions, weights and
+    values as with MZS_RESNET_SEARCH=0 (the per-simulation launches), batched NumPy round trip."""
+    B, S = 24, 32
+    m, mods = _nets(77)
+    dy, pred = mods[2], mods[1]
+    obs_np = _frames(B, seed=8)
+    obs = torch.from_numpy(obs_np).cuda()
+    pl, v, emb = m._root_inference(None, None, obs)
+    noise = torch.from_numpy(np.random.default_rng(1).dirichlet([0.3] * A, B).astype(F32)).cuda()
+    trees = []
+    for parts in ((S,), (S // 2, S)):
+        def native(handle, b, e):
+            lo = b
+            for hi in parts:
+                dy.hip_search(pred, handle, SUPPORT, 0.99, lo, hi)
+                lo = hi
+        s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, 2304, tiebreak=True))
+        o = s.search((pl, v, emb.reshape(B, -1)), None, key=[1, 2], dirichlet_noise=noise, with_tree=True, native_loop=native)
+        torch.cuda.synchronize()
+        trees.append({f: getattr(o.search_tree, f).clone() for f in o.search_tree._fields})
+        s.close()
+    for f in trees[0]:
+        assert torch.equal(trees[0][f], trees[1][f]), f
+    got = m.act(9, obs_np, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=S)
+    import os
+    os.environ["MZS_RESNET_SEARCH"] = "0"
+    try:
+        m2, _ = _nets(77)
+        want = m2.act(9, obs_np, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=S)
+    finally:
+        del os.environ["MZS_RESNET_SEARCH"]
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)

@@ -92,7 +92,8 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 // tiles read their 3x3 windows from the tail
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
-constexpr int kHeadWords = 16 + 3 * 768 + 2 * 256 + 64 + 64;  // reduction slots (4 values x 4 waves) + scratch of the heads
+constexpr int kRhWords = kTowerPix * kTowerC;  // pair mode: the reward head's second feature map, [36][64], kept through the tower
+constexpr int kHeadWords = 16 + 3 * 768 + 2 * 256 + 64 + 64 + kRhWords;  // reduction slots (4 values x 4 waves) + scratch of the heads
 
 // sum over the 64 lanes of a wavefront, in every lane: the DPP butterfly inside the 16-lane rows, then the four row
 // sums through v_readlane (round 3; the six shuffles through LDS this replaces cost ~0.3 us per reduction, and a launch
@@ -525,9 +526,12 @@ MZ_DEV void norm_tiles(f32x4 (&acc)[3], float mean, float rstd, const float* so,
 struct HeadLds {
   float *hv, *hv2, *hp, *part, *part2, *vec, *lgt;
 };
-// reward head on [s, a / num_actions] held in `in` (haloed map); `tmp` is a second haloed map
-MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in, float* tmp, const HeadLds& H,
-                        const int (&rowc)[3], int ch, int tid, int lane, int wave) {
+// reward head on [s, a / num_actions] held in `in` (haloed map); `tmp` is a second haloed map.  Three pieces so that
+// pair mode can spread it over the idle time of the 16-pixel half (below); one workgroup per root runs them back to back.
+// (1) the two 1x1 convolutions + relu -> feature map `fmap` (haloed layout when fmap == tmp, else compact [36][64])
+template <bool COMPACT>
+MZ_DEV void reward_front(const TowerParams& p, const TowerIO& io, const float* in, float* tmp, float* fmap,
+                         const int (&rowc)[3], int ch, int lane) {
   const int g4 = lane >> 4;
   f32x4 acc[3];
   conv1x1_tiles(in, rowc, p.r_c1, kTowerC, ch, 4, g4, acc);
@@ -544,24 +548,34 @@ MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(acc[mt][v], 0.0f);
   __syncthreads();  // every wave has read tmp
-  store_map(acc, tmp, ch, lane);
-  __syncthreads();
-  {
-    // Linear(2304 -> 64): wave = 9 pixels of the map, lane = output unit; weights stream from L2
-    // 576 weights per thread, all from L2: the loop is bound by load latency, so a whole pixel's 64 loads
-    // are put in flight before the first fma (8 at a time cost 3 x the time)
-    float sacc = 0.0f;
-    for (int px = 9 * wave; px < 9 * wave + 9; ++px) {
-      const float* row = tmp + map_word(px);
-      const float* wr = p.r_l1 + (size_t)px * kTowerC * kTowerC + lane;
-      float w[kTowerC];
+  if constexpr (COMPACT) {
 #pragma unroll
-      for (int c = 0; c < kTowerC; ++c) w[c] = wr[c * kTowerC];
+    for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-      for (int c = 0; c < kTowerC; ++c) sacc = __builtin_fmaf(row[c], w[c], sacc);
-    }
-    H.part[tid] = sacc;
+      for (int v = 0; v < 4; ++v) {
+        const int px = 16 * mt + 4 * g4 + v;
+        if (px < kTowerPix) fmap[px * kTowerC + ch] = acc[mt][v];
+      }
+  } else {
+    store_map(acc, fmap, ch, lane);
   }
+  __syncthreads();
+}
+// (2) Linear(2304 -> 64), one pixel: wave = 9 pixels of the map (9 wave + k, k = 0..8), lane = output unit; `row` = the
+// pixel's 64 features in LDS.  576 weights per thread in all, streamed from L2: the loop is bound by load latency, so a
+// whole pixel's 64 loads are put in flight before the first fma (8 at a time cost 3 x the time).  The partial sum of a
+// lane runs over its wave's pixels in order, channels in order -- whoever calls the pieces, the bits are the same.
+MZ_DEV void reward_linear_pixel(const TowerParams& p, const float* row, int px, int lane, float& sacc) {
+  const float* wr = p.r_l1 + (size_t)px * kTowerC * kTowerC + lane;
+  float w[kTowerC];
+#pragma unroll
+  for (int c = 0; c < kTowerC; ++c) w[c] = wr[c * kTowerC];
+#pragma unroll
+  for (int c = 0; c < kTowerC; ++c) sacc = __builtin_fmaf(row[c], w[c], sacc);
+}
+// (3) the four waves' partial sums -> hidden vector -> logits -> support_to_scalar
+MZ_DEV void reward_finish(const TowerParams& p, const TowerIO& io, const HeadLds& H, float sacc, int tid, int lane, int wave) {
+  H.part[tid] = sacc;
   __syncthreads();
   if (tid < 64)
     H.vec[tid] = fmaxf(((H.part[tid] + H.part[64 + tid]) + (H.part[128 + tid] + H.part[192 + tid])) + p.r_b1[tid], 0.0f);
@@ -577,6 +591,13 @@ MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in
     if (lane == 0) *io.reward = rw;
   }
   __syncthreads();
+}
+MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in, float* tmp, const HeadLds& H,
+                        const int (&rowc)[3], int ch, int tid, int lane, int wave) {
+  reward_front<false>(p, io, in, tmp, tmp, rowc, ch, lane);
+  float sacc = 0.0f;
+  for (int px = 9 * wave; px < 9 * wave + 9; ++px) reward_linear_pixel(p, tmp + map_word(px), px, lane, sacc);
+  reward_finish(p, io, H, sacc, tid, lane, wave);
 }
 // prediction heads on the normalised next state held in `cur` (haloed map)
 MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const float* cur, const HeadLds& H, const int (&rowc)[3],
@@ -697,13 +718,14 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
   H.part2 = H.part + 256;     // [256]
   H.vec = H.part2 + 256;      // [64] hidden vectors
   H.lgt = H.vec + 64;         // [64] logits
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* rhmap = H.lgt + 64;  // [36][64] pair mode: second feature map of the reward head
+  const int tid = opaque_tid(), lane = tid & 63, wave = tid >> 6;
 #ifdef MZ_PROFILE
   unsigned long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
   const unsigned long long tstart = tlast;
 #endif
-  for (int i = tid; i < 2 * kBufWords + kHeadWords; i += 256) lds[i] = 0.0f;
+  for (int i = tid; i < 2 * kBufWords + kHeadWords - kRhWords; i += 256) lds[i] = 0.0f;  // (rhmap is written before it is read)
   __syncthreads();
   load_state(io.x, bufA, tid);
   __syncthreads();
@@ -725,6 +747,15 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
   for (int mt = 0; mt < 3; ++mt) rowc[mt] = abase[mt] + (kHalo + 1) * kPixStride;
   if constexpr (!PAIR)
     if (p.heads) reward_head(p, io, bufA, bufB, H, rowc, ch, tid, lane, wave);
+  // Pair mode: the reward head (it needs only (s, a)) belongs to the 16-PIXEL half, which idles ~2 us in every one of
+  // the 16 convolution passes waiting for the 20-pixel half: its two 1x1 convolutions run here, up front; the
+  // flatten -> Linear(2304 -> 64) layer is cut into one pixel per wave and pass (9 of the 16 passes), issued between
+  // posting a message and waiting for the partner's; the rest after the tower.  (Until round 4 the 20-pixel half ran
+  // the whole head AFTER the tower: 11 - 24 us on the critical path of every simulation.)
+  float rh_acc = 0.0f;
+  int rh_k = 0;
+  if constexpr (TSEL == 1)
+    if (p.heads) reward_front<true>(p, io, bufA, bufB, rhmap, rowc, ch, lane);
   MZ_TT(1)
 
   float* cur = bufA;
@@ -793,6 +824,11 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         put_boundary<TSEL>(pr[1], out + 8, ch, lane);
         pair_post(L, tid);
         MZ_TT(5)
+        if constexpr (TSEL == 1) {
+          if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+          rh_k += 1;
+          MZ_TT(1)
+        }
         const float* in = pair_wait(L, tid);
         MZ_TT(6)
         float mean[2], rstd[2];
@@ -838,6 +874,11 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         put_boundary<TSEL>(pr[0], msg + 8 + kPairBnd * kTowerC, ch, lane);
         pair_post(L, tid);
         MZ_TT(5)
+        if constexpr (TSEL == 1) {
+          if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+          rh_k += 1;
+          MZ_TT(1)
+        }
         const float* in = pair_wait(L, tid);
         MZ_TT(6)
         float mean, rstd;
@@ -933,12 +974,14 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
   MZ_TT(10)
   if (p.heads) {
     if constexpr (TSEL == 2) {
-      // half 1: the reward head, on the state reloaded into the (now free) buffers
-      __syncthreads();
-      load_state(io.x, bufA, tid);
-      __syncthreads();
-      reward_head(p, io, bufA, bufB, H, rowc, ch, tid, lane, wave);
+      // half 1: nothing left (the reward head runs on half 0, spread over its idle time)
     } else {
+      if constexpr (TSEL == 1) {
+        // (fewer than 5 blocks: the pixels the passes did not get to)
+        for (; rh_k < 9; ++rh_k) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+        __syncthreads();
+        reward_finish(p, io, H, rh_acc, tid, lane, wave);
+      }
       // ---- prediction heads on the normalised next state ----
       store_map<TSEL>(acc, cur, ch, lane);
       if constexpr (TSEL == 1) {

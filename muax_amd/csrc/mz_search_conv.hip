@@ -17,8 +17,8 @@
 //
 //   * one workgroup per root (any batch): no communication between workgroups at all;
 //   * pair mode (<= 128 roots, two workgroups per root splitting the pixels, mz_conv.cuh): the halves already meet in
-//     their XCD's L2 after every convolution pass; two more messages per simulation carry the reward (half 1 -> half 0,
-//     which owns the tree) and the next simulation's (parent, action, new node) (half 0 -> half 1).
+//     their XCD's L2 after every convolution pass; half 0 (which also evaluates both heads) owns the tree, and one more
+//     message per simulation tells half 1 the next simulation's (parent, action, new node).
 #include <hip/hip_runtime.h>
 
 #define MZ_NO_STEP_KERNELS   // device functions and types of the step-wise path only: its kernels live in mz_api.hip,
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
     else pair_link_init<2>(p, r, L);
   }
   // simulate() of sim_begin has run (mzs_select, or the tail of the previous launch): its decision is in the handle
-  int parent = s.sel_parent[r], action = s.sel_action[r];
+  int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
   int newn;
   {
     const int next = s.children_index[(rb + parent) * A + action];
@@ -77,32 +77,39 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   io.reward = p.reward + r;
   io.value = p.value + r;
   io.prior_logits = p.prior_logits + (size_t)r * A;
+#ifdef MZ_PROFILE
+  unsigned long long st[4] = {0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define MZ_ST(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - tl; tl = t_; }
+#else
+#define MZ_ST(k)
+#endif
   for (int sim = loop.sim_begin; sim < loop.sim_end; ++sim) {
     io.x = s.embeddings + (rb + parent) * E;
     io.y = s.embeddings + (rb + newn) * E;
     io.action = action;
     const bool more = sim + 1 < loop.sim_end && sim + 1 < s.S;
-    int sel[2] = {0, 0};
+    int sel[3] = {0, 0, 0};
     if (!PAIRED || h == 0) {
-      float rew;
       if constexpr (PAIRED) {
-        tower_body<1>(p, io, lds, L);  // ... ends with the prediction heads: value and prior logits of this root
-        L.seq += 1;                    // (half 0 posts nothing under this number)
-        const float* in = pair_wait(L, tid);  // message R of half 1: the reward
-        rew = pair_load(in);
+        tower_body<1>(p, io, lds, L);  // ... ends with the reward head's tail and the prediction heads of this root
+        MZ_ST(0)
         if (pair_lost_uniform(L, tid, &lost_flag)) return;  // the host sees the status word and repeats the search
+        MZ_ST(1)
       } else {
         tower_body<0>(p, io, lds, L);
-        __syncthreads();
-        rew = *reinterpret_cast<const volatile float*>(io.reward);
+        MZ_ST(0)
       }
-      __syncthreads();  // value / prior logits were written by other threads of this workgroup
+      __syncthreads();  // reward / value / prior logits were written by other threads of this workgroup
+      const float rew = *reinterpret_cast<const volatile float*>(io.reward);
       const float val = *reinterpret_cast<const volatile float*>(io.value);
+      const int known[4] = {parent, action, depth, newn};
       jump_expand_backup_body<GUMBEL>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
-                                      nullptr, sel);
+                                      nullptr, sel, known);
+      MZ_ST(2)
       if (more) {
         parent = sel[0];
         action = sel[1];
+        depth = sel[2];
         const int next = s.children_index[(rb + parent) * A + action];
         newn = next == -1 ? sim + 2 : next;
       }
@@ -121,18 +128,15 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
         }
       }
       __syncthreads();
+      MZ_ST(3)
     } else {
       if constexpr (PAIRED) {
-        tower_body<2>(p, io, lds, L);  // ... ends with the reward head
-        float* msg = pair_out(L);      // message R
-        if (tid == 0) {
-          pair_store(msg, *reinterpret_cast<const volatile float*>(io.reward));
-          pair_store(msg + 4, __uint_as_float(L.xcc));
-        }
-        pair_post(L, tid);
+        tower_body<2>(p, io, lds, L);
+        MZ_ST(0)
         L.seq += 1;  // (half 1 posts nothing under the number of message T)
         if (more) {
           const float* in = pair_wait(L, tid);
+          MZ_ST(2)
           if (pair_lost_uniform(L, tid, &lost_flag)) return;
           parent = min(max(__float_as_int(pair_load(in)), 0), N - 1);
           action = min(max(__float_as_int(pair_load(in + 1)), 0), A - 1);
@@ -141,6 +145,10 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
       }
     }
   }
+#ifdef MZ_PROFILE
+  if (tid == 0)
+    for (int k = 1; k < 4; ++k) g_tower_prof[(size_t)blockIdx.x * 16 + 11 + k] += st[k];  // slots 12..14 (0..11, 15: the pass itself)
+#endif
   if constexpr (PAIRED) {
     // the root's epoch advances by the simulations of this launch (each uses fewer than kPairMsgs message numbers);
     // both halves read it before their first message and half 0 is past the last one it waits for
@@ -151,6 +159,24 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
 }  // namespace mz
 
 extern "C" {
+
+#ifdef MZ_PROFILE
+// profiling builds only (tools/profile_search.py): read and clear this translation unit's per-workgroup phase counters
+int mzs_debug_search_profile(uint64_t* host_out, int32_t words) {
+  static unsigned long long zero[1024 * 16];
+  if (words > 1024 * 16) words = 1024 * 16;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mz::g_tower_prof), sizeof(uint64_t) * (size_t)words) != hipSuccess) return MZS_E_RUNTIME;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mz::g_tower_prof), zero, sizeof(zero)) != hipSuccess) return MZS_E_RUNTIME;
+  return MZS_OK;
+}
+int mzs_debug_jump_profile(uint64_t* host_out, int32_t words) {
+  static unsigned long long zero[1024 * 8];
+  if (words > 1024 * 8) words = 1024 * 8;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mz::g_jump_prof), sizeof(uint64_t) * (size_t)words) != hipSuccess) return MZS_E_RUNTIME;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mz::g_jump_prof), zero, sizeof(zero)) != hipSuccess) return MZS_E_RUNTIME;
+  return MZS_OK;
+}
+#endif
 
 int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, int32_t sim_begin, int32_t sim_end,
                       void* stream_) {

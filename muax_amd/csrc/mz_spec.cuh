@@ -37,6 +37,16 @@ struct StaticFor<N, N> {
   static MZ_DEV void run(Fn&&) {}
 };
 
+// threadIdx.x behind an empty asm statement: a device function that is called once per iteration of a long loop (the
+// one-launch ResNet search) must not have its lane-dependent address arithmetic hoisted out of that loop -- the
+// hundreds of pre-computed offsets then live across the whole body and spill (measured: 2.2 KB of scratch per lane,
+// the heads of the recurrent pass 6x slower)
+MZ_DEV int opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 MZ_DEV float u2f(uint32_t u) { return __uint_as_float(u); }
 MZ_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 

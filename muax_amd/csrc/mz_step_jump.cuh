@@ -24,6 +24,21 @@
 namespace mz {
 
 constexpr int kJumpMaxNodes = 1024;
+
+// opt-in phase timers of the expand / backward / refresh body (tools/profile_search.py builds with -DMZ_PROFILE)
+#ifdef MZ_PROFILE
+__device__ unsigned long long g_jump_prof[1024 * 8];
+#define MZ_JT_BEGIN unsigned long long jt_last = __builtin_amdgcn_s_memtime();
+#define MZ_JT(k)                                                             \
+  if (threadIdx.x == 0) {                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
+    g_jump_prof[(size_t)(blockIdx.x & 1023) * 8 + (k)] += t_ - jt_last;      \
+    jt_last = t_;                                                            \
+  }
+#else
+#define MZ_JT_BEGIN
+#define MZ_JT(k)
+#endif
 constexpr int kLevelsInFlight = 3;  // levels of a backed-up path a 16-lane row refreshes at once (mzs_expand_backup)
 
 #define MZ_JROW_SETUP                                                 \
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) 
 // embedding row (a separate transfer kernel costs its own 4.7 us minimum); otherwise one 16-lane row per root.
 // jump_select_core: the decision alone -- every 16-lane row that calls it gets the same (parent, action, depth).
 MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int r, int& parent, int& action, int& depth) {
-  const int lane = threadIdx.x & 63;
+  const int lane = opaque_tid() & 63;
   const int j = lane & 15;
   const int N = s.N, A = s.A;
   const size_t rb = (size_t)r * N;
@@ -283,7 +298,7 @@ MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int 
   const size_t rb = (size_t)r * N;
   int parent, action, depth;
   jump_select_core(s, g, sim, r, parent, action, depth);
-  if (sel_out) { sel_out[0] = parent; sel_out[1] = action; }
+  if (sel_out) { sel_out[0] = parent; sel_out[1] = action; sel_out[2] = depth; }
   if (WG ? threadIdx.x == 0 : j == 0) {
     s.sel_parent[r] = parent;
     s.sel_action[r] = action;
@@ -317,20 +332,24 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
 // The body is a device function of the calling workgroup (any multiple of 64 threads): the step-wise kernel below runs
 // it on a workgroup of its own, the fused ResNet search (mz_search_conv.hip) as the tail of the recurrent_fn pass of
 // the same root.  `prior_logits_row`: the root's A logits; `next_embedding_row` == nullptr: the caller has written the
-// new node's embedding row in place; `select_next`: also run simulate() of sim + 1 (sel_out[0..1] = its parent / action
+// new node's embedding row in place; `select_next`: also run simulate() of sim + 1 (sel_out[0..2] = its parent / action / depth
 // in every thread; `next_parent_embedding_out` == nullptr: no gather).
 template <bool GUMBEL>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
-                                    int* sel_out = nullptr) {
-  const int tid = threadIdx.x, j = tid & 15, row = tid >> 4;
+                                    int* sel_out = nullptr, const int* known = nullptr) {
+  const int tid = opaque_tid(), j = tid & 15, row = tid >> 4;
+  MZ_JT_BEGIN
   const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 1024 / 256 threads (64 / 16 levels in flight) or one wavefront (4)
   const int N = s.N, A = s.A, E = s.E;
   const size_t rb = (size_t)r * N;
-  const int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
+  // `known` = {parent, action, depth, new node} of this simulation when the caller has them in registers (the fused
+  // search: two dependent memory round trips fewer on its critical path); an existing node has an index <= sim
+  const int parent = known ? known[0] : s.sel_parent[r], action = known ? known[1] : s.sel_action[r];
+  const int depth = known ? known[2] : s.sel_depth[r];
   const size_t eo = (rb + parent) * A + action;
-  const int next = s.children_index[eo];
+  const int next = known ? (known[3] == sim + 1 ? -1 : known[3]) : s.children_index[eo];
   __syncthreads();  // every thread has read the edge before row 0 rewrites it
   const bool fresh = next == -1;
   const int newn = fresh ? sim + 1 : next;
@@ -399,6 +418,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
   if (next_embedding_row != nullptr)
     for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding_row[i];
   __syncthreads();
+  MZ_JT(0)
   // -- per-level inputs of the backward pass --
   for (int e = tid; e < depth; e += nthr) {
     const size_t e2 = (rb + pn[e]) * A + pa[e];
@@ -408,6 +428,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
     ds[e] = (e == depth - 1) ? dis_new : s.children_discounts[e2];
   }
   __syncthreads();
+  MZ_JT(1)
   // -- leaf_value = reward + discount * leaf_value, leaf to root (the one sequential chain) --
   // One wavefront, 64 levels per chunk in registers: a step is two v_readlane (off the chain) + mul + add on the
   // wave-uniform G, ~25 cycles, instead of an LDS round trip per level on a lone thread (~90) -- the paths of a long
@@ -428,6 +449,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
     }
   }
   __syncthreads();
+  MZ_JT(2)
   for (int e = tid; e <= depth; e += nthr)
     nv[e] = (e == depth) ? v : (val[e] * (float)cnt[e] + Gs[e]) / ((float)cnt[e] + 1.0f);
   __syncthreads();
@@ -439,6 +461,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
     s.children_visits[e2] = s.children_visits[e2] + 1;
   }
   __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
+  MZ_JT(3)
   // -- decisions of the path nodes and the leaf: one row per level, kLevelsInFlight levels per row at once (all
   // their loads are issued before the first is used: a deep path costs one memory round trip, not one per 64 levels) --
   for (int base = 0; base <= depth; base += nrows * kLevelsInFlight) {
@@ -494,6 +517,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
     }
   }
   __syncthreads();
+  MZ_JT(4)
   // -- JUMP records: a level takes its own end point (near tie, or an unexpanded best child), the stored record of
   // its off-path best child, or -- when its best child is the next level of this very path -- whatever that level
   // resolves to.  The bottom-up chain of the last case is resolved by pointer jumping (log2(depth) rounds over all
@@ -520,10 +544,12 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
       g.jump_lv[rb + pn[e]] = njl[from];
     }
   }
+  MZ_JT(5)
   if (select_next && sim + 1 < s.S) {
     __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
     jump_select_body<true>(s, g, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out);
   }
+  MZ_JT(6)
 }
 template <bool GUMBEL>
 __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, JumpArgs g, int sim, const float* reward,

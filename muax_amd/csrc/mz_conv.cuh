@@ -72,8 +72,8 @@ struct TowerParams {
   float* prior_logits; // [B][A]
   int heads, A, F, support;
   // pair mode (mz_resnet_tower_pair_kernel): exchange slots and flags of the two workgroups of a root
-  float* pair_f;       // [B][2 halves][2 parity][kPairSlot]
-  unsigned* pair_u;    // [B][4]: flag of half 0, flag of half 1, launch epoch, status
+  float* pair_f;       // [B][2 halves][2 parity][kPairSlot] (value, message number) pairs
+  unsigned* pair_u;    // [B][4]: -, -, launch epoch, status
 };
 
 // where ONE root's pass reads and writes (the step-wise launches index the batch arrays of TowerParams by the root;
@@ -403,72 +403,79 @@ MZ_DEV float decode_support(const float* logits, int F, int support, int lane) {
 // message through L2 -- their local (mean, M2) and the RAW boundary pixels -- and each normalises the
 // partner's boundary pixels itself (Chan's merge of the moments, written so that both halves compute the
 // same bits).  Messages go through two slots per half (message k in slot k & 1: the partner cannot post
-// k + 2 before it has read k) and a monotonic flag per half; a per-root launch epoch in device memory keeps
-// the numbering going across launches, so a captured hipGraph can replay the kernel.  A spin that runs out
-// sets the root's status word instead of hanging.  Needs both workgroups resident at once: the host uses it
-// only while 2 B workgroups fit the chip in one wave of dispatch.
-constexpr int kPairSlot = 1536;   // floats per message slot: 8 header + 128 (min, max) + 1280 or 2 x 448 payload
+// k + 2 before it has read k); a per-root launch epoch in device memory keeps the numbering going across launches,
+// so a captured hipGraph can replay the kernel.  A spin that runs out sets the root's status word instead of
+// hanging.  Needs both workgroups resident at once: the host uses it only while 2 B workgroups fit the chip in one
+// wave of dispatch.
+//
+// The two halves of a root sit on the SAME XCD (see mz_resnet_tower_pair_kernel) and meet in that XCD's L2: a CU's L1
+// is write-through, so a plain store is in L2 when it completes; the reader's loads bypass its L1 (volatile: sc0 sc1).
+// Round 4: every word of a message travels as an 8-byte (value, message number) pair -- one aligned 64-bit store,
+// one aligned 64-bit load, never torn -- and the reader polls the very words it needs until they carry the number it
+// waits for.  There is no flag any more: rounds 1-3 stored the payload, drained vmcnt, met at a barrier, stored a flag;
+// the reader polled the flag, met at a barrier, then fetched the payload -- two more L2 round trips and two more
+// barriers per message, 17 messages per pass of the tower (~0.8 us each).  What did NOT work (round 1): agent-scope
+// fences (their L2 write-back / invalidate threw the convolution weights out of L2 for every workgroup of the XCD:
+// 725 us at 128 roots), group-scope atomics (sc0 loads may hit L1 when a workgroup is not split over CUs), and
+// device-scope atomics for every word (each message a trip to the memory side: 4 us per message).  Each message
+// carries the sender's XCC id; a half that sees another id than its own reports status 2 -- the L2 rendezvous is only
+// valid inside one XCD.  A stamped word says nothing about OTHER stores of its sender: whoever needs those (the fused
+// search's hand-over of embedding rows) drains vmcnt and meets at a barrier before it stamps (pair_begin_strong).
+constexpr int kPairSlot = 1536;   // VALUES per message slot (8 bytes each): 8 header + 128 (min, max) + 1280 or 2 x 448 payload
 constexpr int kPairBnd = 7;       // boundary pixels each half sends
-constexpr int kPairMsgs = 64;     // messages per launch, upper bound (epoch stride)
+constexpr int kPairMsgs = 64;     // message numbers per tower pass, upper bound (epoch stride)
 constexpr unsigned kPairSpin = 1u << 19;
 template <int TSEL>
 struct PairGeom {
   static constexpr int first_own = TSEL == 1 ? 0 : 16, n_own = TSEL == 1 ? 16 : 20;
   static constexpr int send_first = TSEL == 1 ? 9 : 16, recv_first = TSEL == 1 ? 16 : 9;
 };
+typedef float pair_word __attribute__((ext_vector_type(2)));  // (value, message number)
 struct PairLink {
-  float* mine;                // [2][kPairSlot]
-  const float* theirs;        // [2][kPairSlot]
-  unsigned* my_flag;
-  const unsigned* their_flag;
+  pair_word* mine;            // [2][kPairSlot]
+  const pair_word* theirs;    // [2][kPairSlot]
   unsigned* status;
-  unsigned seq;               // number of the last message posted
+  unsigned seq;               // number of the message being written / read
   unsigned xcc;               // 1 + id of the XCD this workgroup runs on
 };
-MZ_DEV float* pair_out(const PairLink& L) { return L.mine + ((L.seq + 1) & 1) * kPairSlot; }
-// The two halves of a root sit on the SAME XCD (see mz_resnet_tower_pair_kernel) and meet in that XCD's L2:
-// a CU's L1 is write-through, so a message is in L2 once vmcnt has drained (then the barrier, then the
-// flag); the reader drops its L1 (`buffer_inv sc0`, L1 only) before it looks at the flag and at the
-// message.  What did NOT work: agent-scope fences (their L2 write-back / invalidate threw the convolution
-// weights out of L2 for every workgroup of the XCD, 17 times per launch: 725 us at 128 roots), group-scope
-// atomics (sc0 loads may hit L1 when a workgroup is not split over CUs: the flag was never seen), and
-// device-scope atomics for every word (correct, but each message then costs a trip to the memory side:
-// 4 us per message).  Each message carries the sender's XCC id; a half that sees another id than its own
-// reports status 2 -- the L2 rendezvous is only valid inside one XCD.
-#ifdef MZ_PAIR_SC1
-// A/B build: payload stores write-through at agent scope (global_store ... sc1): with the sc0 sc1 loads below this
-// is the guide's placement-independent form R1 (valid across XCDs), at the price of one fabric write per dword
-MZ_DEV void pair_store(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#else
-MZ_DEV void pair_store(float* q, float v) { *q = v; }
-#endif
-MZ_DEV float pair_load(const float* q) { return *reinterpret_cast<const volatile float*>(q); }
-MZ_DEV void pair_post(PairLink& L, int tid) {  // every thread has stored its part of the message
+// start message L.seq + 1: the slot its words go to (every pair_put after this carries the new number)
+MZ_DEV pair_word* pair_begin(PairLink& L) {
+  L.seq += 1;
+  return L.mine + (L.seq & 1) * kPairSlot;
+}
+// the same after every earlier store of this workgroup has completed (a stamped word then vouches for them)
+MZ_DEV pair_word* pair_begin_strong(PairLink& L) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  L.seq += 1;
-  if (tid == 0) *reinterpret_cast<volatile unsigned*>(L.my_flag) = L.seq;
+  return pair_begin(L);
 }
-MZ_DEV const float* pair_wait(PairLink& L, int tid) {  // the partner's message number L.seq
-  const float* in = L.theirs + (L.seq & 1) * kPairSlot;
-  if (tid == 0) {
-    unsigned n = 0;
-    for (;;) {
-      asm volatile("buffer_inv sc0" ::: "memory");
-      if ((int)(*reinterpret_cast<const volatile unsigned*>(L.their_flag) - L.seq) >= 0) break;
-      if (*reinterpret_cast<const volatile unsigned*>(L.status) != 0u) break;  // once lost, never wait again
-      if (++n > kPairSpin) {
-        *reinterpret_cast<volatile unsigned*>(L.status) = 1u;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
+MZ_DEV const pair_word* pair_in(const PairLink& L) { return L.theirs + (L.seq & 1) * kPairSlot; }  // the partner's message L.seq
+MZ_DEV void pair_put(const PairLink& L, pair_word* out, int i, float v) {
+  pair_word w;
+  w.x = v;
+  w.y = __uint_as_float(L.seq);
+  out[i] = w;  // one global_store_dwordx2
+}
+MZ_DEV float pair_get(const PairLink& L, const pair_word* in, int i) {
+  const volatile unsigned long long* q = reinterpret_cast<const volatile unsigned long long*>(in + i);
+  unsigned long long w = *q;  // one load, sc0 sc1
+  unsigned n = 0;
+  while ((unsigned)(w >> 32) != L.seq) {
+    n += 1;
+    if ((n & 255u) == 0u && *reinterpret_cast<const volatile unsigned*>(L.status) != 0u) break;  // once lost, never wait again
+    if (n > kPairSpin) {
+      *reinterpret_cast<volatile unsigned*>(L.status) = 1u;
+      break;
     }
+    __builtin_amdgcn_s_sleep(1);
+    w = *q;
   }
-  __syncthreads();
-  asm volatile("buffer_inv sc0" ::: "memory");
-  if (tid == 0 && __float_as_uint(pair_load(in + 4)) != L.xcc && *reinterpret_cast<const volatile unsigned*>(L.status) == 0u)
+  return __uint_as_float((unsigned)w);
+}
+// header word 4 of every message: the sender's XCC id
+MZ_DEV void pair_check_xcc(const PairLink& L, const pair_word* in, int tid) {
+  if (tid == 0 && __float_as_uint(pair_get(L, in, 4)) != L.xcc && *reinterpret_cast<const volatile unsigned*>(L.status) == 0u)
     *reinterpret_cast<volatile unsigned*>(L.status) = 2u;
-  return in;
 }
 MZ_DEV int map_word(int px) { return ((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride; }
 
@@ -501,14 +508,14 @@ MZ_DEV void own_moments(const f32x4 (&acc)[NW][3], float (&mean)[NW], float (&m2
   wg_sum<NW>(m2, red, wave, lane);
 }
 template <int TSEL>
-MZ_DEV void put_boundary(const f32x4 (&acc)[3], float* dst, int ch, int lane) {
+MZ_DEV void put_boundary(const PairLink& L, const f32x4 (&acc)[3], pair_word* out, int first, int ch, int lane) {
   const int g = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int b = 16 * mt + 4 * g + v - PairGeom<TSEL>::send_first;
-      if (tile_on<TSEL>(mt) && b >= 0 && b < kPairBnd) pair_store(dst + b * kTowerC + ch, acc[mt][v]);
+      if (tile_on<TSEL>(mt) && b >= 0 && b < kPairBnd) pair_put(L, out, first + b * kTowerC + ch, acc[mt][v]);
     }
 }
 MZ_DEV void norm_tiles(f32x4 (&acc)[3], float mean, float rstd, const float* so, bool relu, int ch) {
@@ -691,20 +698,25 @@ MZ_DEV TowerIO tower_io(const TowerParams& p, int r) {
 template <int TSEL>
 MZ_DEV void pair_link_init(const TowerParams& p, int r, PairLink& L) {
   constexpr int h = TSEL - 1;
-  float* base = p.pair_f + (size_t)r * 4 * kPairSlot;
+  pair_word* base = reinterpret_cast<pair_word*>(p.pair_f) + (size_t)r * 4 * kPairSlot;
   unsigned* u = p.pair_u + (size_t)r * 4;
   L.mine = base + h * 2 * kPairSlot;
   L.theirs = base + (1 - h) * 2 * kPairSlot;
-  L.my_flag = u + h;
-  L.their_flag = u + (1 - h);
   L.status = u + 3;
   L.seq = u[2] * kPairMsgs;  // the launch epoch: written only at the very end of a launch, by half 0
   L.xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg(6164);  // hwreg(HW_REG_XCC_ID, 0, 4)
 }
 // One pass of recurrent_fn for one root (TSEL = 0) or one half of a root (TSEL = 1: pixels 0..15, TSEL = 2: pixels
 // 16..35; `L` = the half's link, initialised once per launch).
-template <int TSEL>
-MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, PairLink& L) {
+// `idle(k)`, k = 0, 1, ...: pair mode, 16-pixel half only -- called once per convolution pass after the reward head's
+// pixels are done (passes 9 .. 15 of an 8-block tower), between posting a message and waiting for the partner's: work
+// the caller wants done in that half's idle time (the fused search loads the tree path of the coming backup there).
+// A barrier follows every call.
+struct NoIdleWork {
+  MZ_DEV void operator()(int) const {}
+};
+template <int TSEL, class Idle = NoIdleWork>
+MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, PairLink& L, Idle&& idle = Idle()) {
   constexpr bool PAIR = TSEL != 0;
   using Geo = PairGeom<TSEL>;
   float* bufA = lds;
@@ -816,33 +828,34 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         float m[2], q[2];
         own_moments<2, TSEL>(pr, m, q, lane, wave, red);
         MZ_TT(4)
-        float* out = pair_out(L);
+        pair_word* out = pair_begin(L);
         if (tid == 0) {
-          pair_store(out, m[0]); pair_store(out + 1, q[0]); pair_store(out + 2, m[1]); pair_store(out + 3, q[1]);
-          pair_store(out + 4, __uint_as_float(L.xcc));
+          pair_put(L, out, 0, m[0]); pair_put(L, out, 1, q[0]); pair_put(L, out, 2, m[1]); pair_put(L, out, 3, q[1]);
+          pair_put(L, out, 4, __uint_as_float(L.xcc));
         }
-        put_boundary<TSEL>(pr[1], out + 8, ch, lane);
-        pair_post(L, tid);
+        put_boundary<TSEL>(L, pr[1], out, 8, ch, lane);
         MZ_TT(5)
         if constexpr (TSEL == 1) {
           if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+          else if (rh_k >= 9) idle(rh_k - 9);
           rh_k += 1;
           MZ_TT(1)
         }
-        const float* in = pair_wait(L, tid);
-        MZ_TT(6)
+        const pair_word* in = pair_in(L);
         float mean[2], rstd[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const float mo = pair_load(in + 2 * s), qo = pair_load(in + 2 * s + 1);
+          const float mo = pair_get(L, in, 2 * s), qo = pair_get(L, in, 2 * s + 1);
           if (TSEL == 1) merge_moments(m[s], q[s], mo, qo, mean[s], rstd[s]);
           else merge_moments(mo, qo, m[s], q[s], mean[s], rstd[s]);
         }
+        pair_check_xcc(L, in, tid);
+        MZ_TT(6)
         norm_tiles(pr[0], mean[0], rstd[0], so[0], false, ch);
         norm_tiles(pr[1], mean[1], rstd[1], so[1], true, ch);
         for (int i = tid; i < kPairBnd * kTowerC; i += 256) {
           const int c = i & 63;
-          const float o = (pair_load(in + 8 + i) - mean[1]) * rstd[1] * so[1][c] + so[1][kTowerC + c];
+          const float o = (pair_get(L, in, 8 + i) - mean[1]) * rstd[1] * so[1][c] + so[1][kTowerC + c];
           oth[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(o, 0.0f);
         }
       }
@@ -865,31 +878,32 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         float m[1], q[1];
         own_moments<1, TSEL>(out, m, q, lane, wave, red);
         MZ_TT(4)
-        float* msg = pair_out(L);
+        pair_word* msg = pair_begin(L);
         if (tid == 0) {
-          pair_store(msg, m[0]); pair_store(msg + 1, q[0]);
-          pair_store(msg + 4, __uint_as_float(L.xcc));
+          pair_put(L, msg, 0, m[0]); pair_put(L, msg, 1, q[0]);
+          pair_put(L, msg, 4, __uint_as_float(L.xcc));
         }
-        put_boundary<TSEL>(out[0], msg + 8, ch, lane);
-        put_boundary<TSEL>(pr[0], msg + 8 + kPairBnd * kTowerC, ch, lane);
-        pair_post(L, tid);
+        put_boundary<TSEL>(L, out[0], msg, 8, ch, lane);
+        put_boundary<TSEL>(L, pr[0], msg, 8 + kPairBnd * kTowerC, ch, lane);
         MZ_TT(5)
         if constexpr (TSEL == 1) {
           if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+          else if (rh_k >= 9) idle(rh_k - 9);
           rh_k += 1;
           MZ_TT(1)
         }
-        const float* in = pair_wait(L, tid);
-        MZ_TT(6)
+        const pair_word* in = pair_in(L);
         float mean, rstd;
-        const float mo = pair_load(in), qo = pair_load(in + 1);
+        const float mo = pair_get(L, in, 0), qo = pair_get(L, in, 1);
+        pair_check_xcc(L, in, tid);
+        MZ_TT(6)
         if (TSEL == 1) merge_moments(m[0], q[0], mo, qo, mean, rstd);
         else merge_moments(mo, qo, m[0], q[0], mean, rstd);
         norm_tiles(out[0], mean, rstd, so[0], false, ch);
         for (int i = tid; i < kPairBnd * kTowerC; i += 256) {
           const int c = i & 63;
-          const float o = (pair_load(in + 8 + i) - mean) * rstd * so[0][c] + so[0][kTowerC + c];
-          cur[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(pair_load(in + 8 + kPairBnd * kTowerC + i) + o, 0.0f);
+          const float o = (pair_get(L, in, 8 + i) - mean) * rstd * so[0][c] + so[0][kTowerC + c];
+          cur[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(pair_get(L, in, 8 + kPairBnd * kTowerC + i) + o, 0.0f);
         }
       }
     }
@@ -928,14 +942,14 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
     mn = fminf(mn, lane_xor16(mn)); mn = fminf(mn, lane_xor32(mn));
     mx = fmaxf(mx, lane_xor16(mx)); mx = fmaxf(mx, lane_xor32(mx));
   }
-  const float* fin = nullptr;
+  const pair_word* fin = nullptr;
   if constexpr (PAIR) {
     // message C: per-channel (min, max) of the own pixels; half 1 adds its 20 raw pixels for the heads
-    float* msg = pair_out(L);
-    if (tid == 0) pair_store(msg + 4, __uint_as_float(L.xcc));
+    pair_word* msg = pair_begin(L);
+    if (tid == 0) pair_put(L, msg, 4, __uint_as_float(L.xcc));
     if (lane < 16) {
-      pair_store(msg + 8 + ch, mn);
-      pair_store(msg + 8 + kTowerC + ch, mx);
+      pair_put(L, msg, 8 + ch, mn);
+      pair_put(L, msg, 8 + kTowerC + ch, mx);
     }
     if constexpr (TSEL == 2) {
       const int g = lane >> 4;
@@ -944,13 +958,13 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int px = 16 * mt + 4 * g + v;
-          if (px < kTowerPix) pair_store(msg + 8 + 2 * kTowerC + (px - 16) * kTowerC + ch, acc[mt][v]);
+          if (px < kTowerPix) pair_put(L, msg, 8 + 2 * kTowerC + (px - 16) * kTowerC + ch, acc[mt][v]);
         }
     }
-    pair_post(L, tid);
-    fin = pair_wait(L, tid);
-    mn = fminf(mn, pair_load(fin + 8 + ch));
-    mx = fmaxf(mx, pair_load(fin + 8 + kTowerC + ch));
+    fin = pair_in(L);
+    mn = fminf(mn, pair_get(L, fin, 8 + ch));
+    mx = fmaxf(mx, pair_get(L, fin, 8 + kTowerC + ch));
+    pair_check_xcc(L, fin, tid);
   }
   float scale = mx - mn;
   scale = scale < 1e-5f ? scale + 1e-5f : scale;
@@ -995,7 +1009,7 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         __syncthreads();
         for (int i = tid; i < 20 * kTowerC; i += 256) {
           const int c = i & 63;
-          const float raw = pair_load(fin + 8 + 2 * kTowerC + i);
+          const float raw = pair_get(L, fin, 8 + 2 * kTowerC + i);
           cur[map_word(16 + (i >> 6)) + c] = p.normalize ? (raw - cmn[c]) / cmn[kTowerC + c] : raw;
         }
       }

@@ -27,7 +27,7 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
     if (a->pair_scratch_bytes < need) return mzh::fail_global(MZS_E_INVALID, "mzs_resnet_tower: pair_scratch too small");
     if (2 * a->blocks + 1 > mz::kPairMsgs) return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resnet_tower: too many blocks for pair mode");
     p.pair_f = static_cast<float*>(a->pair_scratch);
-    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot);
+    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot * 2);  // (8-byte words)
     static bool pair_attr_dev[64] = {};
     bool& pair_attr = pair_attr_dev[a->device & 63];
     if (!pair_attr) {
@@ -59,7 +59,7 @@ int mzs_debug_tower_profile(uint64_t* host_out, int32_t words) {
 
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch) {
   if (batch <= 0 || batch > 128) return 0;  // 2 * batch workgroups have to be resident together
-  return (int64_t)batch * (4 * mz::kPairSlot * (int64_t)sizeof(float) + 4 * (int64_t)sizeof(unsigned));
+  return (int64_t)batch * (4 * mz::kPairSlot * 2 * (int64_t)sizeof(float) + 4 * (int64_t)sizeof(unsigned));
 }
 
 }  // extern "C"

@@ -84,14 +84,31 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
 #define MZ_ST(k)
 #endif
   for (int sim = loop.sim_begin; sim < loop.sim_end; ++sim) {
+    // pair mode: rows of the tree's embedding array hold pixels the partner's CU wrote in earlier simulations (in L2 by
+    // now: messages Y / T below); this CU's L1 may hold older copies of those lines
+    if constexpr (PAIRED) asm volatile("buffer_inv sc0" ::: "memory");
     io.x = s.embeddings + (rb + parent) * E;
     io.y = s.embeddings + (rb + newn) * E;
     io.action = action;
     const bool more = sim + 1 < loop.sim_end && sim + 1 < s.S;
     int sel[3] = {0, 0, 0};
     if (!PAIRED || h == 0) {
+      int prefetched = 0;
       if constexpr (PAIRED) {
-        tower_body<1>(p, io, lds, L);  // ... ends with the reward head's tail and the prediction heads of this root
+        // the half's idle time in passes 9 and 10: the path of the coming backup and its per-level inputs (they need
+        // nothing from this pass) go from the tree into LDS
+        const JumpLds JL = jump_lds(tree_lds, N);
+        const bool fresh = newn == sim + 1;
+        auto idle = [&](int k) {
+          if (k == 0) {
+            jump_prefetch_path(s, g, r, JL, tid, 256, parent, action, depth, newn, fresh);
+            prefetched |= 1;
+          } else if (k == 1) {
+            jump_prefetch_levels(s, r, JL, tid, 256, depth);
+            prefetched |= 2;
+          }
+        };
+        tower_body<1>(p, io, lds, L, idle);  // ... ends with the reward head's tail and the prediction heads of this root
         MZ_ST(0)
         if (pair_lost_uniform(L, tid, &lost_flag)) return;  // the host sees the status word and repeats the search
         MZ_ST(1)
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
       const float val = *reinterpret_cast<const volatile float*>(io.value);
       const int known[4] = {parent, action, depth, newn};
       jump_expand_backup_body<GUMBEL>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
-                                      nullptr, sel, known);
+                                      nullptr, sel, known, prefetched);
       MZ_ST(2)
       if (more) {
         parent = sel[0];
@@ -114,15 +131,20 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
         newn = next == -1 ? sim + 2 : next;
       }
       if constexpr (PAIRED) {
-        if (more) {  // message T: what the next pass works on
-          float* msg = pair_out(L);
+        // message Y of half 1 (number k): its pixels of this simulation's new embedding row are in L2 -- the next pass
+        // may read that row.  Half 0 posts nothing under that number.
+        L.seq += 1;
+        if (tid == 0) pair_check_xcc(L, pair_in(L), tid);
+        if (more) {
+          // message T (number k + 1): what the next pass works on; "strong": half 0's own pixels of the new row and the
+          // tree are complete before the partner can see it (and every thread is past message Y)
+          pair_word* msg = pair_begin_strong(L);
           if (tid == 0) {
-            pair_store(msg, __int_as_float(parent));
-            pair_store(msg + 1, __int_as_float(action));
-            pair_store(msg + 2, __int_as_float(newn));
-            pair_store(msg + 4, __uint_as_float(L.xcc));
+            pair_put(L, msg, 0, __int_as_float(parent));
+            pair_put(L, msg, 1, __int_as_float(action));
+            pair_put(L, msg, 2, __int_as_float(newn));
+            pair_put(L, msg, 4, __uint_as_float(L.xcc));
           }
-          pair_post(L, tid);
         } else {
           L.seq += 1;
         }
@@ -133,14 +155,22 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
       if constexpr (PAIRED) {
         tower_body<2>(p, io, lds, L);
         MZ_ST(0)
+        {  // message Y: every store of this half (its pixels of the new row) has completed
+          pair_word* msg = pair_begin_strong(L);
+          if (tid == 0) pair_put(L, msg, 4, __uint_as_float(L.xcc));
+        }
         L.seq += 1;  // (half 1 posts nothing under the number of message T)
         if (more) {
-          const float* in = pair_wait(L, tid);
+          const pair_word* in = pair_in(L);
+          parent = __float_as_int(pair_get(L, in, 0));
+          action = __float_as_int(pair_get(L, in, 1));
+          newn = __float_as_int(pair_get(L, in, 2));
+          pair_check_xcc(L, in, tid);
           MZ_ST(2)
           if (pair_lost_uniform(L, tid, &lost_flag)) return;
-          parent = min(max(__float_as_int(pair_load(in)), 0), N - 1);
-          action = min(max(__float_as_int(pair_load(in + 1)), 0), A - 1);
-          newn = min(max(__float_as_int(pair_load(in + 2)), 0), N - 1);
+          parent = min(max(parent, 0), N - 1);  // (a lost message must not turn into a wild address)
+          action = min(max(action, 0), A - 1);
+          newn = min(max(newn, 0), N - 1);
         }
       }
     }
@@ -206,7 +236,7 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
     if (need == 0) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: pair mode needs batch <= 128");
     if (a->pair_scratch_bytes < need) return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: pair_scratch too small");
     p.pair_f = static_cast<float*>(a->pair_scratch);
-    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot);
+    p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot * 2);  // (8-byte words)
     fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, true>)
                 : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true>);
     grid = dim3(16 * ((a->batch + 7) / 8));

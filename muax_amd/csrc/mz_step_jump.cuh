@@ -334,11 +334,63 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
 // the same root.  `prior_logits_row`: the root's A logits; `next_embedding_row` == nullptr: the caller has written the
 // new node's embedding row in place; `select_next`: also run simulate() of sim + 1 (sel_out[0..2] = its parent / action / depth
 // in every thread; `next_parent_embedding_out` == nullptr: no gather).
+// LDS of the body: per level e in [0, depth] (entry `depth` is the leaf), 15 arrays of N + 1 words
+struct JumpLds {
+  int *pn, *pa, *cnt;       // node at level e; action taken there (e < depth); node_visits before this backup
+  float *val, *rw, *ds;     // node_values before this backup; reward / discount of edge e
+  float *Gs, *nv;           // leaf_value arriving at level e; node value after this backup
+  int *bst, *chd, *flg;     // refreshed decision, its child index, near tie
+  int *cjp, *cjl;           // stored JUMP record of that child
+  int *njp, *njl;           // new JUMP record of the level's node
+  int *nxa, *nxb;           // pointer jumping (two buffers, in the backward pass's arrays, dead by then)
+};
+MZ_DEV JumpLds jump_lds(int* lds_i, int N) {
+  const int D1 = N + 1;
+  JumpLds L;
+  L.pn = lds_i; L.pa = L.pn + D1; L.cnt = L.pa + D1;
+  L.val = reinterpret_cast<float*>(L.cnt + D1); L.rw = L.val + D1; L.ds = L.rw + D1; L.Gs = L.ds + D1; L.nv = L.Gs + D1;
+  L.bst = reinterpret_cast<int*>(L.nv + D1); L.chd = L.bst + D1; L.flg = L.chd + D1; L.cjp = L.flg + D1; L.cjl = L.cjp + D1;
+  L.njp = L.cjl + D1; L.njl = L.njp + D1;
+  L.nxa = L.cnt; L.nxb = reinterpret_cast<int*>(L.val);
+  return L;
+}
+// The two pieces of the body that need nothing from recurrent_fn -- the fused search runs them while the root's
+// convolution passes wait for their partner (mz_search_conv.hip); a barrier must separate them and follow the second.
+// (1) path of the leaf: the parent's own root path + (parent, action); a fresh node gets its copy
+MZ_DEV void jump_prefetch_path(const StepArgs& s, const JumpArgs& g, int r, const JumpLds& L, int tid, int nthr, int parent,
+                               int action, int depth, int newn, bool fresh) {
+  const int N = s.N;
+  const size_t rb = (size_t)r * N;
+  for (int e = tid; e < depth; e += nthr) {
+    const uint32_t ent = (e < depth - 1) ? g.node_path[(rb + parent) * N + e] : ((uint32_t)parent | ((uint32_t)action << 16));
+    L.pn[e] = (int)(ent & 0xffffu);
+    L.pa[e] = (int)(ent >> 16);
+    if (fresh) g.node_path[(rb + newn) * N + e] = ent;
+  }
+  if (tid == 0) {
+    L.pn[depth] = newn;
+    L.pa[depth] = 0;
+    if (fresh) g.node_depth[rb + newn] = depth;
+  }
+}
+// (2) per-level inputs of the backward pass (the last edge's reward / discount come from recurrent_fn: filled in later)
+MZ_DEV void jump_prefetch_levels(const StepArgs& s, int r, const JumpLds& L, int tid, int nthr, int depth) {
+  const size_t rb = (size_t)r * s.N;
+  for (int e = tid; e < depth; e += nthr) {
+    const size_t e2 = (rb + L.pn[e]) * s.A + L.pa[e];
+    L.cnt[e] = s.node_visits[rb + L.pn[e]];
+    L.val[e] = s.node_values[rb + L.pn[e]];
+    L.rw[e] = (e == depth - 1) ? 0.0f : s.children_rewards[e2];
+    L.ds[e] = (e == depth - 1) ? 0.0f : s.children_discounts[e2];
+  }
+}
+
+// `prefetched`: bit 0 = jump_prefetch_path, bit 1 = jump_prefetch_levels have run for this simulation (and a barrier since)
 template <bool GUMBEL>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
-                                    int* sel_out = nullptr, const int* known = nullptr) {
+                                    int* sel_out = nullptr, const int* known = nullptr, int prefetched = 0) {
   const int tid = opaque_tid(), j = tid & 15, row = tid >> 4;
   MZ_JT_BEGIN
   const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 1024 / 256 threads (64 / 16 levels in flight) or one wavefront (4)
@@ -353,38 +405,14 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
   __syncthreads();  // every thread has read the edge before row 0 rewrites it
   const bool fresh = next == -1;
   const int newn = fresh ? sim + 1 : next;
-  // LDS: per level e in [0, depth] (entry `depth` is the leaf)
-  const int D1 = N + 1;
-  int* pn = lds_i;                 // node at level e
-  int* pa = pn + D1;               // action taken at level e (e < depth)
-  int* cnt = pa + D1;              // node_visits before this backup
-  float* val = reinterpret_cast<float*>(cnt + D1);  // node_values before this backup
-  float* rw = val + D1;            // reward of edge e
-  float* ds = rw + D1;             // discount of edge e
-  float* Gs = ds + D1;             // leaf_value arriving at level e
-  float* nv = Gs + D1;             // node value after this backup
-  int* bst = reinterpret_cast<int*>(nv + D1);  // refreshed decision
-  int* chd = bst + D1;             // its child index
-  int* flg = chd + D1;             // near tie
-  int* cjp = flg + D1;             // stored JUMP record of that child
-  int* cjl = cjp + D1;
-  int* njp = cjl + D1;             // new JUMP record of the level's node
-  int* njl = njp + D1;
-  int* nxa = cnt;                  // pointer jumping: the level whose record level e takes (two buffers, in the
-  int* nxb = reinterpret_cast<int*>(val);  // backward pass's arrays, dead by then)
+  const JumpLds JL = jump_lds(lds_i, N);
+  int* const pn = JL.pn; int* const pa = JL.pa; int* const cnt = JL.cnt;
+  float* const val = JL.val; float* const rw = JL.rw; float* const ds = JL.ds; float* const Gs = JL.Gs; float* const nv = JL.nv;
+  int* const bst = JL.bst; int* const chd = JL.chd; int* const flg = JL.flg; int* const cjp = JL.cjp; int* const cjl = JL.cjl;
+  int* const njp = JL.njp; int* const njl = JL.njl; int* const nxa = JL.nxa; int* const nxb = JL.nxb;
 
   // -- path of the leaf: the parent's own root path + (parent, action) --
-  for (int e = tid; e < depth; e += nthr) {
-    const uint32_t ent = (e < depth - 1) ? g.node_path[(rb + parent) * N + e] : ((uint32_t)parent | ((uint32_t)action << 16));
-    pn[e] = (int)(ent & 0xffffu);
-    pa[e] = (int)(ent >> 16);
-    if (fresh) g.node_path[(rb + newn) * N + e] = ent;
-  }
-  if (tid == 0) {
-    pn[depth] = newn;
-    pa[depth] = 0;
-    if (fresh) g.node_depth[rb + newn] = depth;
-  }
+  if (!(prefetched & 1)) jump_prefetch_path(s, g, r, JL, tid, nthr, parent, action, depth, newn, fresh);
   // -- expand (row 0): prior of the new node, node and edge records --
   if (row == 0) {
     float x[kMaxAS], pr[kMaxAS];
@@ -420,32 +448,35 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
   __syncthreads();
   MZ_JT(0)
   // -- per-level inputs of the backward pass --
-  for (int e = tid; e < depth; e += nthr) {
-    const size_t e2 = (rb + pn[e]) * A + pa[e];
-    cnt[e] = s.node_visits[rb + pn[e]];
-    val[e] = s.node_values[rb + pn[e]];
-    rw[e] = (e == depth - 1) ? rew_new : s.children_rewards[e2];
-    ds[e] = (e == depth - 1) ? dis_new : s.children_discounts[e2];
+  if (!(prefetched & 2)) jump_prefetch_levels(s, r, JL, tid, nthr, depth);
+  if (tid == (depth - 1) % nthr && depth > 0) {  // (the thread that wrote the entry, if it was written just now)
+    rw[depth - 1] = rew_new;
+    ds[depth - 1] = dis_new;
   }
   __syncthreads();
   MZ_JT(1)
   // -- leaf_value = reward + discount * leaf_value, leaf to root (the one sequential chain) --
-  // One wavefront, 64 levels per chunk in registers: a step is two v_readlane (off the chain) + mul + add on the
-  // wave-uniform G, ~25 cycles, instead of an LDS round trip per level on a lone thread (~90) -- the paths of a long
-  // search on few roots are 50 .. 150 levels deep and this chain paced the launch.  Same operations, same order.
+  // One wavefront, 63 levels per chunk, every lane its own level: one step is X[e] = r[e] + d[e] * X[e + 1] on all
+  // lanes at once -- v_mul_f32_dpp wave_shl:1 + v_add_f32 (+ a select for the lanes past the chunk, which hold the
+  // value arriving from below) -- and level e is final after (levels of the chunk - e) steps: ~25 cycles per level
+  // (round 3: two v_readlane + mul + add + select per level on the wave-uniform G, ~140 cycles as compiled; before
+  // that an LDS round trip per level on a lone thread).  The paths of a long search on few roots are 50 .. 150 levels
+  // deep and this chain paces the root.  Same operations in the same order for every level: same bits.
   if (tid < 64) {
     float G = v;
-    for (int c = (depth - 1) >> 6; c >= 0; --c) {
-      const int e = 64 * c + tid;
-      const int rr = __float_as_int(e < depth ? rw[e] : 0.0f), dd = __float_as_int(e < depth ? ds[e] : 0.0f);
-      float mine = 0.0f;
-      for (int k = min(63, depth - 1 - 64 * c); k >= 0; --k) {
-        const float rk = __int_as_float(__builtin_amdgcn_readlane(rr, k));
-        const float dk = __int_as_float(__builtin_amdgcn_readlane(dd, k));
-        G = rk + dk * G;
-        mine = tid == k ? G : mine;
+    for (int c = (depth - 1) / 63; c >= 0; --c) {
+      const int e = 63 * c + tid;
+      const int cn = min(63, depth - 63 * c);
+      const bool mine = tid < cn;
+      const float rr = mine ? rw[e] : 0.0f, dd = mine ? ds[e] : 0.0f;
+      float X = G;
+      for (int k = 0; k < cn; ++k) {
+        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), 0x130, 0xf, 0xf, false));  // wave_shl:1
+        const float t = rr + dd * up;
+        X = mine ? t : G;
       }
-      if (e < depth) Gs[e] = mine;
+      if (mine) Gs[e] = X;
+      G = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(X)));  // arrival at the chunk's first level
     }
   }
   __syncthreads();

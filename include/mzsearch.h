@@ -342,6 +342,25 @@ int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Fused-kernel instances built on demand.
+ *
+ * mzs_act_mlp serves the (num_actions, embedding_dim, support_size, num_simulations) shapes compiled into the library
+ * (muax_amd/csrc/mz_instances.def) and returns MZS_E_UNSUPPORTED for others, although the reference's act() takes any
+ * (muax/model.py:82-96).  A host that has hipcc can close the gap at run time: compile muax_amd/csrc/mz_fused_jit.hip for
+ * the missing shape into a side library (muax_amd/_jit.py does), dlopen it and pass its
+ * mzs_jit_dispatch() / mzs_jit_abi() here; later mzs_act_mlp calls (any handle) try the registered instances after the
+ * built-in ones.  `jit_abi` must equal mzs_fused_jit_abi() (same kernel-argument layout). */
+int mzs_register_fused_dispatch(void *dispatch, int32_t jit_abi);
+int mzs_fused_jit_abi(void);
+/* Shapes the fused kernel cannot be instantiated for at all (more than 8 actions, more than 127 simulations, embeddings
+ * wider than 64): allow != 0 lets mzs_act_mlp / mzs_act_mlp_host serve them through the generic route instead of
+ * returning MZS_E_UNSUPPORTED -- the trio with run-time shapes (num_actions <= 64, support_size 8..31), tree in HBM with
+ * cached decisions, ONE launch for all simulations plus root / select / finish launches (mz_mlp_generic.cuh).  Same
+ * arithmetic spec, same results bit for bit as an instance would give; several times slower per simulation than a
+ * tuned instance, an order of magnitude faster than per-simulation launches with the caller's own nets. */
+int mzs_mlp_allow_generic(mzs_handle *h, int32_t allow);
+
+/* ------------------------------------------------------------------------------------------------------------
  * The simulation loop of a search with the ResNet nets in ONE launch (mz_search_conv.hip).
  *
  * Replaces, for simulations [sim_begin, sim_end) of a search on handle `h` (rooted with mzs_root / mzs_root_gumbel and

@@ -20,7 +20,7 @@ _FUSED = ["mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cu
 # translation unit -> the headers it is rebuilt for
 UNITS = {
     "mz_api.hip": ["mz_host.h", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_step.cuh", "mz_step_jump.cuh",
-                   "mz_train.cuh", "mz_dirichlet.cuh", _ABI],
+                   "mz_mlp_generic.cuh", "mz_train.cuh", "mz_dirichlet.cuh", _ABI],
     "mz_fused_g0.hip": _FUSED,
     "mz_fused_g1.hip": _FUSED,
     "mz_fused_g2.hip": _FUSED,

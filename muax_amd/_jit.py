@@ -1,0 +1,125 @@
+"""On-demand instances of the fused act() kernel (muax_amd/csrc/mz_fused_jit.hip).
+
+libmzsearch.so carries the (num_actions, embedding_dim, support slots, tree size) instances listed in
+muax_amd/csrc/mz_instances.def; the reference's act() takes ANY num_simulations / network widths (muax/model.py:82-96,
+muax/nn.py:59-115).  When mzs_act_mlp has no instance for a shape and a hipcc is present, `ensure_instance` compiles one
+translation unit for that shape (~25 s, once: cached as muax_amd/lib/jit/<shape>-<source hash>.so), loads it and registers
+it with the library (mzs_register_fused_dispatch) -- the shape then runs as ONE launch per act() like a listed one, same
+kernel source, same bits.  Shapes outside the kernel's own limits (more than 8 actions, more than 127 simulations,
+embeddings wider than 64) cannot be instantiated: they take the one-launch generic search (mzs_mlp_search) or the
+step-wise path.  MUAX_AMD_JIT=0 turns the on-demand build off.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+from . import _build
+
+JIT_DIR = os.path.join(_build.LIB_DIR, "jit")
+_SOURCES = ["mz_fused_jit.hip", "mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh"]
+_loaded = {}   # shape -> CDLL (kept alive: the library calls into it)
+_failed = set()
+
+
+def _ceil_log2(n: int) -> int:
+    return 0 if n <= 1 else 1 + _ceil_log2((n + 1) // 2)
+
+
+def lds_bytes(A: int, E: int, NMAX: int, WAVES: int) -> int:
+    """FusedCfg::LDS_BYTES of a plain (non-compact) instance, widest record (the Gumbel modes) -- mz_fused.cuh."""
+    selw = ((2 * A + 3) // 4) * 4
+    st0 = selw + 4
+    path0 = st0 + 5 * A + (E if E <= 16 else 0)
+    entry = 8 if _ceil_log2(NMAX) + max(1, _ceil_log2(A)) <= 8 else 16
+    pathw = (NMAX * entry + 31) // 32
+    ns = (path0 + pathw) | 1
+    tree = ((ns * NMAX + 3) // 4) * 4
+    root = tree + ((8 - tree % 32 + 32) % 32)
+    tbl = 2 * (((NMAX + 2 + 3) // 4) * 4)
+    return 4 * (tbl + 4 * WAVES * root)
+
+
+def plan(A: int, E: int, F: int, S: int):
+    """(FS, NMAX, WAVES) of an instance that serves the shape, or None when the kernel's own limits rule it out."""
+    if not (1 <= A <= 8 and 17 <= F <= 63 and S >= 1):
+        return None
+    if E < 1 or E > 64 or (E > 16 and E % 8):
+        return None
+    FS = 2 if F <= 32 else 4
+    for NMAX in (51, 64, 101, 128):
+        if S + 1 > NMAX:
+            continue
+        entry = 8 if _ceil_log2(NMAX) + max(1, _ceil_log2(A)) <= 8 else 16
+        pathw = (NMAX * entry + 31) // 32
+        if (pathw + 15) // 16 > 4 or A > pathw:
+            continue
+        for W in (4, 3, 2, 1):
+            if lds_bytes(A, E, NMAX, W) <= 160 * 1024:
+                return FS, NMAX, W
+    return None
+
+
+def _source_hash() -> str:
+    h = hashlib.sha256()
+    for f in _SOURCES:
+        with open(os.path.join(_build.CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def ensure_instance(A: int, E: int, F: int, S: int, verbose: bool = False) -> bool:
+    """Make sure mzs_act_mlp can serve (A, E, F, S) with one launch: True when an on-demand instance is registered
+    (built now or earlier), False when the shape cannot be instantiated, there is no compiler, or MUAX_AMD_JIT=0."""
+    if os.environ.get("MUAX_AMD_JIT", "1") == "0":
+        return False
+    pl = plan(A, E, F, S)
+    if pl is None:
+        return False
+    FS, NMAX, W = pl
+    shape = (A, E, FS, NMAX, W)
+    if shape in _loaded:
+        return True
+    if shape in _failed:
+        return False
+    try:
+        cc = _build.hipcc()
+    except RuntimeError:
+        return False
+    tag = f"a{A}_e{E}_fs{FS}_n{NMAX}_w{W}-{_source_hash()}"
+    so = os.path.join(JIT_DIR, f"mzfused_{tag}.so")
+    os.makedirs(JIT_DIR, exist_ok=True)
+    if not os.path.exists(so):
+        import fcntl
+        with open(os.path.join(JIT_DIR, ".jit.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)  # ranks that miss the same shape build it once
+            if not os.path.exists(so):
+                deff = os.path.join(JIT_DIR, f"inst_{tag}.def")
+                with open(deff, "w") as f:
+                    f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, false)\n")
+                tmp = so + f".tmp{os.getpid()}"
+                cmd = [cc] + _build.FLAGS + _build.UNIT_FLAGS["mz_fused_g0.hip"] + [
+                    f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
+                    os.path.join(_build.CSRC, "mz_fused_jit.hip"), "-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
+                try:
+                    subprocess.check_call(cmd, stdout=subprocess.DEVNULL if not verbose else None,
+                                          stderr=subprocess.DEVNULL if not verbose else None)
+                    os.replace(tmp, so)
+                except (subprocess.CalledProcessError, OSError):
+                    _failed.add(shape)
+                    return False
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+    from . import _lib
+    L = _lib.load()
+    side = C.CDLL(so)
+    side.mzs_jit_dispatch.restype = C.c_void_p
+    side.mzs_jit_abi.restype = C.c_int
+    _lib.check(L.mzs_register_fused_dispatch(C.c_void_p(side.mzs_jit_dispatch()), side.mzs_jit_abi()))
+    _loaded[shape] = side
+    return True

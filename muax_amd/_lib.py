@@ -104,7 +104,8 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_finish", "mzs_tree_export", "mzs_mlp_loss_grad", "mzs_mlp_num_params",
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
-                    "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search"]
+                    "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
+                    "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic"]
 
 _lib = None
 
@@ -139,6 +140,8 @@ def load(build_if_missing: bool = True):
     L.mzs_tree_export.argtypes = [_vp, C.POINTER(MzsTreeView), _vp]
     L.mzs_mlp_loss_grad.argtypes = [C.POINTER(MzsMlpWeights), C.POINTER(MzsTrainArgs), _vp]
     L.mzs_resnet_tower.argtypes = [C.POINTER(MzsTowerArgs), _vp]
+    L.mzs_register_fused_dispatch.argtypes = [_vp, C.c_int32]
+    L.mzs_mlp_allow_generic.argtypes = [_vp, C.c_int32]
     L.mzs_resnet_search.argtypes = [_vp, C.POINTER(MzsTowerArgs), C.c_float, C.c_int32, C.c_int32, _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4
     L.mzs_mlp_train_workspace_bytes.argtypes = [C.c_int32] * 5

@@ -14,6 +14,7 @@
 #include "mz_fused_launch.h"
 #include "mz_step.cuh"
 #include "mz_step_jump.cuh"
+#include "mz_mlp_generic.cuh"
 #include "mz_train.cuh"
 #include "mz_dirichlet.cuh"
 
@@ -24,6 +25,10 @@ thread_local std::string g_create_error;
 namespace {
 
 using mzh::g_create_error;
+
+// fused-kernel instances built on demand and registered at run time (mzs_register_fused_dispatch; muax_amd/_jit.py)
+std::mutex g_jit_mutex;
+std::vector<mz::FusedDispatch> g_jit_dispatch;
 
 // ---- host-side JAX threefry (key bookkeeping only: 3 blocks per simulation) ----
 inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -77,6 +82,8 @@ struct mzs_handle {
   mz::JumpArgs jump = {nullptr, nullptr, nullptr, nullptr};  // step-wise path with cached decisions
   void* jump_slab = nullptr;
   bool use_jump = false;
+  bool allow_generic = false;      // mzs_mlp_allow_generic: shapes without a fused instance take the generic one-launch search
+  float* gen_scratch = nullptr;    // generic route: prior logits [B, A] | embeddings [B, E] | actions [B]
 };
 
 namespace {
@@ -168,6 +175,7 @@ static int launch_train(const mz::TrainParams& p, hipStream_t stream) {
 extern "C" {
 
 int mzs_abi_version(void) { return MZS_ABI_VERSION; }
+int mzs_fused_jit_abi(void) { return MZS_ABI_VERSION * 1000 + (int)(sizeof(mz::FusedParams) % 1000); }
 
 const char* mzs_last_error(const mzs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -207,6 +215,12 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
   return MZS_OK;
 }
 
+int mzs_mlp_allow_generic(mzs_handle* h, int32_t allow) {
+  if (!h) return MZS_E_INVALID;
+  h->allow_generic = allow != 0;
+  return MZS_OK;
+}
+
 int mzs_destroy(mzs_handle* h) {
   if (!h) return MZS_OK;
   hipSetDevice(h->cfg.device);
@@ -218,6 +232,7 @@ int mzs_destroy(mzs_handle* h) {
   if (h->host_in) hipHostFree(h->host_in);
   if (h->host_out) hipHostFree(h->host_out);
   if (h->dev_noise) hipFree(h->dev_noise);
+  if (h->gen_scratch) hipFree(h->gen_scratch);
   delete h;
   return MZS_OK;
 }
@@ -232,6 +247,68 @@ int mzs_mlp_set_weights(mzs_handle* h, const mzs_mlp_weights* w) {
   if (w->obs_dim <= 0 || w->support_size <= 0) return fail(h, MZS_E_INVALID, "mzs_mlp_set_weights: obs_dim/support_size");
   h->w = *w;
   h->have_weights = true;
+  return MZS_OK;
+}
+
+static int ensure_step_state(mzs_handle* h);
+// act() of the default MLP trio for shapes the fused kernel has no instance for (mz_mlp_generic.cuh): root inference,
+// mzs_root, mzs_select(0), ONE launch for all simulations, mzs_finish -- five launches per act instead of two per
+// simulation, the nets evaluated by the library to the project's arithmetic spec (== the oracle for any shape).
+static int act_mlp_generic(mzs_handle* h, const mzs_act_args* a, void* stream_) {
+  const mzs_config& c = h->cfg;
+  const mzs_mlp_weights& w = h->w;
+  const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, S = c.num_simulations;
+  if (F < 17 || F > 64 || A > 64)
+    return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): support_size must be 8..31 and num_actions <= 64");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (int rc = ensure_step_state(h)) return rc;
+  if (!h->use_jump)
+    return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): tree beyond the cached-decision budget; use the step-wise path");
+  const size_t B = (size_t)c.batch;
+  if (!h->gen_scratch) MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->gen_scratch), (B * A + B * E + B) * sizeof(float)));
+  float* pl = h->gen_scratch;
+  float* emb = pl + B * A;
+  int32_t* act0 = reinterpret_cast<int32_t*>(emb + B * E);
+  mz::MlpGen g;
+  g.repr_w = w.repr_w; g.repr_b = w.repr_b;
+  g.pv_w1 = w.pv_w1; g.pv_b1 = w.pv_b1; g.pv_w2 = w.pv_w2; g.pv_b2 = w.pv_b2;
+  g.pp_w1 = w.pp_w1; g.pp_b1 = w.pp_b1; g.pp_w2 = w.pp_w2; g.pp_b2 = w.pp_b2;
+  g.dr_w1 = w.dr_w1; g.dr_b1 = w.dr_b1; g.dr_w2 = w.dr_w2; g.dr_b2 = w.dr_b2;
+  g.dn_w1 = w.dn_w1; g.dn_b1 = w.dn_b1; g.dn_w2 = w.dn_w2; g.dn_b2 = w.dn_b2;
+  g.obs_dim = w.obs_dim; g.E = E; g.A = A; g.F = F; g.support = w.support_size; g.pred_on_parent = w.recurrent_pred_on;
+  g.discount = w.discount;
+  const int ew = E > w.obs_dim ? E : w.obs_dim;
+  const size_t lds_root = sizeof(float) * (size_t)mz::gen_scratch_words(ew, A);
+  const size_t lds_search = sizeof(int32_t) * 15 * ((size_t)S + 2) + sizeof(float) * (size_t)mz::gen_scratch_words(E, A);
+  if (lds_root > 64 * 1024 || lds_search > 64 * 1024)
+    return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): num_simulations / embedding too large for the LDS of a workgroup");
+  hipLaunchKernelGGL(mz::mz_mlp_root_kernel, dim3(c.batch), dim3(64), lds_root, stream, g, c.batch, a->obs, pl, a->root_value, emb);
+  MZS_HIP(h, hipGetLastError());
+  int rc = c.policy == 1 ? mzs_root_gumbel(h, pl, a->root_value, emb, a->invalid_actions, a->gumbel, a->key, stream_)
+                         : mzs_root(h, pl, a->root_value, emb, a->invalid_actions, a->dirichlet_noise, a->dirichlet_fraction,
+                                    a->key, stream_);
+  if (rc) return rc;
+  if ((rc = mzs_select(h, 0, act0, emb, stream_))) return rc;  // simulate() of simulation 0 (emb: consumed by mzs_root, reused)
+  mz::StepArgs sa = h->step.args(c);
+  if (c.policy == 1)
+    hipLaunchKernelGGL(mz::mz_mlp_search_kernel<true>, dim3(c.batch), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
+  else
+    hipLaunchKernelGGL(mz::mz_mlp_search_kernel<false>, dim3(c.batch), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
+  MZS_HIP(h, hipGetLastError());
+  if ((rc = mzs_finish(h, a->temperature, c.policy == 1 ? nullptr : a->gumbel, a->action, a->action_weights, a->search_value,
+                       a->depth_sum, stream_)))
+    return rc;
+  if (a->tree) return mzs_tree_export(h, a->tree, stream_);
+  return MZS_OK;
+}
+
+int mzs_register_fused_dispatch(void* dispatch, int32_t jit_abi) {
+  if (!dispatch) return fail(nullptr, MZS_E_INVALID, "mzs_register_fused_dispatch: null");
+  if (jit_abi != mzs_fused_jit_abi()) return fail(nullptr, MZS_E_INVALID, "mzs_register_fused_dispatch: the side library was built from other sources (ABI)");
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  for (auto f : g_jit_dispatch)
+    if (reinterpret_cast<void*>(f) == dispatch) return MZS_OK;
+  g_jit_dispatch.push_back(reinterpret_cast<mz::FusedDispatch>(dispatch));
   return MZS_OK;
 }
 
@@ -307,12 +384,18 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   const int A = c.num_actions, E = c.embed_dim, F = 2 * w.support_size + 1, N = c.num_simulations + 1;
   p.F = F;
   const int mode = c.policy == 1 ? (c.qtransform == 1 ? 3 : 2) : (c.tiebreak ? 1 : 0);
-  const mz::FusedDispatch groups[] = {mz::fused_dispatch_g0, mz::fused_dispatch_g1, mz::fused_dispatch_g2,
-                                      mz::fused_dispatch_g3, mz::fused_dispatch_g4};
+  std::vector<mz::FusedDispatch> groups = {mz::fused_dispatch_g0, mz::fused_dispatch_g1, mz::fused_dispatch_g2,
+                                           mz::fused_dispatch_g3, mz::fused_dispatch_g4};
+  {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);  // instances built on demand (mzs_register_fused_dispatch)
+    groups.insert(groups.end(), g_jit_dispatch.begin(), g_jit_dispatch.end());
+  }
+  // (tools/bench_generic.py: MZS_FORCE_GENERIC=1 sends a shape that HAS an instance through the generic route, for A/B timing)
+  if (h->allow_generic && getenv("MZS_FORCE_GENERIC") != nullptr) return act_mlp_generic(h, a, stream_);
   // more 16-root workgroups than CUs: prefer a compact-record instance (two workgroups per CU), if the shape has one
   for (int compact = (c.batch > 16 * h->cu_count) ? 1 : 0; compact >= 0; --compact) {
     p.path_scratch = compact ? h->fused_path : nullptr;
-    for (size_t gi = 0; gi < sizeof groups / sizeof groups[0]; ++gi) {
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
       std::string err;
       int rc = groups[gi](mode, c.device, p, stream, A, E, F, N, compact != 0, &err);
       if (rc == mz::kNeedPathScratch) {  // first compact launch of this handle: the HBM array of the root paths
@@ -326,6 +409,7 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
       return MZS_OK;
     }
   }
+  if (h->allow_generic) return act_mlp_generic(h, a, stream_);
   return fail(h, MZS_E_UNSUPPORTED,
               "mzs_act_mlp: no fused kernel instance for this (A, E, F, S) (muax_amd/csrc/mz_instances.def); use the step-wise path");
 }

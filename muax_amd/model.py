@@ -231,6 +231,26 @@ class MuZero:
             discount = torch.ones_like(r) * self._discount
         return (r, discount, logits, v), next_embedding
 
+    def _with_jit(self, A, E, S, call, handle=None):
+        """call() -- a fused act(); when the library has no instance of the kernel for this shape, build one on demand
+        (muax_amd/_jit.py: one translation unit, cached on disk) and call again; a shape outside the kernel's limits (more
+        than 8 actions, more than 127 simulations, ...) switches `handle` to the library's generic one-launch search
+        (mzs_mlp_allow_generic).  Re-raises the ValueError when neither applies: the caller then runs the step-wise
+        path with the torch modules."""
+        try:
+            return call()
+        except ValueError as e:
+            if "no fused kernel instance" not in str(e):
+                raise
+            from . import _jit
+            if _jit.ensure_instance(A, E, 2 * self._support_size + 1, S):
+                return call()
+            # outside the fused kernel's limits (or no compiler): the generic one-launch search of the library
+            if os.environ.get("MUAX_AMD_GENERIC", "1") == "0" or handle is None:
+                raise
+            handle.allow_generic()
+            return call()
+
     def _native_loop(self, root):
         """The one-launch simulation loop, when the nets are ones the library evaluates itself (the reference's ResNet
         nets with the prediction net on the child's embedding): a callable for MuZeroSearch.search, else None."""
@@ -293,10 +313,13 @@ class MuZero:
                 h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
                                        1.25, 19652, False, "gumbel", qtransform, max_num_considered_actions,
                                        gumbel_scale, global_batch, root_offset)
+                E_ = self.repr_func.embedding_dim
                 if host_io:
-                    a_, w_, v_ = h.act_mlp_host(obs, key, dirichlet_fraction=0.0, invalid_actions=invalid_actions)
+                    a_, w_, v_ = self._with_jit(A, E_, num_simulations, lambda: h.act_mlp_host(
+                        obs, key, dirichlet_fraction=0.0, invalid_actions=invalid_actions), h)
                     return PolicyOutput(a_, w_, None), v_
-                out = h.act_mlp(obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree)
+                out = self._with_jit(A, E_, num_simulations, lambda: h.act_mlp(
+                    obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree), h)
                 self._last_fused = h
                 return out, h.root_value
             except ValueError as e:
@@ -320,9 +343,9 @@ class MuZero:
             try:  # NumPy in, NumPy out: one C call (staging, root-noise draw from the key, search, one download, sync)
                 h = self._fused_handle(B, A, self.repr_func.embedding_dim, obs.shape[1], num_simulations, max_depth,
                                        pb_c_init, pb_c_base, tiebreak, global_batch=global_batch, root_offset=root_offset)
-                a_, w_, v_ = h.act_mlp_host(obs, key, dirichlet_noise=dirichlet_noise,
-                                            dirichlet_fraction=dirichlet_fraction, dirichlet_alpha=dirichlet_alpha,
-                                            invalid_actions=invalid_actions, temperature=temperature)
+                a_, w_, v_ = self._with_jit(A, self.repr_func.embedding_dim, num_simulations, lambda: h.act_mlp_host(
+                    obs, key, dirichlet_noise=dirichlet_noise, dirichlet_fraction=dirichlet_fraction,
+                    dirichlet_alpha=dirichlet_alpha, invalid_actions=invalid_actions, temperature=temperature), h)
                 return PolicyOutput(a_, w_, None), v_
             except ValueError as e:
                 if "no fused kernel instance" not in str(e):
@@ -339,9 +362,9 @@ class MuZero:
             try:
                 h = self._fused_handle(B, A, E, obs.shape[1], num_simulations, max_depth, pb_c_init, pb_c_base,
                                        tiebreak, global_batch=global_batch, root_offset=root_offset)
-                out = h.act_mlp(obs, key, dirichlet_noise=dirichlet_noise, dirichlet_fraction=dirichlet_fraction,
-                                invalid_actions=invalid_actions, temperature=temperature, gumbel=gumbel,
-                                with_tree=with_tree)
+                out = self._with_jit(A, E, num_simulations, lambda: h.act_mlp(
+                    obs, key, dirichlet_noise=dirichlet_noise, dirichlet_fraction=dirichlet_fraction,
+                    invalid_actions=invalid_actions, temperature=temperature, gumbel=gumbel, with_tree=with_tree), h)
                 self._last_fused = h
                 return out, h.root_value
             except ValueError as e:
@@ -363,15 +386,17 @@ class MuZero:
     _warned_stepwise = set()
 
     def _warn_stepwise(self, A, E, S, err):
-        """Loud, once per shape: the default MLP trio normally runs as ONE fused launch per act(); a shape without
-        a compiled instance drops to the step-wise kernels + torch modules (tens of launches per simulation)."""
+        """Loud, once per shape: the default MLP trio normally runs inside the library (a fused instance, one built on
+        demand, or the generic one-launch search); a shape none of them takes (support_size outside 8..31, more than 64
+        actions, MUAX_AMD_JIT=0 and MUAX_AMD_GENERIC=0) drops to the step-wise kernels + torch modules."""
         key = (A, E, self._support_size, S)
         if key not in MuZero._warned_stepwise:
             MuZero._warned_stepwise.add(key)
             import warnings
-            warnings.warn(f"muax_amd: no fused act() kernel for num_actions={A}, embedding_dim={E}, support_size="
+            warnings.warn(f"muax_amd: no in-library act() route for num_actions={A}, embedding_dim={E}, support_size="
                           f"{self._support_size}, num_simulations={S} ({err}); falling back to the step-wise search "
-                          f"with torch modules, which is far slower (about 70x at 4096 roots x 50 simulations)",
+                          f"with torch modules, which is far slower (about 70x a tuned instance at 4096 roots x 50 "
+                          f"simulations; the generic one-launch route is about 16x)",
                           RuntimeWarning, stacklevel=4)
 
     def _checked_search(self, run):

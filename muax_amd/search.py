@@ -252,6 +252,11 @@ class MuZeroSearch:
         _lib.check(self._L.mzs_mlp_set_weights(self._h, C.byref(w)), self._h)
         self._weights = (keep, obs_dim)  # keep the device buffers alive
 
+    def allow_generic(self, allow: bool = True):
+        """Let act_mlp / act_mlp_host serve default-trio shapes without a fused-kernel instance through the library's
+        generic one-launch search (mzs_mlp_allow_generic) instead of raising "no fused kernel instance"."""
+        _lib.check(self._L.mzs_mlp_allow_generic(self._h, int(bool(allow))), self._h)
+
     def act_mlp(self, obs, key, dirichlet_noise=None, dirichlet_fraction: float = 0.25,
                 invalid_actions=None, temperature: float = 1.0, gumbel=None,
                 with_tree: bool = False) -> PolicyOutput:

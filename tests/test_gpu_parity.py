@@ -416,19 +416,96 @@ def test_stepwise_single_deep_line_beyond_64_levels(oracle):
     _stepwise_vs_oracle(oracle, case, 120, False)
 
 
-def test_model_act_falls_back_to_stepwise_above_fused_limits():
-    """num_simulations = 160 has no fused instance for the default trio: act() must still work (step-wise
-    kernels + torch nets) and keep the reference's conventions."""
+def _fused_any(case, tiebreak, key, route, policy="muzero", **kw):
+    """_fused for a shape without a listed instance: `route` = "jit" (build one on demand) or "generic"."""
+    from muax_amd import MuZeroSearch, SearchConfig, _jit
+    cfg = SearchConfig(case["A"], case["S"], case["E"], tiebreak=tiebreak, policy=policy, **kw)
+    s = MuZeroSearch(case["B"], cfg)
+    s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"], case["support"], 0.99,
+                      kw.get("pred_on", "child"))
+    args = dict(invalid_actions=None if case["invalid"] is None else torch.from_numpy(case["invalid"]), with_tree=True,
+                gumbel=torch.from_numpy(case["gumbel"]))
+    if policy == "muzero":
+        args["dirichlet_noise"] = torch.from_numpy(case["noise"])
+    with pytest.raises(ValueError, match="no fused kernel instance"):
+        s.act_mlp(torch.from_numpy(case["obs"]), key, **args)
+    if route == "jit":
+        assert _jit.ensure_instance(case["A"], case["E"], case["F"], case["S"])
+    else:
+        assert _jit.plan(case["A"], case["E"], case["F"], case["S"]) is None  # no instance can exist for it
+        s.allow_generic()
+    out = s.act_mlp(torch.from_numpy(case["obs"]), key, **args)
+    torch.cuda.synchronize()
+    return s, out
+
+
+@pytest.mark.parametrize("A,E,S,B,support", [(5, 12, 30, 90, 10), (2, 8, 50, 70, 20), (7, 24, 80, 33, 10)])
+def test_fused_instance_built_on_demand_matches_oracle(oracle, A, E, S, B, support):
+    """Shapes mz_instances.def does not list (5 actions x 12-wide embedding; support_size 20 with F = 41 at CartPole
+    widths is listed, 7 actions x 24 at 80 simulations is not ...): mzs_act_mlp refuses, muax_amd/_jit.py compiles ONE
+    translation unit for the shape with the hipcc of this box, registers it, and the same call then runs as one launch --
+    every tree array equal to the oracle's."""
+    from muax_amd import _jit
+    if _jit.plan(A, E, 2 * support + 1, S) is None:
+        pytest.skip("outside the fused kernel's limits")
+    case = make_case(oracle, 300 + A + E, B, 6, E, A, S, support=support, invalid_frac=0.2 if A > 2 else 0.0)
+    key = [31, A]
+    try:
+        s, out = _fused_any(case, True, key, "jit")
+    except BaseException as e:  # (a listed shape does not raise "no fused kernel instance": nothing to build)
+        if "DID NOT RAISE" in str(e):
+            pytest.skip("the library already has an instance for this shape")
+        raise
+    _compare(_oracle(oracle, case, True, key), s, out)
+
+
+@pytest.mark.parametrize("A,E,S,B,policy", [(18, 8, 50, 130, "muzero"), (2, 8, 160, 40, "muzero"), (4, 100, 40, 25, "muzero"),
+                                            (33, 20, 70, 21, "muzero"), (18, 8, 40, 50, "gumbel"), (2, 8, 200, 9, "gumbel")])
+def test_generic_one_launch_search_matches_oracle(oracle, A, E, S, B, policy):
+    """What no instance of the fused kernel can serve -- 18 / 33 actions, 160 / 200 simulations, a 100-wide embedding --
+    through mzs_act_mlp's generic route (mz_mlp_generic.cuh: the trio with run-time shapes, tree in HBM, one launch for
+    all simulations): every tree array, actions, weights, values and depth sums equal to the oracle's, both policies."""
+    case = make_case(oracle, 500 + A + E, B, 6, E, A, S, invalid_frac=0.2 if A > 2 else 0.0)
+    key = [77, S]
+    if policy == "muzero":
+        s, out = _fused_any(case, True, key, "generic")
+        _compare(_oracle(oracle, case, True, key), s, out)
+        return
+    s, out = _fused_any(case, False, key, "generic", policy="gumbel", qtransform="qtransform_completed_by_mix_value")
+    mlp = oracle.Mlp(case["w"], case["obs_dim"], E, A, case["F"])
+    pl, v, emb = oracle.root_inference(mlp, case["obs"])
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S)
+    oracle.tree_init(tree, oracle.mask_root_logits(pl, case["invalid"]), v, emb, case["invalid"])
+    for sim in range(S):
+        p_, a_, _ = oracle.gumbel_step_select(tree, cfg, case["gumbel"], 1, 16)
+        oracle.step_expand_backup(tree, sim, p_, a_, *oracle.recurrent_inference(mlp, a_, tree.embeddings[np.arange(B), p_]))
+    action, weights = oracle.gumbel_finish(tree, case["gumbel"], 1)
+    assert np.array_equal(action, out.action.cpu().numpy()) and np.array_equal(weights, out.action_weights.cpu().numpy())
+    assert np.array_equal(v, s.root_value.cpu().numpy())
+    assert_trees_equal(tree, out.search_tree, exact_floats=True)
+
+
+def test_model_act_above_the_fused_kernels_limits_takes_the_generic_route(oracle):
+    """The reference's act() takes any num_simulations (muax/model.py:82-96): 160 simulations on the default trio (no
+    instance possible) go through the library's generic one-launch search -- no step-wise policy adapter, no torch
+    modules -- and give the oracle's actions, weights and values for the same key; so does an 18-action trio."""
     import muax_amd as mx
-    g = torch.Generator().manual_seed(0)
-    net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(2, 21, generator=g),
-                          mx.nn.Dynamic(8, 2, 21, generator=g))
-    m = mx.MuZero(net)
-    m.init(0, np.zeros((1, 4)))
-    obs = np.random.default_rng(0).uniform(-1, 1, (10, 4)).astype(F32)
-    a, pi = m.act(2, obs, with_pi=True, obs_from_batch=True, num_simulations=160)
-    assert a.shape == (10,) and np.allclose(pi.sum(1), 1, atol=1e-6) and np.allclose(pi * 160, np.round(pi * 160), atol=1e-4)
-    assert len(m._policy._handles) == 1  # went through the step-wise policy adapter
+    for A, S in ((2, 160), (18, 50)):
+        g = torch.Generator().manual_seed(0)
+        net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(A, 21, generator=g),
+                              mx.nn.Dynamic(8, A, 21, generator=g))
+        m = mx.MuZero(net)
+        m.init(0, np.zeros((1, 4)))
+        obs = np.random.default_rng(0).uniform(-1, 1, (10, 4)).astype(F32)
+        a, pi, v = m.act(2, obs, with_pi=True, with_value=True, obs_from_batch=True, num_simulations=S)
+        assert a.shape == (10,) and np.allclose(pi.sum(1), 1, atol=1e-6) and np.allclose(pi * S, np.round(pi * S), atol=1e-4)
+        assert len(m._policy._handles) == 0  # NOT through the step-wise policy adapter
+        w = {k: p.detach().cpu().numpy() for k, p in mx.nn.mlp_trio_weights(m.network).items()}
+        mlp = oracle.Mlp(w, 4, 8, A, 21)
+        noise = oracle.dirichlet(oracle.split([0, 2], 3)[1], 0.3, 10, A)
+        ref = oracle.act_mlp(mlp, oracle.SearchCfg(S, tiebreak=1), obs, [0, 2], noise, 0.25, None, 1.0)
+        assert np.array_equal(ref["action"], a) and np.array_equal(ref["action_weights"], pi) and np.array_equal(ref["root_value"], v)
 
 
 def test_bad_arguments_raise_value_error():

@@ -1,0 +1,50 @@
+"""Per-act time of the three routes a default-trio act() can take, on one shape: the tuned fused instance, the generic
+one-launch search (MZS_FORCE_GENERIC=1 on a handle with allow_generic), and -- for shapes without an instance -- the
+generic route alone.   python tools/bench_generic.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import haiku_style_weights  # noqa: E402
+from muax_amd import MuZeroSearch, SearchConfig  # noqa: E402
+
+
+def run(B, obs_dim, E, A, S, force_generic):
+    w = haiku_style_weights(0, obs_dim, E, A, 21)
+    s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True))
+    s.set_mlp_weights(w, obs_dim, 10, 0.99)
+    s.allow_generic()
+    if force_generic:
+        os.environ["MZS_FORCE_GENERIC"] = "1"
+    else:
+        os.environ.pop("MZS_FORCE_GENERIC", None)
+    obs = (torch.rand(B, obs_dim) * 2 - 1).cuda()
+    noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)).cuda()
+    for i in range(5):
+        s.act_mlp(obs, (0, i), dirichlet_noise=noise)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for i in range(n):
+        s.act_mlp(obs, (0, 100 + i), dirichlet_noise=noise)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    depth = float(s.depth_sum.float().mean()) / S
+    s.close()
+    os.environ.pop("MZS_FORCE_GENERIC", None)
+    return dt, depth
+
+
+if __name__ == "__main__":
+    for (B, od, E, A, S) in ((4096, 4, 8, 2, 50), (8192, 8, 32, 4, 50)):
+        t_f, d = run(B, od, E, A, S, False)
+        t_g, _ = run(B, od, E, A, S, True)
+        print(f"{B} roots, A={A}, E={E}, S={S} (mean depth {d:.1f}): fused instance {t_f * 1e3:8.3f} ms = {t_f / S * 1e6:6.2f} us/sim | "
+              f"generic {t_g * 1e3:8.3f} ms = {t_g / S * 1e6:6.2f} us/sim | x{t_g / t_f:.1f}")
+    for (B, od, E, A, S) in ((4096, 4, 8, 2, 160), (4096, 4, 8, 18, 50), (1024, 8, 100, 4, 50)):
+        t_g, d = run(B, od, E, A, S, False)
+        print(f"{B} roots, A={A}, E={E}, S={S} (mean depth {d:.1f}): generic only {t_g * 1e3:8.3f} ms = {t_g / S * 1e6:6.2f} us/sim")

@@ -348,7 +348,7 @@ int64_t mzs_tower_pair_scratch_bytes(int32_t batch);
  * (muax_amd/csrc/mz_instances.def) and returns MZS_E_UNSUPPORTED for others, although the reference's act() takes any
  * (muax/model.py:82-96).  A host that has hipcc can close the gap at run time: compile muax_amd/csrc/mz_fused_jit.hip for
  * the missing shape into a side library (muax_amd/_jit.py does), dlopen it and pass its
- * mzs_jit_dispatch() / mzs_jit_abi() here; later mzs_act_mlp calls (any handle) try the registered instances after the
+ * two entry points (the values of `mzs_jit_dispatch` and `mzs_jit_abi`) here; later mzs_act_mlp calls (any handle) try the registered instances after the
  * built-in ones.  `jit_abi` must equal mzs_fused_jit_abi() (same kernel-argument layout). */
 int mzs_register_fused_dispatch(void *dispatch, int32_t jit_abi);
 int mzs_fused_jit_abi(void);

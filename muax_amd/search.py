@@ -133,6 +133,7 @@ class MuZeroSearch:
         self._tree = None
         self._parent_emb = None
         self._graphs = {}  # (recurrent_fn) -> captured simulation loop
+        self._act_cache = None  # act_mlp: (argument signature, filled MzsActArgs, tree, kept tensors, noise given)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -265,29 +266,47 @@ class MuZeroSearch:
         if self._weights is None:
             raise ValueError("set_mlp_weights() first")
         B, A = self.batch, self.cfg.num_actions
-        obs = self._stage_obs(obs, self._weights[1])
-        noise = self._f32(dirichlet_noise, (B, A), "dirichlet_noise")
-        inv = self._u8(invalid_actions, (B, A), "invalid_actions")
-        gum = self._f32(gumbel, (B, A), "gumbel")
-        a = MzsActArgs()
-        a.struct_size = C.sizeof(MzsActArgs)
-        a.obs, a.dirichlet_noise = obs.data_ptr(), (noise.data_ptr() if noise is not None else None)
-        a.invalid_actions = inv.data_ptr() if inv is not None else None
-        a.gumbel = gum.data_ptr() if gum is not None else None
+        # An RL loop calls act() with the same device buffers step after step: when every tensor argument is the very
+        # object (and storage) of the previous call, the checked / converted inputs and the filled argument block are
+        # reused and only the key and the scalars are written (~8 us of host time per act otherwise, on the critical
+        # path of a synchronised act: the GPU idles while the host prepares the launch).
+        sig = (id(obs), id(dirichlet_noise), id(invalid_actions), id(gumbel), bool(with_tree),
+               tuple(t.data_ptr() if isinstance(t, torch.Tensor) else None for t in (obs, dirichlet_noise, invalid_actions, gumbel)))
+        fast = self._act_cache if (self._act_cache is not None and self._act_cache[0] == sig
+                                   and isinstance(obs, torch.Tensor) and obs.is_cuda) else None
+        if fast is not None:
+            _, a, tree, keep, has_noise = fast
+        else:
+            obs_t = self._stage_obs(obs, self._weights[1])
+            noise = self._f32(dirichlet_noise, (B, A), "dirichlet_noise")
+            inv = self._u8(invalid_actions, (B, A), "invalid_actions")
+            gum = self._f32(gumbel, (B, A), "gumbel")
+            a = MzsActArgs()
+            a.struct_size = C.sizeof(MzsActArgs)
+            a.obs, a.dirichlet_noise = obs_t.data_ptr(), (noise.data_ptr() if noise is not None else None)
+            a.invalid_actions = inv.data_ptr() if inv is not None else None
+            a.gumbel = gum.data_ptr() if gum is not None else None
+            a.action, a.action_weights = self.action.data_ptr(), self.action_weights.data_ptr()
+            a.root_value, a.search_value = self.root_value.data_ptr(), self.search_value.data_ptr()
+            a.depth_sum = self.depth_sum.data_ptr()
+            tree = None
+            if with_tree:
+                tree = self._alloc_tree()
+                view = self._tree_view(tree)
+                a.tree = C.pointer(view)
+            keep = (obs_t, noise, inv, gum, obs, dirichlet_noise, invalid_actions, gumbel, view if with_tree else None)  # (ids stay unique while held)
+            has_noise = noise is not None
+            # cached only when the kernel reads the caller's own storage (a converted copy would go stale under an
+            # in-place update of the original)
+            same = all(x is None or (isinstance(y, torch.Tensor) and x.data_ptr() == y.data_ptr())
+                       for x, y in ((obs_t, obs), (noise, dirichlet_noise), (inv, invalid_actions), (gum, gumbel)))
+            self._act_cache = (sig, a, tree, keep, has_noise) if same else None
         k = key_words(key)
         a.key[0], a.key[1] = k
-        a.dirichlet_fraction = dirichlet_fraction if noise is not None else 0.0
+        a.dirichlet_fraction = dirichlet_fraction if has_noise else 0.0
         a.temperature = temperature
-        a.action, a.action_weights = self.action.data_ptr(), self.action_weights.data_ptr()
-        a.root_value, a.search_value = self.root_value.data_ptr(), self.search_value.data_ptr()
-        a.depth_sum = self.depth_sum.data_ptr()
-        tree = None
-        if with_tree:
-            tree = self._alloc_tree()
-            view = self._tree_view(tree)
-            a.tree = C.pointer(view)
         _lib.check(self._L.mzs_act_mlp(self._h, C.byref(a), self._stream()), self._h)
-        self._keep = (obs, noise, inv, gum)  # alive until the stream has consumed them
+        self._keep = keep  # alive until the stream has consumed them
         return PolicyOutput(self.action, self.action_weights, tree)
 
     def act_mlp_host(self, obs: np.ndarray, key, dirichlet_noise=None, dirichlet_fraction: float = 0.25,
@@ -459,8 +478,13 @@ class MuZeroSearch:
         do_root()
         if native_loop is not None:
             self.select(0)  # simulate() of simulation 0; every later one is the tail of its predecessor inside the launch
+            ev = getattr(self, "time_native_loop", None)  # (start, end) events of a profiler (bench.py), else None
             try:
+                if ev:
+                    ev[0].record()
                 native_loop(self, 0, self.cfg.num_simulations)
+                if ev:
+                    ev[1].record()
             except ValueError as e:
                 if "cached decisions" not in str(e):
                     raise

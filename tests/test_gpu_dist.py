@@ -181,9 +181,10 @@ def test_bench_line_schema_at_one_gpu():
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert line["api"]["numpy"]["value"] > 0 and line["api"]["device"]["value"] > 0
-    r4 = line["config4_atari"]["roofline"]
-    assert r4["bound"] == "mfma" and r4["peak"] == 157.3
-    assert abs(r4["frac"] - r4["algorithmic_flops_per_launch"] / (r4["kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
+    for r4 in (line["config4_atari"]["roofline"], line["config4_atari"]["recurrent_pass"]):
+        assert r4["bound"] == "mfma" and r4["peak"] == 157.3
+        assert abs(r4["frac"] - r4["algorithmic_flops_per_launch"] / (r4["kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
+    assert "mz_resnet_search_kernel" in line["config4_atari"]["roofline"]["kernel"]
     c5 = line["config5_gumbel_train"]
     assert c5["act"]["ms_per_act"] > 0 and c5["update"]["ms_per_update"] > 0 and c5["update"]["ms_allreduce"] == 0.0
     assert line["config4_atari"]["n_gpus"] == 1 and c5["n_gpus"] == 1

@@ -188,6 +188,8 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     # act's actions.  The same launches enqueued back to back with one synchronisation at the end are reported beside
     # it as `value_pipelined` (what a caller that keeps several acts in flight gets; rounds 1-3 reported that as `value`).
     elapsed, kernel_ms = timed(sync_each=True)
+    for i in range(max(10, warmup)):  # (the secondary figure gets its own untimed warm-up: a different submission pattern)
+        step(i)
     pipelined, kernel_ms_pipelined = timed(sync_each=False)
     depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
     actions = search.action.cpu()

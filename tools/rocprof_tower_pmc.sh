@@ -6,4 +6,4 @@ mkdir -p $OUT
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $OUT/pmc1 -o pmc1 -- python $GRAFT_REPO_ROOT/tools/bench_atari.py 128 20 > $OUT/bench.log 2>&1
 python $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT > /dev/null 2>&1
 rm -f $OUT/*/*.db $OUT/*/*/*.db
-grep "tower" $OUT/summary.txt
+grep "tower\|search" $OUT/summary.txt

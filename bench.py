@@ -147,8 +147,25 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
         per = max(time.perf_counter() - t_s, 2e-5)
         for i in range(min(5000, int(settle_ms * 1e-3 / per) + 1)):
             step(i)
-    for i in range(warmup):
+    # HIP events bracket a SAMPLE of the launches (every 10th): an event pair costs ~6 us of stream time, 5 % of the
+    # kernel, so bracketing every launch would slow the very loop that is being timed.  They are created AND recorded
+    # once up front: the first record() of an event makes the runtime allocate its completion signal, and a pool that
+    # has to grow stalls the host for tens of milliseconds -- once, but inside a 24 ms timed region that is the whole
+    # measurement (seen on this pool: one 45 ms step among 200 steps of 0.118 ms).
+    ev_every = 10 if steps >= 20 else 1
+    sampled = [i for i in range(steps) if i % ev_every == ev_every // 2]
+    ev_sets = []
+    for _ in range(2):
+        evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sampled}
+        for a_, b_ in evs.values():
+            a_.record()
+            b_.record()
+        ev_sets.append(evs)
+    torch.cuda.synchronize()
+    for i in range(warmup):  # the untimed warm-up steps are what the timed steps are: an act and the host synchronisation
         step(i)
+        torch.cuda.synchronize()
+
     def reduce_max(x):
         if not dist:
             return x
@@ -156,23 +173,19 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(sync_each):
+    def timed(sync_each, evs):
         """Exactly `steps` acts between two (barrier + synchronize) brackets; the job's time is the MAX over ranks of
-        the per-rank times.  HIP events bracket a SAMPLE of the launches (every 10th): an event pair costs ~6 us of
-        stream time, 5 % of the kernel, so bracketing every launch would slow the very loop that is being timed."""
+        the per-rank times."""
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        ev_every = 10 if steps >= 20 else 1
-        sampled = [i for i in range(steps) if i % ev_every == ev_every // 2]
         t0 = time.perf_counter()
         for i in range(steps):
-            if i % ev_every == ev_every // 2:
+            if i in evs:
                 evs[i][0].record()
             step(warmup + i)
-            if i % ev_every == ev_every // 2:
+            if i in evs:
                 evs[i][1].record()
             if sync_each:
                 torch.cuda.synchronize()
@@ -187,10 +200,10 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     # the host synchronisation the reference's np.asarray / .item() imply -- the next act of an RL loop needs this
     # act's actions.  The same launches enqueued back to back with one synchronisation at the end are reported beside
     # it as `value_pipelined` (what a caller that keeps several acts in flight gets; rounds 1-3 reported that as `value`).
-    elapsed, kernel_ms = timed(sync_each=True)
+    elapsed, kernel_ms = timed(True, ev_sets[0])
     for i in range(max(10, warmup)):  # (the secondary figure gets its own untimed warm-up: a different submission pattern)
         step(i)
-    pipelined, kernel_ms_pipelined = timed(sync_each=False)
+    pipelined, kernel_ms_pipelined = timed(False, ev_sets[1])
     depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
     actions = search.action.cpu()
     assert int(actions.min()) >= 0 and int(actions.max()) < A

@@ -60,6 +60,9 @@ class SearchConfig:
     gumbel_scale: float = 1.0
 
 
+_NO_ACT_CACHE = bool(__import__("os").environ.get("MUAX_AMD_NO_ACT_CACHE"))  # A/B switch of act_mlp's argument cache
+
+
 def key_words(key) -> tuple:
     """Accept an int seed, a uint32[2] array/tensor (JAX PRNGKey data) or a (hi, lo) tuple."""
     if isinstance(key, (int, np.integer)):
@@ -272,7 +275,7 @@ class MuZeroSearch:
         # path of a synchronised act: the GPU idles while the host prepares the launch).
         sig = (id(obs), id(dirichlet_noise), id(invalid_actions), id(gumbel), bool(with_tree),
                tuple(t.data_ptr() if isinstance(t, torch.Tensor) else None for t in (obs, dirichlet_noise, invalid_actions, gumbel)))
-        fast = self._act_cache if (self._act_cache is not None and self._act_cache[0] == sig
+        fast = self._act_cache if (self._act_cache is not None and self._act_cache[0] == sig and not _NO_ACT_CACHE
                                    and isinstance(obs, torch.Tensor) and obs.is_cuda) else None
         if fast is not None:
             _, a, tree, keep, has_noise = fast

@@ -708,9 +708,8 @@ MZ_DEV void pair_link_init(const TowerParams& p, int r, PairLink& L) {
 }
 // One pass of recurrent_fn for one root (TSEL = 0) or one half of a root (TSEL = 1: pixels 0..15, TSEL = 2: pixels
 // 16..35; `L` = the half's link, initialised once per launch).
-// `idle(k)`, k = 0, 1, ...: pair mode, 16-pixel half only -- called once per convolution pass after the reward head is
-// done (pixels in passes 0 .. 8, its tail in pass 9; passes 10 .. 15 of an 8-block tower are free), between posting a
-// message and waiting for the partner's: work
+// `idle(k)`, k = 0, 1, ...: pair mode, 16-pixel half only -- called once per convolution pass after the reward head's
+// pixels are done (passes 9 .. 15 of an 8-block tower), between posting a message and waiting for the partner's: work
 // the caller wants done in that half's idle time (the fused search loads the tree path of the coming backup there).
 // A barrier follows every call.
 struct NoIdleWork {
@@ -767,7 +766,6 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
   // the whole head AFTER the tower: 11 - 24 us on the critical path of every simulation.)
   float rh_acc = 0.0f;
   int rh_k = 0;
-  bool rh_done = false;
   if constexpr (TSEL == 1)
     if (p.heads) reward_front<true>(p, io, bufA, bufB, rhmap, rowc, ch, lane);
   MZ_TT(1)
@@ -838,14 +836,8 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         put_boundary<TSEL>(L, pr[1], out, 8, ch, lane);
         MZ_TT(5)
         if constexpr (TSEL == 1) {
-          if (p.heads && rh_k < 9) {
-            reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
-          } else if (p.heads && rh_k == 9) {
-            reward_finish(p, io, H, rh_acc, tid, lane, wave);  // (the heads' scratch is free until the tower ends)
-            rh_done = true;
-          } else if (rh_k >= 10) {
-            idle(rh_k - 10);
-          }
+          if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+          else if (rh_k >= 9) idle(rh_k - 9);
           rh_k += 1;
           MZ_TT(1)
         }
@@ -895,14 +887,8 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         put_boundary<TSEL>(L, pr[0], msg, 8 + kPairBnd * kTowerC, ch, lane);
         MZ_TT(5)
         if constexpr (TSEL == 1) {
-          if (p.heads && rh_k < 9) {
-            reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
-          } else if (p.heads && rh_k == 9) {
-            reward_finish(p, io, H, rh_acc, tid, lane, wave);  // (the heads' scratch is free until the tower ends)
-            rh_done = true;
-          } else if (rh_k >= 10) {
-            idle(rh_k - 10);
-          }
+          if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+          else if (rh_k >= 9) idle(rh_k - 9);
           rh_k += 1;
           MZ_TT(1)
         }
@@ -1006,11 +992,11 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
     } else {
       if constexpr (TSEL == 1) {
         // (fewer than 5 blocks: the pixels the passes did not get to)
-        if (!rh_done) {
-          for (; rh_k < 9; ++rh_k) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
-          __syncthreads();
-          reward_finish(p, io, H, rh_acc, tid, lane, wave);
-        }
+        // (the head's tail -- 4 barriers, ~1.5 us -- was also tried inside idle pass 9: it costs the pass what it saves
+        // here, and the stand-alone pass kernel 8 us: profiles/r04_search_phases.txt)
+        for (; rh_k < 9; ++rh_k) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
+        __syncthreads();
+        reward_finish(p, io, H, rh_acc, tid, lane, wave);
       }
       // ---- prediction heads on the normalised next state ----
       store_map<TSEL>(acc, cur, ch, lane);

@@ -57,6 +57,18 @@ write("plugin_nets.txt", "".join(h + rd(n) for h, n in sections if os.path.exist
       f"# {tag} -- wall-clock numbers of the plugin-net paths (1 x MI355X; gpurun_out/{tag})\n\n")
 if os.path.exists(os.path.join(R, "api_profile.txt")):
     write("api_profile.txt", rd("api_profile.txt"))
+if os.path.exists(os.path.join(R, "search_phases.txt")):  # round 4: the one-launch ResNet search (tools/profile_search.py)
+    write("search_phases.txt", rd("search_phases.txt"),
+          f"# {tag} -- config 4's shard (128 roots x 200 simulations): act() through the three routes, and in-kernel phase timers\n"
+          f"# (s_memtime, -DMZ_PROFILE build) of the one-launch search, per simulation (tools/profile_search.py run)\n\n")
+if os.path.exists(os.path.join(R, "generic.txt")):  # round 4: default-trio shapes without a listed instance
+    write("generic_route.txt", rd("generic.txt"),
+          f"# {tag} -- act() of the default MLP trio: tuned fused instance vs the generic one-launch search (mz_mlp_generic.cuh),\n"
+          f"# and shapes only the generic route serves (tools/bench_generic.py)\n\n")
+if os.path.exists(os.path.join(R, "bench_2ranks_1gpu.json")):
+    with open(os.path.join(P, f"{tag}_bench_2ranks_1gpu.json"), "w") as f:
+        f.write(open(os.path.join(R, "bench_2ranks_1gpu.json")).read())
+    print("wrote", f"profiles/{tag}_bench_2ranks_1gpu.json")
 
 
 def pmc(text, counter):

@@ -322,7 +322,11 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   const mzs_config& c = h->cfg;
   if (c.policy == 0 && !a->dirichlet_noise && a->dirichlet_fraction != 0.0f)
     return fail(h, MZS_E_INVALID, "mzs_act_mlp: dirichlet_fraction != 0 needs dirichlet_noise");
-  if (c.num_simulations > mz::kMaxSims) return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: num_simulations > 256 (use the step-wise path)");
+  if (c.num_simulations > mz::kMaxSims) {  // (the fused kernel's argument block holds 256 simulation keys)
+    if (h->allow_generic) return act_mlp_generic(h, a, stream_);
+    return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp: no fused kernel instance for num_simulations > 256; use the generic route "
+                                      "(mzs_mlp_allow_generic) or the step-wise path");
+  }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));
 

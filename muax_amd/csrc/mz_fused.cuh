@@ -456,7 +456,7 @@ struct Nets {
         w[2 * q] = (f32x2){v.x, v.y};
         w[2 * q + 1] = (f32x2){v.z, v.w};
       }
-      fmac_bcast_pair8<(i & 15), i == 0>(h0, h1, x[i >> 4], w);
+      fmac_bcast_pair8<(i & 15), (i & 15) == 0>(h0, h1, x[i >> 4], w);
     });
     return (f32x2){h0, h1};
   }
@@ -483,7 +483,7 @@ struct Nets {
       float h0 = 0.0f, h1 = 0.0f;
       StaticFor<0, C::E / 8>::run([&](auto ic) {
         constexpr int i = 8 * decltype(ic)::value;
-        fmac_bcast_pair8<(i & 15), i == 0>(h0, h1, x[i >> 4], &w[i]);
+        fmac_bcast_pair8<(i & 15), (i & 15) == 0>(h0, h1, x[i >> 4], &w[i]);
       });
       return (f32x2){h0, h1};
     } else {

@@ -102,7 +102,12 @@ template <int B, bool FIRST, class W>
 MZ_DEV void fmac_bcast_pair8(float& acc0, float& acc1, float x, const W* w) {
   static_assert(B == 0 || B == 8, "");
   static_assert(!FIRST || B == 0, "");
-  if constexpr (FIRST)  // (x may be fresh: the two wait states of a DPP read)
+  // FIRST: the first eight lanes of a slot register, i.e. a register this chain has not read yet.  It may have been
+  // written by the instruction just before this statement (a select that masks the lanes past E, a move), and the
+  // compiler's hazard recogniser does not look inside an asm statement: the two wait states of a DPP read are spelled
+  // out.  (Until round 4 only the chain's very first block had them; an on-demand instance with E = 24 -- whose third
+  // block starts the second slot register right behind that select -- read a stale lane in the first link of chain 0.)
+  if constexpr (FIRST)
     asm("s_nop 1\n\t" MZ_FB_LINE(3, 0) MZ_FB_LINE2(4, 0) MZ_FB_LINE(5, 1) MZ_FB_LINE2(6, 1) MZ_FB_LINE(7, 2) MZ_FB_LINE2(8, 2)
         MZ_FB_LINE(9, 3) MZ_FB_LINE2(10, 3) MZ_FB_LINE(11, 4) MZ_FB_LINE2(12, 4) MZ_FB_LINE(13, 5) MZ_FB_LINE2(14, 5)
         MZ_FB_LINE(15, 6) MZ_FB_LINE2(16, 6) MZ_FB_LINE(17, 7) MZ_FB_LINE2(18, 7)

@@ -439,12 +439,14 @@ def _fused_any(case, tiebreak, key, route, policy="muzero", **kw):
     return s, out
 
 
-@pytest.mark.parametrize("A,E,S,B,support", [(5, 12, 30, 90, 10), (2, 8, 50, 70, 20), (7, 24, 80, 33, 10)])
+@pytest.mark.parametrize("A,E,S,B,support", [(5, 12, 30, 90, 10), (2, 8, 50, 70, 20), (7, 24, 80, 33, 10), (2, 24, 20, 40, 10),
+                                             (4, 24, 52, 59, 10), (3, 40, 60, 20, 12), (1, 56, 25, 17, 10)])
 def test_fused_instance_built_on_demand_matches_oracle(oracle, A, E, S, B, support):
     """Shapes mz_instances.def does not list (5 actions x 12-wide embedding; support_size 20 with F = 41 at CartPole
     widths is listed, 7 actions x 24 at 80 simulations is not ...): mzs_act_mlp refuses, muax_amd/_jit.py compiles ONE
     translation unit for the shape with the hipcc of this box, registers it, and the same call then runs as one launch --
-    every tree array equal to the oracle's."""
+    every tree array equal to the oracle's.  E = 24 is the shape that exposed a DPP read hazard inside the first-layer
+    asm blocks (the second slot register read right behind the select that masks its lanes: mz_spec.cuh)."""
     from muax_amd import _jit
     if _jit.plan(A, E, 2 * support + 1, S) is None:
         pytest.skip("outside the fused kernel's limits")

@@ -342,6 +342,24 @@ int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * hk.Conv2D(C, kernel_shape=3, stride=1, padding='SAME', with_bias=False) on NHWC maps with C -> C channels, C = 32 or
+ * 64: the convolutions inside the residual blocks of the representation nets at their 21 x 21 / 11 x 11 / 6 x 6 stages
+ * (muax/nn.py:118-178 inside ResNetRepresentation :291-310 and EZStateEncoder :180-207; root inference,
+ * muax/model.py:251-263).  fp32 MFMA implicit GEMM (mz_repr.cuh); any height / width whose rows fit a CU's LDS.
+ *   w_packed: the HWIO kernel w[3][3][C][C] re-ordered once by the caller to Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co]
+ *   (the layout of mzs_resnet_tower's conv_w).  relu != 0: max(., 0) on the way out. */
+typedef struct mzs_conv3x3_args {
+  int32_t struct_size;     /* = sizeof(mzs_conv3x3_args) */
+  int32_t device;
+  int32_t batch, height, width, channels;
+  int32_t relu, reserved0;
+  const float *x;          /* [B, H, W, C] */
+  const float *w_packed;   /* 9 * C * C floats */
+  float *y;                /* [B, H, W, C] out */
+} mzs_conv3x3_args;
+int mzs_conv3x3_nhwc(const mzs_conv3x3_args *a, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Fused-kernel instances built on demand.
  *
  * mzs_act_mlp serves the (num_actions, embedding_dim, support_size, num_simulations) shapes compiled into the library

@@ -98,6 +98,12 @@ class MzsEzArgs(C.Structure):
                 + [("r", MzsEzHead), ("v", MzsEzHead), ("p", MzsEzHead)])
 
 
+class MzsConv3x3Args(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("channels", C.c_int32), ("relu", C.c_int32), ("reserved0", C.c_int32),
+                ("x", _vp), ("w_packed", _vp), ("y", _vp)]
+
+
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup", "mzs_expand_backup_select",
@@ -105,7 +111,7 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
                     "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
-                    "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic"]
+                    "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc"]
 
 _lib = None
 
@@ -142,6 +148,7 @@ def load(build_if_missing: bool = True):
     L.mzs_resnet_tower.argtypes = [C.POINTER(MzsTowerArgs), _vp]
     L.mzs_register_fused_dispatch.argtypes = [_vp, C.c_int32]
     L.mzs_mlp_allow_generic.argtypes = [_vp, C.c_int32]
+    L.mzs_conv3x3_nhwc.argtypes = [C.POINTER(MzsConv3x3Args), _vp]
     L.mzs_resnet_search.argtypes = [_vp, C.POINTER(MzsTowerArgs), C.c_float, C.c_int32, C.c_int32, _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4
     L.mzs_mlp_train_workspace_bytes.argtypes = [C.c_int32] * 5

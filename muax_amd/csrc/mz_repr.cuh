@@ -1,0 +1,146 @@
+// mz_repr.cuh -- hk.Conv2D(C, kernel_shape=3, stride=1, padding='SAME', with_bias=False) on NHWC maps, C -> C channels
+// with C = 32 or 64: the convolutions inside the residual blocks of the reference's REPRESENTATION nets at their
+// 21 x 21, 11 x 11 and 6 x 6 stages (muax/nn.py:118-178 ResidualConvBlockV1 / V2 inside ResNetRepresentation :291-310
+// and EZStateEncoder :180-207) -- 18 of the 26 convolutions of config 4's root inference (muax/model.py:251-263), the
+// ones the library's implicit GEMM runs at 31 .. 47 TFLOP/s (profiles/r03_plugin_nets.txt).  The stride-2 stems and the
+// 42 x 42 x 32 layers (114 TFLOP/s in the library) stay where they are.
+//
+// Implicit GEMM on v_mfma_f32_16x16x4_f32, the recurrent kernel's tile (mz_conv.cuh):
+//     out[pixel][co] = sum_{tap, ci} in[pixel + tap][ci] W[tap][ci][co],   M = pixels in tiles of 16, N = C, K = 9 C.
+// A workgroup owns a run of 16 TPW NTG consecutive pixels (row-major) of ONE image and stages the rows that run
+// touches, plus a zero halo, in LDS (pixel stride C + 4 words: 16-byte aligned rows that spread over the banks).  Wave
+// w owns output channels 16 (w % NCB) .. + 15 (NCB = C / 16 channel blocks) and the TPW pixel tiles of its tile group
+// w / NCB; K is walked in 9 C / 16 groups of 16 input channels: per group a lane reads ONE ds_read_b128 of activations
+// per tile and ONE global_load_dwordx4 of weights from the host-packed array Wp[tap][c][g][co][i] = W[tap][16 c + 4 g + i][co]
+// (the recurrent kernel's layout), fetched one group ahead.  fp32 throughout, one accumulator chain per output.
+//
+// Floating-point kernel: checked against the torch module it replaces (MIOpen) and an fp64 evaluation, tolerance in
+// tests/test_gpu_cfg4.py.
+#pragma once
+#include "mz_spec.cuh"
+
+#pragma clang fp contract(off)
+
+namespace mz {
+
+struct ReprConvParams {
+  const float* x;    // [B][H][W][C]
+  const float* wp;   // packed weights, 9 * C * C floats
+  float* y;          // [B][H][W][C]
+  int B, H, W, relu;
+};
+
+typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C, int TPW>
+__global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvParams p) {
+  constexpr int NCB = C / 16, NTG = 4 / NCB, NC = C / 16, PS = C + 4, G = 9 * NC;
+  constexpr int BLOCK_PX = 16 * TPW * NTG;
+  extern __shared__ __attribute__((aligned(16))) float rc_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, H = p.H, W = p.W, npix = H * W, W2 = W + 2;
+  const int p0 = blockIdx.x * BLOCK_PX, p1 = min(p0 + BLOCK_PX, npix);
+  const int row0 = p0 / W - 1, row1 = (p1 - 1) / W + 1;  // staged image rows, halo rows included (may be -1 / H)
+  const int nrows = row1 - row0 + 1;
+  // ---- stage rows [row0, row1] x columns [-1, W] (zero outside the image): a thread keeps its channel quad and walks
+  // the pixels 256 / (C / 4) apart, eight loads in flight before the first LDS write (one load per trip is one L2 / HBM
+  // round trip per trip: 20 trips, a third of the 21 x 21 layers' time)
+  {
+    constexpr int QPP = C / 4, PSTEP = 256 / QPP, U = 8;
+    const float* img = p.x + (size_t)b * npix * C;
+    const int c4 = tid % QPP, npx = nrows * W2;
+    int px = tid / QPP;
+    int ry = px / W2, cx = px - ry * W2;
+    while (px < npx) {
+      rc_f32x4 v[U];
+      int dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int y = row0 + ry, x = cx - 1;
+        v[u] = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        dst[u] = px < npx ? px : -1;
+        if (px < npx && y >= 0 && y < H && x >= 0 && x < W)
+          v[u] = *reinterpret_cast<const rc_f32x4*>(img + ((size_t)y * W + x) * C + 4 * c4);
+        px += PSTEP;
+        cx += PSTEP;
+        while (cx >= W2) {
+          cx -= W2;
+          ++ry;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<rc_f32x4*>(rc_lds + (size_t)dst[u] * PS + 4 * c4) = v[u];
+    }
+  }
+  __syncthreads();
+  const int cb = wave % NCB, tg = wave / NCB;
+  const int g = lane >> 4, m = lane & 15;
+  const int ch = 16 * cb + m;
+  // A operand: lane (m, g) reads pixel tile_base + m, input channels 16 c + 4 g + {0..3}; LDS word of tap (0, 0)
+  int abase[TPW];
+#pragma unroll
+  for (int mt = 0; mt < TPW; ++mt) {
+    const int px = p0 + 16 * (tg * TPW + mt) + m;
+    const int pc = px < p1 ? px : p0;  // (rows past the run shadow its first pixel: computed, never stored)
+    const int py = pc / W, pxx = pc - py * W;
+    abase[mt] = ((py - 1 - row0) * W2 + pxx) * PS + 4 * g;
+  }
+  rc_f32x4 acc[TPW];
+#pragma unroll
+  for (int mt = 0; mt < TPW; ++mt) acc[mt] = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  // Software pipeline, stated explicitly (left to itself the scheduler sinks the weight load to its first use -- one L2
+  // round trip per group, 20 of the 51 us of the 21 x 21 layers -- and reuses accumulator registers as load targets,
+  // which serialises ds_read -> 4 dependent MFMAs): group grp's MFMAs run on registers filled during group grp - 1
+  // (activations: TPW ds_read_b128) and grp - 2 (weights: one global_load_dwordx4), one LDS read issued per 4 MFMAs.
+  const rc_f32x4* wq = reinterpret_cast<const rc_f32x4*>(p.wp) + g * C + ch;  // quad [g][co] of a packed group
+  rc_f32x4 wcur = wq[0], wn1 = wq[(size_t)4 * C];
+  rc_f32x4 acur[TPW];
+#pragma unroll
+  for (int mt = 0; mt < TPW; ++mt) acur[mt] = *reinterpret_cast<const rc_f32x4*>(rc_lds + abase[mt]);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int toff = ((tap / 3) * W2 + (tap % 3)) * PS;
+    const int tn = tap < 8 ? tap + 1 : 8;
+    const int toff_next = ((tn / 3) * W2 + (tn % 3)) * PS;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int grp = tap * NC + c;
+      const rc_f32x4 wn2 = wq[(size_t)(grp + 2 < G ? grp + 2 : G - 1) * 4 * C];
+      const int off_next = c + 1 < NC ? toff + 16 * (c + 1) : toff_next;
+      rc_f32x4 anext[TPW];
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt) anext[mt] = *reinterpret_cast<const rc_f32x4*>(rc_lds + abase[mt] + off_next);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int mt = 0; mt < TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[mt][i], wcur[i], acc[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // the weight load first
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // four MFMAs
+      }
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt) acur[mt] = anext[mt];
+      wcur = wn1;
+      wn1 = wn2;
+    }
+  }
+  float* out = p.y + (size_t)b * npix * C;
+#pragma unroll
+  for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int px = p0 + 16 * (tg * TPW + mt) + 4 * g + v;
+      if (px < p1) {
+        const float o = acc[mt][v];
+        out[(size_t)px * C + ch] = p.relu ? fmaxf(o, 0.0f) : o;
+      }
+    }
+}
+
+// rows of LDS a block of BLOCK_PX consecutive pixels of a width-W image needs (halo included)
+inline int repr_conv_rows(int block_px, int W) { return (block_px + W - 1) / W + 1 + 2; }
+
+}  // namespace mz

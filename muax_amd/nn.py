@@ -231,10 +231,59 @@ class HkConv2D(nn.Module):
             nn.init.trunc_normal_(w, 0.0, 1.0, -2.0, 2.0, generator=self._gen)
             self.w = nn.Parameter(w / math.sqrt(self.k * self.k * cin))
 
+    use_hip = True  # C -> C (32 / 64) 3x3 stride-1 convolutions of the representation nets on mzs_conv3x3_nhwc in inference
+
+    def _hip_ok(self, x) -> bool:
+        """mzs_conv3x3_nhwc applies: inference on a dense fp32 NHWC map on the GPU, 3x3, stride 1, C -> C with C = 32 or
+        64, the rows a run of pixels touches fitting a CU's LDS (every C -> C layer of the representation nets: 42 x 42 x 32,
+        21 x 21, 11 x 11, 6 x 6)."""
+        if not (self.use_hip and self.k == 3 and self.stride == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            return False
+        c = x.shape[-1]
+        if c != self.out_channels or c not in (32, 64):
+            return False
+        tiles = (x.shape[1] * x.shape[2] + 15) // 16  # the library's choice of run length (mz_repr.hip) -> its LDS bytes
+        run = 16 * (14 if tiles > 16 else (8 if tiles > 8 else 4))
+        if ((run + x.shape[2] - 1) // x.shape[2] + 3) * (x.shape[2] + 2) * (c + 4) * 4 > 160 * 1024:
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or self.w.requires_grad):
+            return False
+        return self.w.is_cuda and self.w.dtype == torch.float32 and self.w.device == x.device
+
+    def _packed(self):
+        """The HWIO kernel in the HIP kernels' order Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co]; rebuilt when the
+        parameter changes."""
+        sig = (self.w.data_ptr(), self.w._version, self.w.device)
+        if getattr(self, "_pack_sig", None) != sig:
+            c = self.out_channels
+            with torch.no_grad():
+                self._pack = self.w.detach().reshape(9, c // 16, 4, 4, c).permute(0, 1, 2, 4, 3).contiguous()
+            self._pack_sig = sig
+        return self._pack
+
+    def _conv_hip(self, x):
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        xc = x.contiguous()
+        wp = self._packed()
+        y = torch.empty_like(xc)
+        a = _lib.MzsConv3x3Args()
+        a.struct_size = C.sizeof(_lib.MzsConv3x3Args)
+        a.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        a.batch, a.height, a.width, a.channels, a.relu = xc.shape[0], xc.shape[1], xc.shape[2], xc.shape[3], 0
+        a.x, a.w_packed, a.y = xc.data_ptr(), wp.data_ptr(), y.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(L.mzs_conv3x3_nhwc(C.byref(a), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return y
+
     def forward(self, x):
         self.materialize(x.shape[-1])
         if self.k == 1 and self.stride == 1:  # a 1x1 convolution on NHWC is a matrix product over the channels
             return x @ self.w[0, 0]
+        if self._hip_ok(x):
+            return self._conv_hip(x)
         xc = x.permute(0, 3, 1, 2)
         (ht, hb), (wl, wr) = _same_pad(x.shape[1], self.k, self.stride), _same_pad(x.shape[2], self.k, self.stride)
         pad = (0, 0)

@@ -507,3 +507,50 @@ def test_one_launch_search_in_two_halves_and_through_act():
         del os.environ["MZS_RESNET_SEARCH"]
     for x, y in zip(got, want):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("C,H,W,B", [(64, 21, 21, 9), (64, 11, 11, 16), (64, 6, 6, 5), (32, 21, 21, 7), (32, 11, 11, 3), (32, 6, 6, 130),
+                                     (64, 13, 29, 2), (32, 32, 32, 2), (64, 1, 1, 3)])
+def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
+    """mzs_conv3x3_nhwc (the C -> C 3x3 stride-1 convolutions of the representation nets' residual blocks at their 21 x 21
+    / 11 x 11 / 6 x 6 stages: muax/nn.py:118-178 inside :180-207, :291-310) against an fp64 evaluation of the same
+    hk.Conv2D(SAME, no bias), with MIOpen's fp32 result beside it: a floating-point kernel, 9 C terms per output.  Bars:
+    within 2e-6 x sqrt(9 C) x max|y| of fp64 and no further from it than 2 x the library's fp32 result + that floor;
+    odd sizes (runs of pixels ending mid-row, a 1 x 1 map) included."""
+    g = torch.Generator().manual_seed(C + H + W)
+    conv = mx.nn.HkConv2D(C, 3, 1, in_channels=C, generator=g).cuda()
+    x = (torch.rand(B, H, W, C, generator=g) * 2 - 1).cuda()
+    with torch.no_grad():
+        assert conv._hip_ok(x)
+        y = conv(x)
+        conv.use_hip = False
+        y_lib = conv(x)
+        conv.use_hip = True
+        y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), conv.w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    e_hip, e_lib = float((y.double() - y64).abs().max()), float((y_lib.double() - y64).abs().max())
+    floor = 2e-6 * (9 * C) ** 0.5 * float(y64.abs().max())
+    assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_lib + floor, (e_hip, e_lib, floor)
+
+
+def test_representation_net_takes_the_hip_convolutions():
+    """Root inference of the ResNet nets (muax/model.py:251-263) with its 24 C -> C convolutions (42 x 42 x 32, 21 x 21 x 64,
+    11 x 11 x 64) on mzs_conv3x3_nhwc against the same nets on the library's convolutions: embeddings (after
+    min_max_normalize2d), prior logits and values agree to 1e-3 of their largest entries (two fp32 summation orders
+    through 26 convolutions and 17 LayerNorms: 2.2e-4 measured)."""
+    m, mods = _nets(5)
+    obs = torch.from_numpy(_frames(6, seed=3)).cuda()
+    calls = []
+    orig = mx.nn.HkConv2D._conv_hip
+    mx.nn.HkConv2D._conv_hip = lambda self, x: (calls.append(tuple(x.shape[1:])), orig(self, x))[1]
+    try:
+        pl, v, emb = m._root_inference(None, None, obs)
+    finally:
+        mx.nn.HkConv2D._conv_hip = orig
+    assert calls.count((42, 42, 32)) == 6 and calls.count((21, 21, 64)) == 9 and calls.count((11, 11, 64)) == 9 and len(calls) == 24
+    mx.nn.HkConv2D.use_hip = False
+    try:
+        pl0, v0, emb0 = m._root_inference(None, None, obs)
+    finally:
+        mx.nn.HkConv2D.use_hip = True
+    for a, b in ((pl, pl0), (v, v0), (emb, emb0)):
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))

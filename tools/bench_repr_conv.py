@@ -1,0 +1,35 @@
+"""mzs_conv3x3_nhwc against the library's convolution on the shapes of config 4's root inference (128 roots).
+    python tools/bench_repr_conv.py [roots]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import muax_amd as mx  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+for C, H in ((64, 21), (64, 11), (64, 6), (32, 21), (32, 11), (32, 42)):
+    g = torch.Generator().manual_seed(0)
+    conv = mx.nn.HkConv2D(C, 3, 1, in_channels=C, generator=g).cuda()
+    x = torch.rand(B, H, H, C, generator=g).cuda()
+    out = {}
+    for hip in (False, True):
+        conv.use_hip = hip
+        with torch.no_grad():
+            if hip and not conv._hip_ok(x):
+                out[hip] = float("nan")
+                continue
+            for _ in range(5):
+                conv(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                conv(x)
+            e1.record()
+            torch.cuda.synchronize()
+        out[hip] = e0.elapsed_time(e1) / 50 * 1e3
+    fl = 2 * B * H * H * 9 * C * C
+    print(f"{B} x {H}x{H}x{C}: library {out[False]:7.1f} us ({fl / out[False] / 1e6:5.1f} TFLOP/s)   mzs_conv3x3_nhwc {out[True]:7.1f} us "
+          f"({fl / out[True] / 1e6:5.1f} TFLOP/s)")

@@ -521,8 +521,8 @@ def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
     conv = mx.nn.HkConv2D(C, 3, 1, in_channels=C, generator=g).cuda()
     x = (torch.rand(B, H, W, C, generator=g) * 2 - 1).cuda()
     with torch.no_grad():
-        assert conv._hip_ok(x)
-        y = conv(x)
+        assert conv._hip_ok(x) == (H * W >= 100)  # smaller maps stay with the library in the module; the entry point takes them
+        y = conv._conv_hip(x)
         conv.use_hip = False
         y_lib = conv(x)
         conv.use_hip = True

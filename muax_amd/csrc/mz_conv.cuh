@@ -38,6 +38,18 @@ __device__ unsigned long long g_tower_prof[1024 * 16];
 #else
 #define MZ_TT(k)
 #endif
+// -DMZ_PROF_HEADS (with -DMZ_PROFILE): slots 3..9 time the pieces of "heads after the tower" instead of the passes
+#if defined(MZ_PROFILE) && defined(MZ_PROF_HEADS)
+#define MZ_TP(k)
+#define MZ_TH(k) MZ_TT(k)
+#define MZ_TH_PARAMS , unsigned long long* pt, unsigned long long& tlast
+#define MZ_TH_ARGS , pt, tlast
+#else
+#define MZ_TP(k) MZ_TT(k)
+#define MZ_TH(k)
+#define MZ_TH_PARAMS
+#define MZ_TH_ARGS
+#endif
 
 struct TowerParams {
   const float* x;          // [B][36][64]  NHWC hidden state s
@@ -93,7 +105,7 @@ constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride 
 constexpr int kTailPix = 2 * kHalo + 2 + 1;
 constexpr int kBufWords = (kHalo * kHalo + kTailPix) * kPixStride;
 constexpr int kRhWords = kTowerPix * kTowerC;  // pair mode: the reward head's second feature map, [36][64], kept through the tower
-constexpr int kHeadWords = 16 + 3 * 768 + 2 * 256 + 64 + 64 + kRhWords;  // reduction slots (4 values x 4 waves) + scratch of the heads
+constexpr int kHeadWords = 32 + 3 * 768 + 2 * 256 + 64 + 64 + kRhWords;  // reduction slots (2 sets x 4 values x 4 waves) + scratch of the heads
 
 // sum over the 64 lanes of a wavefront, in every lane: the DPP butterfly inside the 16-lane rows, then the four row
 // sums through v_readlane (round 3; the six shuffles through LDS this replaces cost ~0.3 us per reduction, and a launch
@@ -115,15 +127,26 @@ MZ_DEV float lane_xor32(float x) {
   auto s = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
   return u2f((threadIdx.x & 32) ? s[0] : s[1]);
 }
+// sum over the workgroup, in every lane.  Two sets of slots used in turn: a wave that writes set k for reduction n + 2
+// has passed the barrier of reduction n + 1, which every wave reaches only after its reads of reduction n -- so ONE
+// barrier per reduction is enough (round 4; the second one, "previous use of red[] is over", cost 32 barriers a pass).
+struct RedSlots {
+  float* base;  // [2][16]
+  int k;
+};
 template <int NV>
-MZ_DEV void wg_sum(float (&v)[NV], float* red, int wave, int lane) {
+MZ_DEV void wg_sum(float (&v)[NV], RedSlots& R, int wave, int lane) {
+  static_assert(NV <= 4, "16 words per set");
+  float* red = R.base + 16 * R.k;
+  R.k ^= 1;
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = wave_sum64(v[i]);
-  __syncthreads();  // previous use of red[] is over
   if (lane == 0)
 #pragma unroll
     for (int i = 0; i < NV; ++i) red[NV * wave + i] = v[i];
-  __syncthreads();
+  // the barrier orders LDS only: __syncthreads() would also drain vmcnt -- the message stores of the previous layer and
+  // the early loads of the partner's message (pair_peek) must stay in flight across it
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
 }
@@ -298,7 +321,7 @@ MZ_DEV void merge_moments(float m0, float q0, float m1, float q1, float& mean, f
 // is sharded over GPUs).
 template <int NW>
 MZ_DEV void layer_norm_tiles(f32x4 (&acc)[NW][3], const float* const (&so)[NW], const bool (&relu)[NW], int ch, int lane,
-                             int wave, float* red) {
+                             int wave, RedSlots& red) {
   const int g = lane >> 4;
   float mh[2 * NW], qh[2 * NW];
 #pragma unroll
@@ -363,15 +386,25 @@ MZ_DEV void conv1x1_tiles(const float* in, const int (&rowbase)[3], const float*
                           int KC, int g, f32x4 (&acc)[3]) {
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  for (int c = 0; c < KC; ++c) {
-    f32x4u a[3];
+  // four groups of 16 input channels at a time, their 16 weights requested before the first MFMA (one group per trip
+  // was one L2 round trip per group: 2.4 of the 3 us a 64-channel 1x1 convolution took)
+  for (int c0 = 0; c0 < KC; c0 += 4) {
+    float b[4][4];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) a[mt] = *reinterpret_cast<const f32x4u*>(in + rowbase[mt] + 16 * c);
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float b = W[(16 * c + 4 * g + i) * ldw + ncol];
+      for (int i = 0; i < 4; ++i) b[c][i] = c0 + c < KC ? W[(16 * (c0 + c) + 4 * g + i) * ldw + ncol] : 0.0f;
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], b, acc[mt], 0, 0, 0);
+    for (int c = 0; c < 4; ++c) {
+      if (c0 + c < KC) {
+        f32x4u a[3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a[mt] = *reinterpret_cast<const f32x4u*>(in + rowbase[mt] + 16 * (c0 + c));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], b[c][i], acc[mt], 0, 0, 0);
+      }
     }
   }
 }
@@ -472,6 +505,19 @@ MZ_DEV float pair_get(const PairLink& L, const pair_word* in, int i) {
   }
   return __uint_as_float((unsigned)w);
 }
+// Early copies (round 4): the slower half of a pair (half 1) finds the partner's message already in L2 when it
+// finishes its own convolution, yet paid one L2 round trip (~0.65 us, 16 times a pass) to look at it AFTER posting its
+// own.  It now issues the loads of the words it will need between its two moment reductions -- in flight while it
+// reduces and posts -- and takes a copy whose stamp is the awaited message number; any other copy falls back to polling.
+// (a relaxed system-scope atomic load: the same `sc0 sc1` access as the polling load, but the compiler waits for it at
+// its first use -- a volatile load gets `s_waitcnt vmcnt(0)` right behind it, six serial round trips)
+MZ_DEV unsigned long long pair_peek(const pair_word* in, int i) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(in + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+MZ_DEV float pair_take(const PairLink& L, const pair_word* in, int i, unsigned long long early) {
+  if ((unsigned)(early >> 32) == L.seq) return __uint_as_float((unsigned)early);
+  return pair_get(L, in, i);
+}
 // header word 4 of every message: the sender's XCC id
 MZ_DEV void pair_check_xcc(const PairLink& L, const pair_word* in, int tid) {
   if (tid == 0 && __float_as_uint(pair_get(L, in, 4)) != L.xcc && *reinterpret_cast<const volatile unsigned*>(L.status) == 0u)
@@ -480,8 +526,13 @@ MZ_DEV void pair_check_xcc(const PairLink& L, const pair_word* in, int tid) {
 MZ_DEV int map_word(int px) { return ((px / kTowerHW + 1) * kHalo + px % kTowerHW + 1) * kPixStride; }
 
 // moments of the OWN pixels of NW maps: mean over n_own * 64 elements and M2 = sum (x - mean)^2
-template <int NW, int TSEL>
-MZ_DEV void own_moments(const f32x4 (&acc)[NW][3], float (&mean)[NW], float (&m2)[NW], int lane, int wave, float* red) {
+struct NoMidWork {
+  MZ_DEV void operator()() const {}
+};
+// (`mid` runs between the two reductions: the early loads of the partner's message, below)
+template <int NW, int TSEL, class Mid = NoMidWork>
+MZ_DEV void own_moments(const f32x4 (&acc)[NW][3], float (&mean)[NW], float (&m2)[NW], int lane, int wave, RedSlots& red,
+                        Mid&& mid = Mid()) {
   const int g = lane >> 4;
 #pragma unroll
   for (int s = 0; s < NW; ++s) {
@@ -493,6 +544,7 @@ MZ_DEV void own_moments(const f32x4 (&acc)[NW][3], float (&mean)[NW], float (&m2
         mean[s] = mean[s] + ((tile_on<TSEL>(mt) && 16 * mt + 4 * g + v < kTowerPix) ? acc[s][mt][v] : 0.0f);
   }
   wg_sum<NW>(mean, red, wave, lane);
+  mid();
 #pragma unroll
   for (int s = 0; s < NW; ++s) {
     mean[s] = mean[s] * (1.0f / (PairGeom<TSEL>::n_own * kTowerC));
@@ -608,8 +660,24 @@ MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in
 }
 // prediction heads on the normalised next state held in `cur` (haloed map)
 MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const float* cur, const HeadLds& H, const int (&rowc)[3],
-                             int tid, int lane, int wave) {
+                             int tid, int lane, int wave MZ_TH_PARAMS) {
   const int g4 = lane >> 4, n16 = lane & 15;
+  // the weights of the last layers do not depend on the map: requested here, before the 1x1 convolutions and their
+  // barriers (a barrier is a fence: the compiler cannot hoist them itself).  The flatten -> Linear(576 -> 16) matrices were
+  // tried up here too (the first convolution's own weight loads queue behind those 72 loads) and as a copy in LDS for
+  // the whole search (the layer went from 0.4 to 1.9 us): the phase is the 192 MFMAs of the first 1x1 convolutions on
+  // one wave per head, 2.6 of its 8 us (profiles/r04_search_phases.txt).
+  const int n = tid & 15, sl = tid >> 4;
+  float wl2[16];
+  float bl2 = 0.0f;
+  {
+    const bool isv = tid < p.F, isp = tid >= 64 && tid < 64 + p.A;
+    const int j = isv ? tid : tid - 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wl2[k] = isv ? p.v_l2[k * p.F + j] : (isp ? p.p_l2[k * p.A + j] : 0.0f);
+    bl2 = isv ? p.v_b2[j] : (isp ? p.p_b2[j] : 0.0f);
+  }
+  const float bl1 = tid < 32 ? (tid < 16 ? p.v_b1[n] : p.p_b1[n]) : 0.0f;
   if (wave < 2) {  // wave 0: value head, wave 1: policy head -- first 1x1 conv (64 -> 16) + relu
     f32x4 h[3];
     conv1x1_tiles(cur, rowc, wave == 0 ? p.v_c1 : p.p_c1, 16, n16, 4, g4, h);
@@ -623,6 +691,7 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
       }
   }
   __syncthreads();
+  MZ_TH(6)
   if (wave == 0) {  // value head: second 1x1 conv (16 -> 16) + relu
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
@@ -635,9 +704,9 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
     }
   }
   __syncthreads();
+  MZ_TH(7)
   {
     // Linear(576 -> 16) of both heads: thread = (output unit n, one of 16 slices of 36 inputs)
-    const int n = tid & 15, sl = tid >> 4;
     float sv = 0.0f, sp = 0.0f;
     float wv[36], wp[36];
 #pragma unroll
@@ -655,29 +724,32 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
     H.part2[tid] = sp;
   }
   __syncthreads();
+  MZ_TH(8)
   if (tid < 32) {
-    const int n = tid & 15;
     const float* src = tid < 16 ? H.part : H.part2;
     float a = 0.0f;
-    for (int sl = 0; sl < 16; ++sl) a = a + src[sl * 16 + n];
-    H.vec[tid] = fmaxf(a + (tid < 16 ? p.v_b1[n] : p.p_b1[n]), 0.0f);
+    for (int q = 0; q < 16; ++q) a = a + src[q * 16 + n];
+    H.vec[tid] = fmaxf(a + bl1, 0.0f);
   }
   __syncthreads();
   if (tid < p.F) {
     float a = 0.0f;
-    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[k], p.v_l2[k * p.F + tid], a);
-    H.lgt[tid] = a + p.v_b2[tid];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[k], wl2[k], a);
+    H.lgt[tid] = a + bl2;
   } else if (tid >= 64 && tid < 64 + p.A) {
     const int j = tid - 64;
     float a = 0.0f;
-    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[16 + k], p.p_l2[k * p.A + j], a);
-    io.prior_logits[j] = a + p.p_b2[j];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[16 + k], wl2[k], a);
+    io.prior_logits[j] = a + bl2;
   }
   __syncthreads();
   if (wave == 0) {
     const float vl = decode_support(H.lgt, p.F, p.support, lane);
     if (lane == 0) *io.value = vl;
   }
+  MZ_TH(9)
 }
 
 MZ_DEV void load_state(const float* xin, float* buf, int tid) {
@@ -721,9 +793,9 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
   using Geo = PairGeom<TSEL>;
   float* bufA = lds;
   float* bufB = lds + kBufWords;
-  float* red = lds + 2 * kBufWords;
+  RedSlots red = {lds + 2 * kBufWords, 0};
   HeadLds H;
-  H.hv = red + 16;            // [48][16] value head map (rows >= 36 stay zero)
+  H.hv = red.base + 32;            // [48][16] value head map (rows >= 36 stay zero)
   H.hv2 = H.hv + 768;         // [48][16]
   H.hp = H.hv2 + 768;         // [48][16] policy head map
   H.part = H.hp + 768;        // [256] partial sums of the flatten -> Linear layers
@@ -818,23 +890,33 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
       const float* const w2[2] = {W, W + CW};
       const float* const nx[2] = {W + 2 * CW, W + 2 * CW};  // one stream follows; the second fetch is a dummy
       conv3x3_tiles<2, TSEL, AH>(cur, w2, nx, abase, wcol, lane, pf, pr);
-      MZ_TT(3)
+      MZ_TP(3)
       const float* const so[2] = {LN, LN + 2 * kTowerC};
       if constexpr (!PAIR) {
         const bool rl[2] = {false, true};
         layer_norm_tiles<2>(pr, so, rl, ch, lane, wave, red);
       } else {
-        // message A: moments of both maps + the raw boundary pixels of conv_0's map
-        float m[2], q[2];
-        own_moments<2, TSEL>(pr, m, q, lane, wave, red);
-        MZ_TT(4)
+        // message A: the raw boundary pixels of conv_0's map (posted first: the stores travel while the moments are
+        // reduced) + the moments of both maps
         pair_word* out = pair_begin(L);
+        put_boundary<TSEL>(L, pr[1], out, 8, ch, lane);
+        const pair_word* ein = pair_in(L);
+        float m[2], q[2];
+        unsigned long long ea[6] = {0, 0, 0, 0, 0, 0};
+        own_moments<2, TSEL>(pr, m, q, lane, wave, red, [&]() {
+          if constexpr (TSEL == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ea[k] = pair_peek(ein, k);
+            ea[4] = pair_peek(ein, 8 + tid);
+            if (tid + 256 < kPairBnd * kTowerC) ea[5] = pair_peek(ein, 8 + tid + 256);
+          }
+        });
+        MZ_TP(4)
         if (tid == 0) {
           pair_put(L, out, 0, m[0]); pair_put(L, out, 1, q[0]); pair_put(L, out, 2, m[1]); pair_put(L, out, 3, q[1]);
           pair_put(L, out, 4, __uint_as_float(L.xcc));
         }
-        put_boundary<TSEL>(L, pr[1], out, 8, ch, lane);
-        MZ_TT(5)
+        MZ_TP(5)
         if constexpr (TSEL == 1) {
           if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
           else if (rh_k >= 9) idle(rh_k - 9);
@@ -845,47 +927,68 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         float mean[2], rstd[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const float mo = pair_get(L, in, 2 * s), qo = pair_get(L, in, 2 * s + 1);
+          const float mo = pair_take(L, in, 2 * s, ea[2 * s]), qo = pair_take(L, in, 2 * s + 1, ea[2 * s + 1]);
           if (TSEL == 1) merge_moments(m[s], q[s], mo, qo, mean[s], rstd[s]);
           else merge_moments(mo, qo, m[s], q[s], mean[s], rstd[s]);
         }
-        pair_check_xcc(L, in, tid);
-        MZ_TT(6)
+        // (the sender's XCC id is checked once a pass, in message C: a workgroup does not move, and the check is one more
+        // L2 round trip of wave 0 -- 0.45 us, 16 times a pass, in the half that does not wait for anything else)
+        MZ_TP(6)
         norm_tiles(pr[0], mean[0], rstd[0], so[0], false, ch);
         norm_tiles(pr[1], mean[1], rstd[1], so[1], true, ch);
-        for (int i = tid; i < kPairBnd * kTowerC; i += 256) {
-          const int c = i & 63;
-          const float o = (pair_get(L, in, 8 + i) - mean[1]) * rstd[1] * so[1][c] + so[1][kTowerC + c];
-          oth[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(o, 0.0f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = tid + 256 * k;
+          if (i < kPairBnd * kTowerC) {
+            const int c = i & 63;
+            const float o = (pair_take(L, in, 8 + i, ea[4 + k]) - mean[1]) * rstd[1] * so[1][c] + so[1][kTowerC + c];
+            oth[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(o, 0.0f);
+          }
         }
       }
     }
     store_map<TSEL>(pr[1], oth, ch, lane);
     __syncthreads();
-    MZ_TT(7)
+    MZ_TP(7)
     f32x4 out[1][3];
     {
       const float* const w1[1] = {W + 2 * CW};
       const float* const nx[2] = {last ? W : W + 3 * CW, last ? W : W + 4 * CW};  // (last block: dummies)
       conv3x3_tiles<1, TSEL, AH>(oth, w1, nx, abase, wcol, lane, pf, out);
-      MZ_TT(8)
+      MZ_TP(8)
       const float* const so[1] = {LN + 4 * kTowerC};
       if constexpr (!PAIR) {
         const bool rl[1] = {false};
         layer_norm_tiles<1>(out, so, rl, ch, lane, wave, red);
       } else {
-        // message B: moments + raw boundary pixels of conv_1's map + the normalised shortcut at those pixels
-        float m[1], q[1];
-        own_moments<1, TSEL>(out, m, q, lane, wave, red);
-        MZ_TT(4)
+        // message B: raw boundary pixels of conv_1's map + the normalised shortcut at those pixels (posted first) + moments
         pair_word* msg = pair_begin(L);
+        put_boundary<TSEL>(L, out[0], msg, 8, ch, lane);
+        put_boundary<TSEL>(L, pr[0], msg, 8 + kPairBnd * kTowerC, ch, lane);
+        const pair_word* ein = pair_in(L);
+        float m[1], q[1];
+        unsigned long long eb[6] = {0, 0, 0, 0, 0, 0};
+        own_moments<1, TSEL>(out, m, q, lane, wave, red, [&]() {
+          if constexpr (TSEL == 2) {
+            eb[2] = pair_peek(ein, 8 + tid);
+            eb[4] = pair_peek(ein, 8 + kPairBnd * kTowerC + tid);
+            if (tid + 256 < kPairBnd * kTowerC) {
+              eb[3] = pair_peek(ein, 8 + tid + 256);
+              eb[5] = pair_peek(ein, 8 + kPairBnd * kTowerC + tid + 256);
+            }
+          }
+        });
+        if constexpr (TSEL == 2) {
+          // (pass B is nearly balanced: the partner's moments are posted about now, later than its boundary pixels)
+          eb[0] = pair_peek(ein, 0);
+          eb[1] = pair_peek(ein, 1);
+        }
+        MZ_TP(4)
         if (tid == 0) {
           pair_put(L, msg, 0, m[0]); pair_put(L, msg, 1, q[0]);
           pair_put(L, msg, 4, __uint_as_float(L.xcc));
         }
-        put_boundary<TSEL>(L, out[0], msg, 8, ch, lane);
-        put_boundary<TSEL>(L, pr[0], msg, 8 + kPairBnd * kTowerC, ch, lane);
-        MZ_TT(5)
+        MZ_TP(5)
         if constexpr (TSEL == 1) {
           if (p.heads && rh_k < 9) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
           else if (rh_k >= 9) idle(rh_k - 9);
@@ -894,16 +997,20 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         }
         const pair_word* in = pair_in(L);
         float mean, rstd;
-        const float mo = pair_get(L, in, 0), qo = pair_get(L, in, 1);
-        pair_check_xcc(L, in, tid);
-        MZ_TT(6)
+        const float mo = pair_take(L, in, 0, eb[0]), qo = pair_take(L, in, 1, eb[1]);
+        MZ_TP(6)
         if (TSEL == 1) merge_moments(m[0], q[0], mo, qo, mean, rstd);
         else merge_moments(mo, qo, m[0], q[0], mean, rstd);
         norm_tiles(out[0], mean, rstd, so[0], false, ch);
-        for (int i = tid; i < kPairBnd * kTowerC; i += 256) {
-          const int c = i & 63;
-          const float o = (pair_get(L, in, 8 + i) - mean) * rstd * so[0][c] + so[0][kTowerC + c];
-          cur[map_word(Geo::recv_first + (i >> 6)) + c] = fmaxf(pair_get(L, in, 8 + kPairBnd * kTowerC + i) + o, 0.0f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = tid + 256 * k;
+          if (i < kPairBnd * kTowerC) {
+            const int c = i & 63;
+            const float o = (pair_take(L, in, 8 + i, eb[2 + k]) - mean) * rstd * so[0][c] + so[0][kTowerC + c];
+            cur[map_word(Geo::recv_first + (i >> 6)) + c] =
+                fmaxf(pair_take(L, in, 8 + kPairBnd * kTowerC + i, eb[4 + k]) + o, 0.0f);
+          }
         }
       }
     }
@@ -913,7 +1020,7 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
       for (int v = 0; v < 4; ++v) acc[mt][v] = fmaxf(pr[0][mt][v] + out[0][mt][v], 0.0f);
     store_map<TSEL>(acc, cur, ch, lane);  // every wave is past its reads of `cur` (the LayerNorm barriers)
     __syncthreads();
-    MZ_TT(9)
+    MZ_TP(9)
   }
   if (p.blocks == 0) {
     // (stem only) bring the map back into registers
@@ -998,6 +1105,7 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         __syncthreads();
         reward_finish(p, io, H, rh_acc, tid, lane, wave);
       }
+      MZ_TH(3)
       // ---- prediction heads on the normalised next state ----
       store_map<TSEL>(acc, cur, ch, lane);
       if constexpr (TSEL == 1) {
@@ -1009,14 +1117,22 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
           cmn[kTowerC + ch] = scale;
         }
         __syncthreads();
-        for (int i = tid; i < 20 * kTowerC; i += 256) {
-          const int c = i & 63;
-          const float raw = pair_get(L, fin, 8 + 2 * kTowerC + i);
-          cur[map_word(16 + (i >> 6)) + c] = p.normalize ? (raw - cmn[c]) / cmn[kTowerC + c] : raw;
+        {
+          // (five words a thread: all five loads in flight at once; a copy that is not message C yet is polled)
+          unsigned long long ew[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) ew[k] = pair_peek(fin, 8 + 2 * kTowerC + tid + 256 * k);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const int i = tid + 256 * k, c = i & 63;
+            const float raw = pair_take(L, fin, 8 + 2 * kTowerC + i, ew[k]);
+            cur[map_word(16 + (i >> 6)) + c] = p.normalize ? (raw - cmn[c]) / cmn[kTowerC + c] : raw;
+          }
         }
       }
       __syncthreads();
-      prediction_heads(p, io, cur, H, rowc, tid, lane, wave);
+      MZ_TH(4)
+      prediction_heads(p, io, cur, H, rowc, tid, lane, wave MZ_TH_ARGS);
     }
   }
   MZ_TT(11)

@@ -139,12 +139,8 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
           // message T (number k + 1): what the next pass works on; "strong": half 0's own pixels of the new row and the
           // tree are complete before the partner can see it (and every thread is past message Y)
           pair_word* msg = pair_begin_strong(L);
-          if (tid == 0) {
-            pair_put(L, msg, 0, __int_as_float(parent));
-            pair_put(L, msg, 1, __int_as_float(action));
-            pair_put(L, msg, 2, __int_as_float(newn));
-            pair_put(L, msg, 4, __uint_as_float(L.xcc));
-          }
+          // (one word: parent | action << 12 | new node << 20 -- the partner's next pass starts one L2 round trip after it)
+          if (tid == 0) pair_put(L, msg, 0, __int_as_float(parent | (action << 12) | (newn << 20)));
         } else {
           L.seq += 1;
         }
@@ -162,10 +158,10 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
         L.seq += 1;  // (half 1 posts nothing under the number of message T)
         if (more) {
           const pair_word* in = pair_in(L);
-          parent = __float_as_int(pair_get(L, in, 0));
-          action = __float_as_int(pair_get(L, in, 1));
-          newn = __float_as_int(pair_get(L, in, 2));
-          pair_check_xcc(L, in, tid);
+          const unsigned w = (unsigned)__float_as_int(pair_get(L, in, 0));
+          parent = (int)(w & 0xfffu);
+          action = (int)((w >> 12) & 0xffu);
+          newn = (int)(w >> 20);
           MZ_ST(2)
           if (pair_lost_uniform(L, tid, &lost_flag)) return;
           parent = min(max(parent, 0), N - 1);  // (a lost message must not turn into a wild address)
@@ -226,6 +222,8 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
     return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: too many blocks");
   const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 15 * ((size_t)sa.S + 2);
   if (lds > 160 * 1024) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: num_simulations too large for the LDS of a CU");
+  if (sa.S + 1 > 4096 || sa.A > 255)
+    return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: message T packs (node, action, node) as 12 + 8 + 12 bits");
   const mz::SearchLoop loop = {sim_begin, sim_end, discount};
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const bool gumbel = policy == 1;

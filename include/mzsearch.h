@@ -359,6 +359,29 @@ typedef struct mzs_conv3x3_args {
 } mzs_conv3x3_args;
 int mzs_conv3x3_nhwc(const mzs_conv3x3_args *a, void *stream);
 
+/* A whole ResidualConvBlockV1 (muax/nn.py:118-148: conv_0 - LN - relu - conv_1 - LN, + LN(projection conv) or + x,
+ * relu) of those nets, stride 1, C -> C with C = 32 or 64, inference, in three launches: the projection and conv_0
+ * share one pass over the input and leave the moments of their outputs, conv_1 normalises its input on the way into
+ * LDS, one streaming pass applies the last LayerNorm(s), the shortcut and the relu (mz_repr.cuh, mz_norm.cuh).
+ *   w_proj / w0 / w1: packed kernels as for mzs_conv3x3_nhwc; w_proj NULL = identity shortcut (y = relu(LN1(.) + x)).
+ *   workspace >= mzs_resblock_workspace_bytes(...) bytes of device memory, overwritten; y must not alias x. */
+typedef struct mzs_resblock_args {
+  int32_t struct_size;     /* = sizeof(mzs_resblock_args) */
+  int32_t device;
+  int32_t batch, height, width, channels;
+  float eps;               /* haiku: 1e-5 */
+  int32_t reserved0;
+  const float *x;          /* [B, H, W, C] */
+  const float *w_proj, *w0, *w1;
+  const float *proj_scale, *proj_offset;   /* [C] each; NULL with w_proj NULL */
+  const float *ln0_scale, *ln0_offset, *ln1_scale, *ln1_offset;
+  float *y;                /* [B, H, W, C] out */
+  void *workspace;
+  int64_t workspace_bytes;
+} mzs_resblock_args;
+int mzs_resblock_v1(const mzs_resblock_args *a, void *stream);
+int64_t mzs_resblock_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused-kernel instances built on demand.
  *

@@ -28,8 +28,8 @@ UNITS = {
     "mz_fused_g4.hip": _FUSED,
     "mz_conv.hip": ["mz_host.h", "mz_conv_host.h", "mz_conv.cuh", "mz_spec.cuh", _ABI],
     "mz_search_conv.hip": ["mz_host.h", "mz_conv_host.h", "mz_conv.cuh", "mz_step.cuh", "mz_step_jump.cuh", "mz_spec.cuh", _ABI],
-    "mz_norm.hip": ["mz_host.h", "mz_norm.cuh", _ABI],
-    "mz_repr.hip": ["mz_host.h", "mz_repr.cuh", "mz_spec.cuh", _ABI],
+    "mz_norm.hip": ["mz_host.h", "mz_norm.cuh", "mz_repr.cuh", "mz_repr_host.h", "mz_spec.cuh", _ABI],
+    "mz_repr.hip": ["mz_host.h", "mz_repr.cuh", "mz_repr_host.h", "mz_norm.cuh", "mz_spec.cuh", _ABI],
     "mz_ez.hip": ["mz_host.h", "mz_ez.cuh", "mz_spec.cuh", _ABI],
 }
 SOURCES = list(UNITS)

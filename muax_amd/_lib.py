@@ -104,6 +104,14 @@ class MzsConv3x3Args(C.Structure):
                 ("x", _vp), ("w_packed", _vp), ("y", _vp)]
 
 
+class MzsResblockArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("channels", C.c_int32), ("eps", C.c_float), ("reserved0", C.c_int32),
+                ("x", _vp), ("w_proj", _vp), ("w0", _vp), ("w1", _vp), ("proj_scale", _vp), ("proj_offset", _vp),
+                ("ln0_scale", _vp), ("ln0_offset", _vp), ("ln1_scale", _vp), ("ln1_offset", _vp), ("y", _vp),
+                ("workspace", _vp), ("workspace_bytes", C.c_int64)]
+
+
 EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_destroy",
                     "mzs_mlp_set_weights", "mzs_act_mlp", "mzs_root", "mzs_root_gumbel", "mzs_select",
                     "mzs_expand_backup", "mzs_expand_backup_select",
@@ -111,7 +119,8 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
                     "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
-                    "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc"]
+                    "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc",
+                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes"]
 
 _lib = None
 
@@ -149,6 +158,8 @@ def load(build_if_missing: bool = True):
     L.mzs_register_fused_dispatch.argtypes = [_vp, C.c_int32]
     L.mzs_mlp_allow_generic.argtypes = [_vp, C.c_int32]
     L.mzs_conv3x3_nhwc.argtypes = [C.POINTER(MzsConv3x3Args), _vp]
+    L.mzs_resblock_v1.argtypes = [C.POINTER(MzsResblockArgs), _vp]
+    L.mzs_resblock_workspace_bytes.argtypes = [C.c_int32] * 4
     L.mzs_resnet_search.argtypes = [_vp, C.POINTER(MzsTowerArgs), C.c_float, C.c_int32, C.c_int32, _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4
     L.mzs_mlp_train_workspace_bytes.argtypes = [C.c_int32] * 5
@@ -162,6 +173,7 @@ def load(build_if_missing: bool = True):
     L.mzs_layernorm_act.argtypes = [C.POINTER(MzsLayerNormArgs), _vp]
     L.mzs_layernorm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     L.mzs_layernorm_workspace_bytes.restype = C.c_int64
+    L.mzs_resblock_workspace_bytes.restype = C.c_int64
     L.mzs_tower_pair_scratch_bytes.argtypes = [C.c_int32]
     L.mzs_tower_pair_scratch_bytes.restype = C.c_int64
     if L.mzs_abi_version() != 1:

@@ -27,6 +27,21 @@ struct NormParams {
 
 constexpr int kNormThreads = 256;
 
+// mean and 1 / sqrt(var + eps) of a sample from its K (sum, sum of squares) pairs
+__device__ __forceinline__ void ln_stats(const double* ws, int K, int n, float eps, float& mean, float& rstd) {
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < K; ++k) { s += ws[2 * k]; q += ws[2 * k + 1]; }
+  const double m = s / (double)n;
+  double var = q / (double)n - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  mean = (float)m;
+  rstd = 1.0f / sqrtf((float)var + eps);
+}
+
+
+// (mz_repr.hip takes ln_stats only: the kernels below belong to mz_norm.hip's translation unit)
+#ifndef MZ_NORM_STATS_ONLY
+
 __global__ __launch_bounds__(kNormThreads) void ln_moments_kernel(NormParams p) {
   const int b = blockIdx.x, k = blockIdx.y, t = blockIdx.z;  // samples in grid x: no 65535 limit on the batch
   const float* src = (t == 0 ? p.x : p.x2) + (size_t)b * p.n;
@@ -56,16 +71,6 @@ __global__ __launch_bounds__(kNormThreads) void ln_moments_kernel(NormParams p) 
     out[0] = ts;
     out[1] = tq;
   }
-}
-
-__device__ __forceinline__ void ln_stats(const double* ws, int K, int n, float eps, float& mean, float& rstd) {
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < K; ++k) { s += ws[2 * k]; q += ws[2 * k + 1]; }
-  const double m = s / (double)n;
-  double var = q / (double)n - m * m;
-  var = var < 0.0 ? 0.0 : var;
-  mean = (float)m;
-  rstd = 1.0f / sqrtf((float)var + eps);
 }
 
 #pragma clang fp contract(off)
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(kNormThreads) void ln_apply_kernel(NormParams p) {
     *reinterpret_cast<float4*>(p.y + base + i) = y;
   }
 }
+
+#endif  // MZ_NORM_STATS_ONLY
 
 inline int norm_chunks(int n) {
   int k = n / 4096;

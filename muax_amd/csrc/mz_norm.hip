@@ -1,10 +1,12 @@
-// mz_norm.hip -- translation unit of the fused LayerNorm (+ add, + relu) of the convolutional plugin nets (mz_norm.cuh).
+// mz_norm.hip -- translation unit of the fused LayerNorm (+ add, + relu) of the convolutional plugin nets (mz_norm.cuh)
+// and of a whole residual block of the representation nets in three launches (mzs_resblock_v1: mz_repr.cuh + mz_norm.cuh).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 
 #include "mz_host.h"
 #include "mz_norm.cuh"
+#include "mz_repr_host.h"
 
 extern "C" {
 
@@ -45,6 +47,76 @@ int mzs_layernorm_act(const mzs_layernorm_args* a, void* stream_) {
   int slices = (a->n + per_block - 1) / per_block;
   if (slices > 65535) slices = 65535;  // (grid y; the kernel strides over the sample)
   hipLaunchKernelGGL(mz::ln_apply_kernel, dim3(a->batch, slices), dim3(mz::kNormThreads), 0, stream, p);
+  MZS_HIPG(hipGetLastError());
+  return MZS_OK;
+}
+
+// ---- ResidualConvBlockV1 (muax/nn.py:118-148), stride 1, C -> C, in three launches --------------------------------
+//   K1  projection and conv_0 of the input in one pass over the staged rows (mz_repr.cuh, NW = 2), each workgroup
+//       leaving the (sum, sum of squares) of its outputs in fp64;
+//   K2  conv_1 on relu(LayerNorm_0(conv_0)): the normalisation happens on the way into LDS, from K1's moments;
+//   K3  relu(LayerNorm_1(conv_1) + LayerNorm_p(projection))  (or + x, the identity shortcut) from the moments: the
+//       apply kernel of mz_norm.cuh.  The two moment passes and one apply pass of the five-call chain are gone.
+static size_t resblock_moment_doubles(int batch, int blocks) { return (size_t)3 * batch * blocks * 2; }
+
+int64_t mzs_resblock_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels) {
+  if (batch <= 0 || height <= 0 || width <= 0 || (channels != 32 && channels != 64)) return 0;
+  const mzr::Geometry g = mzr::geometry(height, width, channels);
+  const size_t n = (size_t)batch * height * width * channels;
+  return (int64_t)(3 * n * sizeof(float) + resblock_moment_doubles(batch, g.blocks) * sizeof(double));
+}
+
+int mzs_resblock_v1(const mzs_resblock_args* a, void* stream_) {
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_resblock_args))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v1: null arguments or size mismatch (ABI)");
+  if (a->batch <= 0 || a->height <= 0 || a->width <= 0 || !a->x || !a->w0 || !a->w1 || !a->y || !a->workspace)
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v1: batch / height / width / pointers");
+  if (!a->ln0_scale || !a->ln0_offset || !a->ln1_scale || !a->ln1_offset || (a->w_proj && (!a->proj_scale || !a->proj_offset)))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v1: every LayerNorm needs its scale and offset");
+  if (a->channels != 32 && a->channels != 64)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v1: channels must be 32 or 64 (in == out)");
+  if (a->workspace_bytes < mzs_resblock_workspace_bytes(a->batch, a->height, a->width, a->channels))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v1: workspace too small");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return mzh::fail_global(MZS_E_NODEVICE, "mzs_resblock_v1: no HIP device (this library has no CPU fallback)");
+  if (a->device < 0 || a->device >= ndev) return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v1: bad device ordinal");
+  MZS_HIPG(hipSetDevice(a->device));
+  const int C = a->channels, n1 = a->height * a->width * C;
+  const mzr::Geometry g = mzr::geometry(a->height, a->width, C);
+  if (g.lds > 160 * 1024) return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v1: image too wide for the LDS of a CU");
+  const size_t n = (size_t)a->batch * n1, bk2 = (size_t)a->batch * g.blocks * 2;
+  float* c0 = static_cast<float*>(a->workspace);
+  float* out = c0 + n;
+  float* cp = out + n;
+  double* m_out = reinterpret_cast<double*>(cp + n);  // [out][projection][conv_0] moments, [B][K][2] each
+  double* m_cp = m_out + bk2;
+  double* m_c0 = m_cp + bk2;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  mz::ReprConvParams p;
+  memset(&p, 0, sizeof p);
+  p.B = a->batch; p.H = a->height; p.W = a->width; p.eps = a->eps;
+  p.x = a->x;
+  if (a->w_proj) {
+    p.wp = a->w_proj; p.y = cp; p.wp2 = a->w0; p.y2 = c0; p.mom = m_cp;  // (stream 0 -> m_cp, stream 1 -> m_c0)
+    if (int rc = mzr::conv<2, false, true>(p, C, g, stream)) return rc;
+  } else {
+    p.wp = a->w0; p.y = c0; p.mom = m_c0;
+    if (int rc = mzr::conv<1, false, true>(p, C, g, stream)) return rc;
+  }
+  p.x = c0; p.wp = a->w1; p.y = out; p.wp2 = nullptr; p.y2 = nullptr; p.mom = m_out;
+  p.in_mom = m_c0; p.in_scale = a->ln0_scale; p.in_offset = a->ln0_offset;
+  if (int rc = mzr::conv<1, true, true>(p, C, g, stream)) return rc;
+  mz::NormParams q;
+  memset(&q, 0, sizeof q);
+  q.x = out; q.scale = a->ln1_scale; q.offset = a->ln1_offset;
+  if (a->w_proj) { q.x2 = cp; q.scale2 = a->proj_scale; q.offset2 = a->proj_offset; }
+  else q.residual = a->x;
+  q.y = a->y; q.ws = m_out; q.B = a->batch; q.n = n1; q.C = C; q.K = g.blocks; q.relu = 1; q.eps = a->eps;
+  const int per_block = 4 * mz::kNormThreads * 4;
+  int slices = (n1 + per_block - 1) / per_block;
+  if (slices > 65535) slices = 65535;
+  hipLaunchKernelGGL(mz::ln_apply_kernel, dim3(a->batch, slices), dim3(mz::kNormThreads), 0, stream, q);
   MZS_HIPG(hipGetLastError());
   return MZS_OK;
 }

@@ -17,6 +17,7 @@
 // Floating-point kernel: checked against the torch module it replaces (MIOpen) and an fp64 evaluation, tolerance in
 // tests/test_gpu_cfg4.py.
 #pragma once
+#include "mz_norm.cuh"
 #include "mz_spec.cuh"
 
 #pragma clang fp contract(off)
@@ -24,15 +25,25 @@
 namespace mz {
 
 struct ReprConvParams {
-  const float* x;    // [B][H][W][C]
-  const float* wp;   // packed weights, 9 * C * C floats
-  float* y;          // [B][H][W][C]
+  const float* x;      // [B][H][W][C]
+  const float* wp;     // packed weights, 9 * C * C floats
+  float* y;            // [B][H][W][C]
   int B, H, W, relu;
+  // --- a residual block in three launches (mzs_resblock_v1, mz_repr.hip) ---
+  const float* wp2;    // NW = 2: a second convolution of the SAME input (the projection beside conv_0) ...
+  float* y2;           // ... and its output
+  // MOM: (sum, sum of squares) of this workgroup's outputs in fp64, the layout mz_norm.cuh's apply kernel adds up:
+  double* mom;         // [NW][B][K = gridDim.x][2]
+  // LNIN: the input is a raw convolution output; its hk.LayerNorm + relu happen on the way into LDS
+  const double* in_mom;  // [B][K][2] of the input tensor (K = gridDim.x: same geometry)
+  const float* in_scale; // [C]
+  const float* in_offset;
+  float eps;
 };
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int C, int TPW>
+template <int C, int TPW, int NW = 1, bool LNIN = false, bool MOM = false>
 __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvParams p) {
   constexpr int NCB = C / 16, NTG = 4 / NCB, NC = C / 16, PS = C + 4, G = 9 * NC;
   constexpr int BLOCK_PX = 16 * TPW * NTG;
@@ -49,18 +60,28 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
     constexpr int QPP = C / 4, PSTEP = 256 / QPP, U = 8;
     const float* img = p.x + (size_t)b * npix * C;
     const int c4 = tid % QPP, npx = nrows * W2;
+    float in_mean = 0.0f, in_rstd = 1.0f;
+    rc_f32x4 in_g = (rc_f32x4){1.0f, 1.0f, 1.0f, 1.0f}, in_o = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (LNIN) {
+      ln_stats(p.in_mom + (size_t)b * gridDim.x * 2, (int)gridDim.x, npix * C, p.eps, in_mean, in_rstd);
+      in_g = *reinterpret_cast<const rc_f32x4*>(p.in_scale + 4 * c4);
+      in_o = *reinterpret_cast<const rc_f32x4*>(p.in_offset + 4 * c4);
+    }
     int px = tid / QPP;
     int ry = px / W2, cx = px - ry * W2;
     while (px < npx) {
       rc_f32x4 v[U];
       int dst[U];
+      bool inside_mask[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int y = row0 + ry, x = cx - 1;
+        inside_mask[u] = false;
         v[u] = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         dst[u] = px < npx ? px : -1;
-        if (px < npx && y >= 0 && y < H && x >= 0 && x < W)
-          v[u] = *reinterpret_cast<const rc_f32x4*>(img + ((size_t)y * W + x) * C + 4 * c4);
+        bool inside = px < npx && y >= 0 && y < H && x >= 0 && x < W;
+        if (inside) v[u] = *reinterpret_cast<const rc_f32x4*>(img + ((size_t)y * W + x) * C + 4 * c4);
+        if constexpr (LNIN) inside_mask[u] = inside;
         px += PSTEP;
         cx += PSTEP;
         while (cx >= W2) {
@@ -69,8 +90,15 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u) {
+        if constexpr (LNIN) {
+          if (inside_mask[u]) {  // (the zero padding of the convolution is applied to the ACTIVATED map: halo stays 0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = fmaxf((v[u][i] - in_mean) * in_rstd * in_g[i] + in_o[i], 0.0f);
+          }
+        }
         if (dst[u] >= 0) *reinterpret_cast<rc_f32x4*>(rc_lds + (size_t)dst[u] * PS + 4 * c4) = v[u];
+      }
     }
   }
   __syncthreads();
@@ -86,15 +114,25 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
     const int py = pc / W, pxx = pc - py * W;
     abase[mt] = ((py - 1 - row0) * W2 + pxx) * PS + 4 * g;
   }
-  rc_f32x4 acc[TPW];
+  rc_f32x4 acc[NW][TPW];
 #pragma unroll
-  for (int mt = 0; mt < TPW; ++mt) acc[mt] = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int mt = 0; mt < TPW; ++mt) acc[s][mt] = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   // Software pipeline, stated explicitly (left to itself the scheduler sinks the weight load to its first use -- one L2
   // round trip per group, 20 of the 51 us of the 21 x 21 layers -- and reuses accumulator registers as load targets,
   // which serialises ds_read -> 4 dependent MFMAs): group grp's MFMAs run on registers filled during group grp - 1
-  // (activations: TPW ds_read_b128) and grp - 2 (weights: one global_load_dwordx4), one LDS read issued per 4 MFMAs.
-  const rc_f32x4* wq = reinterpret_cast<const rc_f32x4*>(p.wp) + g * C + ch;  // quad [g][co] of a packed group
-  rc_f32x4 wcur = wq[0], wn1 = wq[(size_t)4 * C];
+  // (activations: TPW ds_read_b128) and grp - 2 (weights: one global_load_dwordx4 per stream), one LDS read issued per
+  // 4 NW MFMAs.
+  const rc_f32x4* wq[NW];
+  wq[0] = reinterpret_cast<const rc_f32x4*>(p.wp) + g * C + ch;  // quad [g][co] of a packed group
+  if constexpr (NW == 2) wq[1] = reinterpret_cast<const rc_f32x4*>(p.wp2) + g * C + ch;
+  rc_f32x4 wcur[NW], wn1[NW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    wcur[s] = wq[s][0];
+    wn1[s] = wq[s][(size_t)4 * C];
+  }
   rc_f32x4 acur[TPW];
 #pragma unroll
   for (int mt = 0; mt < TPW; ++mt) acur[mt] = *reinterpret_cast<const rc_f32x4*>(rc_lds + abase[mt]);
@@ -106,7 +144,9 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int grp = tap * NC + c;
-      const rc_f32x4 wn2 = wq[(size_t)(grp + 2 < G ? grp + 2 : G - 1) * 4 * C];
+      rc_f32x4 wn2[NW];
+#pragma unroll
+      for (int s = 0; s < NW; ++s) wn2[s] = wq[s][(size_t)(grp + 2 < G ? grp + 2 : G - 1) * 4 * C];
       const int off_next = c + 1 < NC ? toff + 16 * (c + 1) : toff_next;
       rc_f32x4 anext[TPW];
 #pragma unroll
@@ -114,30 +154,77 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int mt = 0; mt < TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[mt][i], wcur[i], acc[mt], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // the weight load first
+        for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+          for (int s = 0; s < NW; ++s)
+            acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[mt][i], wcur[s][i], acc[s][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, NW, 0);  // the weight loads first
 #pragma unroll
       for (int mt = 0; mt < TPW; ++mt) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // four MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one ds_read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NW, 0);  // its share of the MFMAs
       }
 #pragma unroll
       for (int mt = 0; mt < TPW; ++mt) acur[mt] = anext[mt];
-      wcur = wn1;
-      wn1 = wn2;
-    }
-  }
-  float* out = p.y + (size_t)b * npix * C;
 #pragma unroll
-  for (int mt = 0; mt < TPW; ++mt)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int px = p0 + 16 * (tg * TPW + mt) + 4 * g + v;
-      if (px < p1) {
-        const float o = acc[mt][v];
-        out[(size_t)px * C + ch] = p.relu ? fmaxf(o, 0.0f) : o;
+      for (int s = 0; s < NW; ++s) {
+        wcur[s] = wn1[s];
+        wn1[s] = wn2[s];
       }
     }
+  }
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    float* out = (s == 0 ? p.y : p.y2) + (size_t)b * npix * C;
+#pragma unroll
+    for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int px = p0 + 16 * (tg * TPW + mt) + 4 * g + v;
+        if (px < p1) {
+          const float o = acc[s][mt][v];
+          out[(size_t)px * C + ch] = p.relu ? fmaxf(o, 0.0f) : o;
+        }
+      }
+  }
+  if constexpr (MOM) {
+    // (sum, sum of squares) of the RAW outputs of this workgroup, fp64 like mz_norm.cuh's moments kernel: the LayerNorm
+    // that follows needs no pass of its own over the tensor
+    double sq[NW][2];
+#pragma unroll
+    for (int s = 0; s < NW; ++s) {
+      double su = 0.0, qu = 0.0;
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int px = p0 + 16 * (tg * TPW + mt) + 4 * g + v;
+          const double x = px < p1 ? (double)acc[s][mt][v] : 0.0;
+          su += x;
+          qu += x * x;
+        }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        su += __shfl_down(su, d);
+        qu += __shfl_down(qu, d);
+      }
+      sq[s][0] = su;
+      sq[s][1] = qu;
+    }
+    __syncthreads();  // every wave is past its reads of the staged rows
+    double* red = reinterpret_cast<double*>(rc_lds);
+    if (lane == 0)
+#pragma unroll
+      for (int s = 0; s < NW; ++s) {
+        red[(2 * s) * 4 + wave] = sq[s][0];
+        red[(2 * s + 1) * 4 + wave] = sq[s][1];
+      }
+    __syncthreads();
+    if (tid < 2 * NW) {
+      const double t = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
+      p.mom[(((size_t)(tid >> 1) * p.B + b) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = t;
+    }
+  }
 }
 
 // rows of LDS a block of BLOCK_PX consecutive pixels of a width-W image needs (halo included)

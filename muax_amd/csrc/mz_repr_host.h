@@ -1,0 +1,56 @@
+// mz_repr_host.h -- host side of the representation nets' 3x3 convolution kernel (mz_repr.cuh): the launch geometry and
+// the dispatch over the compiled instances, shared by mzs_conv3x3_nhwc (mz_repr.hip) and mzs_resblock_v1 (mz_norm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mz_host.h"
+#include "mz_repr.cuh"
+
+namespace mzr {
+
+struct Geometry {
+  int tiles_per_block, blocks;
+  size_t lds;
+};
+// tiles per workgroup: 14 / 8 / 4 (the block sizes compiled); small maps take the small block so that a batch of 128
+// images still covers the chip
+inline Geometry geometry(int height, int width, int C) {
+  Geometry g;
+  const int tiles = (height * width + 15) / 16;
+  g.tiles_per_block = tiles > 16 ? 14 : (tiles > 8 ? 8 : 4);
+  g.blocks = (tiles + g.tiles_per_block - 1) / g.tiles_per_block;
+  g.lds = sizeof(float) * (size_t)mz::repr_conv_rows(16 * g.tiles_per_block, width) * (width + 2) * (C + 4);
+  return g;
+}
+
+template <int C, int TPW, int NW, bool LNIN, bool MOM>
+int launch(const mz::ReprConvParams& p, int blocks, size_t lds, hipStream_t stream) {
+  static size_t granted[64] = {};
+  int dev = 0;
+  MZS_HIPG(hipGetDevice(&dev));
+  if (lds > granted[dev & 63]) {
+    MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted[dev & 63] = lds;
+  }
+  hipLaunchKernelGGL((mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM>), dim3(blocks, p.B), dim3(256), lds, stream, p);
+  MZS_HIPG(hipGetLastError());
+  return MZS_OK;
+}
+
+// one variant (NW convolutions of the input, LayerNorm + relu on the way in, moments of the outputs) on the instance
+// the geometry picks
+template <int NW, bool LNIN, bool MOM>
+int conv(const mz::ReprConvParams& p, int C, const Geometry& g, hipStream_t s) {
+  const int bt = g.tiles_per_block;
+  if (C == 64) {
+    if (bt == 14) return launch<64, 14, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+    if (bt == 8) return launch<64, 8, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+    return launch<64, 4, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+  }
+  if (bt == 14) return launch<32, 7, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+  if (bt == 8) return launch<32, 4, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+  return launch<32, 2, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+}
+
+}  // namespace mzr

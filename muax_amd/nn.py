@@ -240,8 +240,10 @@ class HkConv2D(nn.Module):
         if not (self.use_hip and self.k == 3 and self.stride == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             return False
         c = x.shape[-1]
-        if c != self.out_channels or c not in (32, 64) or x.shape[1] * x.shape[2] < 100:
-            return False  # (6 x 6 x 64 on 128 images: 13.6 us against the library's 10.7 -- three pixel tiles per image)
+        if c != self.out_channels or c not in (32, 64):
+            return False
+        # (6 x 6 x 64 on 128 images is 13.6 us here against 10.7 for the library's kernel alone, but inside the EZ
+        # encoder the library's side kernels make the same layers 25 us dearer each: every size stays here)
         tiles = (x.shape[1] * x.shape[2] + 15) // 16  # the library's choice of run length (mz_repr.hip) -> its LDS bytes
         run = 16 * (14 if tiles > 16 else (8 if tiles > 8 else 4))
         if ((run + x.shape[2] - 1) // x.shape[2] + 3) * (x.shape[2] + 2) * (c + 4) * 4 > 160 * 1024:
@@ -459,10 +461,49 @@ class ResidualConvBlockV1(nn.Module):
         self.conv_0, self.ln_0 = HkConv2D(channels, 3, stride, generator=generator), HkLayerNorm()
         self.conv_1, self.ln_1 = HkConv2D(channels, 3, 1, generator=generator), HkLayerNorm()
 
+    use_hip = True  # the whole block as one C call (mzs_resblock_v1: three launches) in GPU inference
+
+    def _hip_ok(self, x) -> bool:
+        """mzs_resblock_v1 applies: inference, every layer built, stride-1 C -> C convolutions the HIP kernel takes
+        (HkConv2D._hip_ok), LayerNorms over the whole sample with dense fp32 parameters on x's device."""
+        if not (self.use_hip and x.dim() == 4 and x.is_contiguous() and self.conv_0.w is not None and self.conv_1.w is not None):
+            return False
+        convs = [self.conv_0, self.conv_1] + ([self.proj_conv] if self.use_projection else [])
+        lns = [self.ln_0, self.ln_1] + ([self.proj_ln] if self.use_projection else [])
+        if any(c.w is None or not c._hip_ok(x) for c in convs):
+            return False
+        return all(ln.scale is not None and ln.fused_ok(x) for ln in lns)
+
+    def _forward_hip(self, x):
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        B, H, W, Cc = x.shape
+        a = _lib.MzsResblockArgs()
+        a.struct_size = C.sizeof(_lib.MzsResblockArgs)
+        a.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        a.batch, a.height, a.width, a.channels, a.eps = B, H, W, Cc, 1e-5
+        keep = [self.conv_0._packed(), self.conv_1._packed()]
+        a.x, a.w0, a.w1 = x.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr()
+        if self.use_projection:
+            keep.append(self.proj_conv._packed())
+            a.w_proj, a.proj_scale, a.proj_offset = keep[2].data_ptr(), self.proj_ln.scale.data_ptr(), self.proj_ln.offset.data_ptr()
+        a.ln0_scale, a.ln0_offset = self.ln_0.scale.data_ptr(), self.ln_0.offset.data_ptr()
+        a.ln1_scale, a.ln1_offset = self.ln_1.scale.data_ptr(), self.ln_1.offset.data_ptr()
+        y = torch.empty_like(x)
+        ws = torch.empty(L.mzs_resblock_workspace_bytes(B, H, W, Cc) // 8, dtype=torch.float64, device=x.device)
+        a.y, a.workspace, a.workspace_bytes = y.data_ptr(), ws.data_ptr(), ws.numel() * 8
+        with torch.cuda.device(x.device):
+            _lib.check(L.mzs_resblock_v1(C.byref(a), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return y
+
     def forward(self, x):
         # ln_act = the torch expressions in training / on the CPU, one fused HIP call per chain in GPU inference
         # (module calls in the reference's creation order -- projection, conv_0, conv_1: lazily built weights draw
         # from the generator in that order)
+        if self._hip_ok(x):
+            return self._forward_hip(x)
         cp = self.proj_conv(x) if self.use_projection else None
         out = self.conv_1(ln_act(self.conv_0(x), self.ln_0, relu=True))
         if self.use_projection:

@@ -521,8 +521,8 @@ def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
     conv = mx.nn.HkConv2D(C, 3, 1, in_channels=C, generator=g).cuda()
     x = (torch.rand(B, H, W, C, generator=g) * 2 - 1).cuda()
     with torch.no_grad():
-        assert conv._hip_ok(x) == (H * W >= 100)  # smaller maps stay with the library in the module; the entry point takes them
-        y = conv._conv_hip(x)
+        assert conv._hip_ok(x)
+        y = conv(x)
         conv.use_hip = False
         y_lib = conv(x)
         conv.use_hip = True
@@ -533,24 +533,63 @@ def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
 
 
 def test_representation_net_takes_the_hip_convolutions():
-    """Root inference of the ResNet nets (muax/model.py:251-263) with its 24 C -> C convolutions (42 x 42 x 32, 21 x 21 x 64,
-    11 x 11 x 64) on mzs_conv3x3_nhwc against the same nets on the library's convolutions: embeddings (after
-    min_max_normalize2d), prior logits and values agree to 1e-3 of their largest entries (two fp32 summation orders
-    through 26 convolutions and 17 LayerNorms: 2.2e-4 measured)."""
+    """Root inference of the ResNet nets (muax/model.py:251-263) with its 8 residual blocks (24 C -> C convolutions at
+    42 x 42 x 32, 21 x 21 x 64, 11 x 11 x 64 and their 24 LayerNorms) as mzs_resblock_v1 calls, against the same blocks on
+    single mzs_conv3x3_nhwc / mzs_layernorm_act calls and against the library's convolutions: embeddings (after
+    min_max_normalize2d), prior logits and values agree to 1e-3 of their largest entries (fp32 summation orders through 26
+    convolutions and 17 LayerNorms: 2.2e-4 measured)."""
     m, mods = _nets(5)
     obs = torch.from_numpy(_frames(6, seed=3)).cuda()
-    calls = []
-    orig = mx.nn.HkConv2D._conv_hip
-    mx.nn.HkConv2D._conv_hip = lambda self, x: (calls.append(tuple(x.shape[1:])), orig(self, x))[1]
+    m._root_inference(None, None, obs)  # (lazily built layers: the first call takes the module path)
+    calls, convs = [], []
+    orig, orig_c = mx.nn.ResidualConvBlockV1._forward_hip, mx.nn.HkConv2D._conv_hip
+    mx.nn.ResidualConvBlockV1._forward_hip = lambda self, x: (calls.append(tuple(x.shape[1:])), orig(self, x))[1]
+    mx.nn.HkConv2D._conv_hip = lambda self, x: (convs.append(tuple(x.shape[1:])), orig_c(self, x))[1]
     try:
         pl, v, emb = m._root_inference(None, None, obs)
-    finally:
-        mx.nn.HkConv2D._conv_hip = orig
-    assert calls.count((42, 42, 32)) == 6 and calls.count((21, 21, 64)) == 9 and calls.count((11, 11, 64)) == 9 and len(calls) == 24
-    mx.nn.HkConv2D.use_hip = False
-    try:
+        assert calls.count((42, 42, 32)) == 2 and calls.count((21, 21, 64)) == 3 and calls.count((11, 11, 64)) == 3 and len(calls) == 8
+        assert convs == []
+        mx.nn.ResidualConvBlockV1.use_hip = False
+        pl1, v1, emb1 = m._root_inference(None, None, obs)
+        assert convs.count((42, 42, 32)) == 6 and convs.count((21, 21, 64)) == 9 and convs.count((11, 11, 64)) == 9 and len(convs) == 24
+        mx.nn.HkConv2D.use_hip = False
         pl0, v0, emb0 = m._root_inference(None, None, obs)
     finally:
+        mx.nn.ResidualConvBlockV1._forward_hip, mx.nn.HkConv2D._conv_hip = orig, orig_c
         mx.nn.HkConv2D.use_hip = True
-    for a, b in ((pl, pl0), (v, v0), (emb, emb0)):
-        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
+        mx.nn.ResidualConvBlockV1.use_hip = True
+    for ref in ((pl1, v1, emb1), (pl0, v0, emb0)):
+        for a, b in zip((pl, v, emb), ref):
+            assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("C,H,W,B,proj", [(64, 21, 21, 5, True), (64, 11, 11, 9, True), (32, 42, 42, 3, True), (64, 21, 21, 4, False),
+                                         (32, 13, 29, 2, True), (64, 10, 10, 130, False)])
+def test_residual_block_in_three_launches_against_fp64(C, H, W, B, proj):
+    """mzs_resblock_v1 (ResidualConvBlockV1, muax/nn.py:118-148, projected and identity shortcut) against an fp64
+    evaluation of the block and against the module path (single convolution / LayerNorm calls): a floating-point kernel --
+    within 2e-5 of the fp64 result's largest entry (outputs are O(1): three LayerNorms) and no further from it than twice
+    the module path + that floor."""
+    g = torch.Generator().manual_seed(C + H + B)
+    blk = mx.nn.ResidualConvBlockV1(C, 1, proj, generator=g)
+    x = (torch.rand(B, H, W, C, generator=g) * 2 - 1).cuda()
+    with torch.no_grad():
+        blk.use_hip = False
+        blk(x[:1].cpu())  # builds the layers
+        blk.cuda()
+        for ln in ([blk.ln_0, blk.ln_1] + ([blk.proj_ln] if proj else [])):  # non-trivial scales and offsets
+            ln.scale.copy_(torch.rand(C, generator=g) + 0.5)
+            ln.offset.copy_(torch.rand(C, generator=g) - 0.5)
+        y_mod = blk(x)
+        blk.use_hip = True
+        assert blk._hip_ok(x)
+        y = blk(x)
+        mx.nn.HkConv2D.use_hip = mx.nn.HkLayerNorm.use_hip = False
+        blk.use_hip = False
+        try:
+            y64 = blk.double()(x.double())
+        finally:
+            mx.nn.HkConv2D.use_hip = mx.nn.HkLayerNorm.use_hip = True
+    e_hip, e_mod = float((y.double() - y64).abs().max()), float((y_mod.double() - y64).abs().max())
+    floor = 2e-5 * max(1.0, float(y64.abs().max()))
+    assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_mod + floor, (e_hip, e_mod, floor)

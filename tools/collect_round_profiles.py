@@ -22,7 +22,7 @@ def header(path, default=""):
         return default
     out = []
     for ln in open(path):
-        if ln.startswith("#") or (not ln.strip() and out):
+        if (ln.startswith("#") and not ln.startswith("##")) or (not ln.strip() and out):
             out.append(ln)
         else:
             break
@@ -52,7 +52,9 @@ sections = [("## config 4's shard end to end (tools/bench_atari.py 128 200): 40.
             ("\n## root inference of the convolutional nets, 128 roots of 84x84x4 frames (tools/bench_root_inference.py)\n", "root_inference.txt"),
             ("\n## EfficientZero-style nets through MuZero.act(), search loop as one hipGraph (tools/bench_ez.py [roots] [S] [channels])\n", "ez_bench.txt"),
             ("\n## kernel trace of the EZ search, C = 32 (tools/rocprof_ez.sh 32)\n", "ez_trace.txt"),
-            ("\n## config 5's shape on one GPU (tools/bench_cfg5.py)\n", "cfg5.txt")]
+            ("\n## config 5's shape on one GPU (tools/bench_cfg5.py)\n", "cfg5.txt"),
+            ("\n## the representation nets' C -> C 3x3 convolutions and residual blocks on 128 images (tools/bench_repr_conv.py;\n"
+             "## Python call to call, i.e. >= ~15 us per launch)\n", "repr_conv.txt")]
 write("plugin_nets.txt", "".join(h + rd(n) for h, n in sections if os.path.exists(os.path.join(R, n))),
       f"# {tag} -- wall-clock numbers of the plugin-net paths (1 x MI355X; gpurun_out/{tag})\n\n")
 if os.path.exists(os.path.join(R, "api_profile.txt")):

@@ -39,6 +39,7 @@ struct ReprConvParams {
   const float* in_scale; // [C]
   const float* in_offset;
   float eps;
+  int b0;              // first image of this launch (batches above 65535 images go in slices of grid y)
 };
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
     float in_mean = 0.0f, in_rstd = 1.0f;
     rc_f32x4 in_g = (rc_f32x4){1.0f, 1.0f, 1.0f, 1.0f}, in_o = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (LNIN) {
-      ln_stats(p.in_mom + (size_t)b * gridDim.x * 2, (int)gridDim.x, npix * C, p.eps, in_mean, in_rstd);
+      ln_stats(p.in_mom + (size_t)(p.b0 + b) * gridDim.x * 2, (int)gridDim.x, npix * C, p.eps, in_mean, in_rstd);
       in_g = *reinterpret_cast<const rc_f32x4*>(p.in_scale + 4 * c4);
       in_o = *reinterpret_cast<const rc_f32x4*>(p.in_offset + 4 * c4);
     }
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
     __syncthreads();
     if (tid < 2 * NW) {
       const double t = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
-      p.mom[(((size_t)(tid >> 1) * p.B + b) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = t;
+      p.mom[(((size_t)(tid >> 1) * p.B + p.b0 + b) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = t;
     }
   }
 }

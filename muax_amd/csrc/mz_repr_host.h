@@ -33,8 +33,19 @@ int launch(const mz::ReprConvParams& p, int blocks, size_t lds, hipStream_t stre
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     granted[dev & 63] = lds;
   }
-  hipLaunchKernelGGL((mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM>), dim3(blocks, p.B), dim3(256), lds, stream, p);
-  MZS_HIPG(hipGetLastError());
+  // images in grid y: at most 65535 per launch (larger batches go in slices; the moment arrays are [tensor][B][K][2], so
+  // a slice keeps the full batch as its stride and only shifts the image index)
+  for (int b0 = 0; b0 < p.B; b0 += 65535) {
+    mz::ReprConvParams q = p;
+    const int nb = p.B - b0 < 65535 ? p.B - b0 : 65535;
+    const size_t off = (size_t)b0 * p.H * p.W * C;
+    q.x = p.x + off;
+    q.y = p.y + off;
+    if (p.y2) q.y2 = p.y2 + off;
+    q.b0 = b0;
+    hipLaunchKernelGGL((mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM>), dim3(blocks, nb), dim3(256), lds, stream, q);
+    MZS_HIPG(hipGetLastError());
+  }
   return MZS_OK;
 }
 

@@ -2,6 +2,7 @@
     python tools/stress_round4.py generic [cases] [seed]   # mzs_act_mlp's generic one-launch search vs the C oracle
     python tools/stress_round4.py jit [cases] [seed]       # fused instances compiled on demand vs the C oracle
     python tools/stress_round4.py search [cases] [seed]    # one-launch ResNet search vs the per-simulation launches
+    python tools/stress_round4.py repr [cases] [seed]      # representation convolutions / residual blocks vs fp64
 generic: num_actions 1..64, embeddings 1..120, num_simulations 1..260, support sizes 8..31, both recurrent_pred_on modes,
 depth cuts, masks, weight scales (0 = every score ties: the noise decides), MuZero and Gumbel MuZero policies.
 search: 1..200 roots (pair mode up to 128), 1..60 simulations, depth cuts, masks, both policies."""
@@ -95,6 +96,50 @@ if mode in ("generic", "jit"):
             print(f"MISMATCH case {c}: A={A} E={E} support={support} S={S} B={B} policy={policy} tb={tiebreak} md={max_depth} "
                   f"scale={scale} T={temperature} pred_on={pred_on}: {str(e)[:200]}")
     print(f"{mode} seed {seed}: {n} cases, {bad} mismatches")
+elif mode == "repr":
+    # mzs_conv3x3_nhwc / mzs_resblock_v1 against an fp64 evaluation with the module path beside them: random C, odd
+    # heights / widths (runs of pixels ending mid-row, maps narrower than a staging sweep), batches, both shortcuts
+    g = torch.Generator().manual_seed(seed)
+    worst = 0.0
+    for c in range(n):
+        C = int(rng.choice([32, 64]))
+        H, W = int(rng.integers(1, 49)), int(rng.integers(1, 49))
+        if C == 64 and H * W > 1200:
+            H = W = 24
+        B = int(rng.integers(1, 24))
+        proj = bool(rng.integers(2))
+        blk = mx.nn.ResidualConvBlockV1(C, 1, proj, generator=g)
+        x = (torch.rand(B, H, W, C, generator=g) * 2 - 1) * float(rng.choice([0.1, 1.0, 10.0]))
+        with torch.no_grad():
+            blk.use_hip = False
+            blk(x[:1])
+            blk.cuda()
+            x = x.cuda()
+            for ln in ([blk.ln_0, blk.ln_1] + ([blk.proj_ln] if proj else [])):
+                ln.scale.copy_(torch.rand(C, generator=g) + 0.5)
+                ln.offset.copy_(torch.rand(C, generator=g) - 0.5)
+            y_mod = blk(x)
+            yc = blk.conv_0(x)
+            blk.use_hip = True
+            ok_path = blk._hip_ok(x)
+            y = blk(x)
+            mx.nn.HkConv2D.use_hip = mx.nn.HkLayerNorm.use_hip = False
+            blk.use_hip = False
+            yc_lib = blk.conv_0(x)
+            blk.double()
+            y64 = blk(x.double())
+            yc64 = blk.conv_0(x.double())
+            mx.nn.HkConv2D.use_hip = mx.nn.HkLayerNorm.use_hip = True
+        e, em = float((y.double() - y64).abs().max()), float((y_mod.double() - y64).abs().max())
+        ec, el = float((yc.double() - yc64).abs().max()), float((yc_lib.double() - yc64).abs().max())
+        floor = 2e-5 * max(1.0, float(y64.abs().max()))
+        floor_c = 2e-6 * (9 * C) ** 0.5 * max(1e-30, float(yc64.abs().max()))
+        worst = max(worst, e / floor)
+        if not ok_path or not (e <= floor and e <= 2 * em + floor) or not (ec <= floor_c and ec <= 2 * el + floor_c):
+            bad += 1
+            print(f"MISMATCH case {c}: C={C} H={H} W={W} B={B} proj={proj} hip_ok={ok_path}: block {e:.3g} (module {em:.3g}, floor {floor:.3g}) "
+                  f"conv {ec:.3g} (library {el:.3g}, floor {floor_c:.3g})")
+    print(f"repr seed {seed}: {n} cases, {bad} outside the bars (largest block error / bar {worst:.2f})")
 else:
     A_, SUP = 18, 10
     g = torch.Generator().manual_seed(seed)

@@ -359,6 +359,25 @@ typedef struct mzs_conv3x3_args {
 } mzs_conv3x3_args;
 int mzs_conv3x3_nhwc(const mzs_conv3x3_args *a, void *stream);
 
+/* The stems of those nets: hk.Conv2D(out, kernel_shape=3, stride=2, padding='SAME', with_bias=False) with (in, out)
+ * channels (4, 32) -- raw frame stacks, muax/nn.py:299 / :189 -- or (32, 64) (muax/nn.py:303); output
+ * [B, ceil(H / 2), ceil(W / 2), out].  w_packed: Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co] with the 4 frame
+ * channels padded to 16 by zero rows (9 * 16 * 32 floats).  in_div != 0: the input is divided by it on the way in (the
+ * reference's observations / 255); relu != 0: max(., 0) on the way out. */
+typedef struct mzs_conv3x3s_args {
+  int32_t struct_size;     /* = sizeof(mzs_conv3x3s_args) */
+  int32_t device;
+  int32_t batch, height, width;   /* of the input */
+  int32_t in_channels, out_channels;
+  int32_t relu;
+  float in_div;
+  int32_t reserved0;
+  const float *x;          /* [B, H, W, in] */
+  const float *w_packed;
+  float *y;                /* [B, ceil(H/2), ceil(W/2), out] */
+} mzs_conv3x3s_args;
+int mzs_conv3x3_stride2_nhwc(const mzs_conv3x3s_args *a, void *stream);
+
 /* A whole ResidualConvBlockV1 (muax/nn.py:118-148: conv_0 - LN - relu - conv_1 - LN, + LN(projection conv) or + x,
  * relu) of those nets, stride 1, C -> C with C = 32 or 64, inference, in three launches: the projection and conv_0
  * share one pass over the input and leave the moments of their outputs, conv_1 normalises its input on the way into

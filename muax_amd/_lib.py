@@ -104,6 +104,12 @@ class MzsConv3x3Args(C.Structure):
                 ("x", _vp), ("w_packed", _vp), ("y", _vp)]
 
 
+class MzsConv3x3sArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("relu", C.c_int32),
+                ("in_div", C.c_float), ("reserved0", C.c_int32), ("x", _vp), ("w_packed", _vp), ("y", _vp)]
+
+
 class MzsResblockArgs(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32),
                 ("width", C.c_int32), ("channels", C.c_int32), ("eps", C.c_float), ("reserved0", C.c_int32),
@@ -120,7 +126,7 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
                     "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
                     "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc",
-                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes"]
+                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes", "mzs_conv3x3_stride2_nhwc"]
 
 _lib = None
 
@@ -159,6 +165,7 @@ def load(build_if_missing: bool = True):
     L.mzs_mlp_allow_generic.argtypes = [_vp, C.c_int32]
     L.mzs_conv3x3_nhwc.argtypes = [C.POINTER(MzsConv3x3Args), _vp]
     L.mzs_resblock_v1.argtypes = [C.POINTER(MzsResblockArgs), _vp]
+    L.mzs_conv3x3_stride2_nhwc.argtypes = [C.POINTER(MzsConv3x3sArgs), _vp]
     L.mzs_resblock_workspace_bytes.argtypes = [C.c_int32] * 4
     L.mzs_resnet_search.argtypes = [_vp, C.POINTER(MzsTowerArgs), C.c_float, C.c_int32, C.c_int32, _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4

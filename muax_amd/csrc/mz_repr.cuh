@@ -40,31 +40,45 @@ struct ReprConvParams {
   const float* in_offset;
   float eps;
   int b0;              // first image of this launch (batches above 65535 images go in slices of grid y)
+  // --- the stems (stride 2, channels changing): H, W are the INPUT's; the input tensor has cin_real channels per pixel
+  // (4 raw frames: padded to the kernel's 16 with zeros in LDS and in the packed weights); in_div != 0: x / in_div on
+  // the way in (the reference's observations / 255)
+  int cin_real;
+  float in_div;
 };
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int C, int TPW, int NW = 1, bool LNIN = false, bool MOM = false>
+// C = output channels; CIN = input channels as the kernel sees them (a multiple of 16), STRIDE = 1 or 2 with haiku's
+// 'SAME' geometry (output ceil(H / STRIDE); total padding max((out - 1) STRIDE + 3 - H, 0), the smaller half first)
+template <int C, int TPW, int NW = 1, bool LNIN = false, bool MOM = false, int CIN = C, int STRIDE = 1>
 __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvParams p) {
-  constexpr int NCB = C / 16, NTG = 4 / NCB, NC = C / 16, PS = C + 4, G = 9 * NC;
+  constexpr int NCB = C / 16, NTG = 4 / NCB, NC = CIN / 16, PS = CIN + 4, G = 9 * NC;
   constexpr int BLOCK_PX = 16 * TPW * NTG;
+  static_assert(STRIDE == 1 || (NW == 1 && !LNIN), "the strided variant is the plain convolution");
   extern __shared__ __attribute__((aligned(16))) float rc_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, H = p.H, W = p.W, npix = H * W, W2 = W + 2;
+  const int b = blockIdx.y, H = p.H, W = p.W;
+  const int Ho = (H + STRIDE - 1) / STRIDE, Wo = (W + STRIDE - 1) / STRIDE, npix = Ho * Wo;  // (npix: OUTPUT pixels)
+  const int pt = max((Ho - 1) * STRIDE + 3 - H, 0) / 2, pl = max((Wo - 1) * STRIDE + 3 - W, 0) / 2;
+  const int W2 = (Wo - 1) * STRIDE + 3;  // staged columns: -pl .. -pl + W2 - 1
   const int p0 = blockIdx.x * BLOCK_PX, p1 = min(p0 + BLOCK_PX, npix);
-  const int row0 = p0 / W - 1, row1 = (p1 - 1) / W + 1;  // staged image rows, halo rows included (may be -1 / H)
+  // staged input rows, halo rows included (may be -1 / H)
+  const int row0 = STRIDE * (p0 / Wo) - pt, row1 = STRIDE * ((p1 - 1) / Wo) - pt + 2;
   const int nrows = row1 - row0 + 1;
   // ---- stage rows [row0, row1] x columns [-1, W] (zero outside the image): a thread keeps its channel quad and walks
   // the pixels 256 / (C / 4) apart, eight loads in flight before the first LDS write (one load per trip is one L2 / HBM
   // round trip per trip: 20 trips, a third of the 21 x 21 layers' time)
   {
-    constexpr int QPP = C / 4, PSTEP = 256 / QPP, U = 8;
-    const float* img = p.x + (size_t)b * npix * C;
+    constexpr int QPP = CIN / 4, PSTEP = 256 / QPP, U = 8;
+    const int cin = (CIN == C && STRIDE == 1) ? CIN : p.cin_real;  // channels per pixel of the tensor in memory
+    const float* img = p.x + (size_t)b * H * W * cin;
     const int c4 = tid % QPP, npx = nrows * W2;
+    const bool real_quad = 4 * c4 < cin;
     float in_mean = 0.0f, in_rstd = 1.0f;
     rc_f32x4 in_g = (rc_f32x4){1.0f, 1.0f, 1.0f, 1.0f}, in_o = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (LNIN) {
-      ln_stats(p.in_mom + (size_t)(p.b0 + b) * gridDim.x * 2, (int)gridDim.x, npix * C, p.eps, in_mean, in_rstd);
+      ln_stats(p.in_mom + (size_t)(p.b0 + b) * gridDim.x * 2, (int)gridDim.x, H * W * CIN, p.eps, in_mean, in_rstd);
       in_g = *reinterpret_cast<const rc_f32x4*>(p.in_scale + 4 * c4);
       in_o = *reinterpret_cast<const rc_f32x4*>(p.in_offset + 4 * c4);
     }
@@ -76,12 +90,12 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
       bool inside_mask[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int y = row0 + ry, x = cx - 1;
+        const int y = row0 + ry, x = cx - pl;
         inside_mask[u] = false;
         v[u] = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         dst[u] = px < npx ? px : -1;
-        bool inside = px < npx && y >= 0 && y < H && x >= 0 && x < W;
-        if (inside) v[u] = *reinterpret_cast<const rc_f32x4*>(img + ((size_t)y * W + x) * C + 4 * c4);
+        bool inside = px < npx && y >= 0 && y < H && x >= 0 && x < W && real_quad;
+        if (inside) v[u] = *reinterpret_cast<const rc_f32x4*>(img + ((size_t)y * W + x) * cin + 4 * c4);
         if constexpr (LNIN) inside_mask[u] = inside;
         px += PSTEP;
         cx += PSTEP;
@@ -98,6 +112,12 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
             for (int i = 0; i < 4; ++i) v[u][i] = fmaxf((v[u][i] - in_mean) * in_rstd * in_g[i] + in_o[i], 0.0f);
           }
         }
+        if constexpr (STRIDE != 1 || CIN != C) {
+          if (p.in_div != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = v[u][i] / p.in_div;
+          }
+        }
         if (dst[u] >= 0) *reinterpret_cast<rc_f32x4*>(rc_lds + (size_t)dst[u] * PS + 4 * c4) = v[u];
       }
     }
@@ -112,8 +132,8 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
   for (int mt = 0; mt < TPW; ++mt) {
     const int px = p0 + 16 * (tg * TPW + mt) + m;
     const int pc = px < p1 ? px : p0;  // (rows past the run shadow its first pixel: computed, never stored)
-    const int py = pc / W, pxx = pc - py * W;
-    abase[mt] = ((py - 1 - row0) * W2 + pxx) * PS + 4 * g;
+    const int py = pc / Wo, pxx = pc - py * Wo;
+    abase[mt] = ((STRIDE * py - pt - row0) * W2 + STRIDE * pxx) * PS + 4 * g;
   }
   rc_f32x4 acc[NW][TPW];
 #pragma unroll
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
   }
 }
 
-// rows of LDS a block of BLOCK_PX consecutive pixels of a width-W image needs (halo included)
-inline int repr_conv_rows(int block_px, int W) { return (block_px + W - 1) / W + 1 + 2; }
+// rows of LDS a block of BLOCK_PX consecutive OUTPUT pixels of an output of width Wo needs (halo included)
+inline int repr_conv_rows(int block_px, int Wo, int stride = 1) { return stride * ((block_px + Wo - 1) / Wo) + 3; }
 
 }  // namespace mz

@@ -28,4 +28,27 @@ int mzs_conv3x3_nhwc(const mzs_conv3x3_args* a, void* stream_) {
   return mzr::conv<1, false, false>(p, a->channels, g, static_cast<hipStream_t>(stream_));
 }
 
+int mzs_conv3x3_stride2_nhwc(const mzs_conv3x3s_args* a, void* stream_) {
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_conv3x3s_args))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_conv3x3_stride2_nhwc: null arguments or size mismatch (ABI)");
+  if (a->batch <= 0 || a->height <= 0 || a->width <= 0 || !a->x || !a->w_packed || !a->y)
+    return mzh::fail_global(MZS_E_INVALID, "mzs_conv3x3_stride2_nhwc: batch / height / width / pointers");
+  const bool stem0 = a->in_channels == 4 && a->out_channels == 32, stem1 = a->in_channels == 32 && a->out_channels == 64;
+  if (!stem0 && !stem1)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_conv3x3_stride2_nhwc: (in, out) channels must be (4, 32) or (32, 64)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return mzh::fail_global(MZS_E_NODEVICE, "mzs_conv3x3_stride2_nhwc: no HIP device (this library has no CPU fallback)");
+  if (a->device < 0 || a->device >= ndev) return mzh::fail_global(MZS_E_INVALID, "mzs_conv3x3_stride2_nhwc: bad device ordinal");
+  MZS_HIPG(hipSetDevice(a->device));
+  mz::ReprConvParams p;
+  memset(&p, 0, sizeof p);
+  p.x = a->x; p.wp = a->w_packed; p.y = a->y; p.B = a->batch; p.H = a->height; p.W = a->width; p.relu = a->relu;
+  p.cin_real = a->in_channels; p.in_div = a->in_div;
+  const mzr::Geometry g = mzr::geometry_strided(a->height, a->width, stem0 ? 16 : 32, 2);
+  if (g.lds > 160 * 1024) return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_conv3x3_stride2_nhwc: image too wide for the LDS of a CU");
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  return stem0 ? mzr::conv_stride2<32, 16>(p, g, s) : mzr::conv_stride2<64, 32>(p, g, s);
+}
+
 }  // extern "C"

@@ -22,14 +22,30 @@ inline Geometry geometry(int height, int width, int C) {
   g.lds = sizeof(float) * (size_t)mz::repr_conv_rows(16 * g.tiles_per_block, width) * (width + 2) * (C + 4);
   return g;
 }
+// the strided / channel-changing variant: `height`, `width` of the INPUT, cin = the kernel's (padded) input channels;
+// the longest run whose rows fit the LDS
+inline Geometry geometry_strided(int height, int width, int cin, int stride) {
+  Geometry g;
+  const int ho = (height + stride - 1) / stride, wo = (width + stride - 1) / stride;
+  const int tiles = (ho * wo + 15) / 16;
+  int bt = tiles > 16 ? 14 : (tiles > 8 ? 8 : 4);
+  for (;;) {
+    g.lds = sizeof(float) * (size_t)mz::repr_conv_rows(16 * bt, wo, stride) * ((wo - 1) * stride + 3) * (cin + 4);
+    if (g.lds <= 160 * 1024 || bt == 4) break;
+    bt = bt == 14 ? 8 : 4;
+  }
+  g.tiles_per_block = bt;
+  g.blocks = (tiles + bt - 1) / bt;
+  return g;
+}
 
-template <int C, int TPW, int NW, bool LNIN, bool MOM>
+template <int C, int TPW, int NW, bool LNIN, bool MOM, int CIN = C, int STRIDE = 1>
 int launch(const mz::ReprConvParams& p, int blocks, size_t lds, hipStream_t stream) {
   static size_t granted[64] = {};
   int dev = 0;
   MZS_HIPG(hipGetDevice(&dev));
   if (lds > granted[dev & 63]) {
-    MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM>),
+    MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM, CIN, STRIDE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     granted[dev & 63] = lds;
   }
@@ -38,12 +54,13 @@ int launch(const mz::ReprConvParams& p, int blocks, size_t lds, hipStream_t stre
   for (int b0 = 0; b0 < p.B; b0 += 65535) {
     mz::ReprConvParams q = p;
     const int nb = p.B - b0 < 65535 ? p.B - b0 : 65535;
-    const size_t off = (size_t)b0 * p.H * p.W * C;
-    q.x = p.x + off;
+    const int ho = (p.H + STRIDE - 1) / STRIDE, wo = (p.W + STRIDE - 1) / STRIDE;
+    const size_t off = (size_t)b0 * ho * wo * C;
+    q.x = p.x + (size_t)b0 * p.H * p.W * ((CIN == C && STRIDE == 1) ? C : p.cin_real);
     q.y = p.y + off;
     if (p.y2) q.y2 = p.y2 + off;
     q.b0 = b0;
-    hipLaunchKernelGGL((mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM>), dim3(blocks, nb), dim3(256), lds, stream, q);
+    hipLaunchKernelGGL((mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM, CIN, STRIDE>), dim3(blocks, nb), dim3(256), lds, stream, q);
     MZS_HIPG(hipGetLastError());
   }
   return MZS_OK;
@@ -62,6 +79,15 @@ int conv(const mz::ReprConvParams& p, int C, const Geometry& g, hipStream_t s) {
   if (bt == 14) return launch<32, 7, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
   if (bt == 8) return launch<32, 4, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
   return launch<32, 2, NW, LNIN, MOM>(p, g.blocks, g.lds, s);
+}
+
+// the stems: stride 2, (4 ->) 16 -> 32 and 32 -> 64 channels
+template <int C, int CIN>
+int conv_stride2(const mz::ReprConvParams& p, const Geometry& g, hipStream_t s) {
+  constexpr int D = C == 64 ? 1 : 2;  // tiles per wave = tiles per block / tile groups
+  if (g.tiles_per_block == 14) return launch<C, 14 / D, 1, false, false, CIN, 2>(p, g.blocks, g.lds, s);
+  if (g.tiles_per_block == 8) return launch<C, 8 / D, 1, false, false, CIN, 2>(p, g.blocks, g.lds, s);
+  return launch<C, 4 / D, 1, false, false, CIN, 2>(p, g.blocks, g.lds, s);
 }
 
 }  // namespace mzr

@@ -234,51 +234,84 @@ class HkConv2D(nn.Module):
     use_hip = True  # C -> C (32 / 64) 3x3 stride-1 convolutions of the representation nets on mzs_conv3x3_nhwc in inference
 
     def _hip_ok(self, x) -> bool:
-        """mzs_conv3x3_nhwc applies: inference on a dense fp32 NHWC map on the GPU, 3x3, stride 1, C -> C with C = 32 or
-        64, the rows a run of pixels touches fitting a CU's LDS (every C -> C layer of the representation nets: 42 x 42 x 32,
-        21 x 21, 11 x 11, 6 x 6)."""
-        if not (self.use_hip and self.k == 3 and self.stride == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        """A HIP convolution applies: inference on a dense fp32 NHWC map on the GPU, 3x3, and either stride 1 with C -> C
+        channels, C = 32 or 64 (mzs_conv3x3_nhwc: every layer inside the residual blocks of the representation nets,
+        42 x 42 x 32, 21 x 21, 11 x 11, 6 x 6) or stride 2 with 4 -> 32 / 32 -> 64 channels (mzs_conv3x3_stride2_nhwc: their
+        stems); the rows a run of output pixels touches must fit a CU's LDS."""
+        if not (self.use_hip and self.k == 3 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             return False
-        c = x.shape[-1]
-        if c != self.out_channels or c not in (32, 64):
-            return False
-        # (6 x 6 x 64 on 128 images is 13.6 us here against 10.7 for the library's kernel alone, but inside the EZ
-        # encoder the library's side kernels make the same layers 25 us dearer each: every size stays here)
-        tiles = (x.shape[1] * x.shape[2] + 15) // 16  # the library's choice of run length (mz_repr.hip) -> its LDS bytes
-        run = 16 * (14 if tiles > 16 else (8 if tiles > 8 else 4))
-        if ((run + x.shape[2] - 1) // x.shape[2] + 3) * (x.shape[2] + 2) * (c + 4) * 4 > 160 * 1024:
+        c, co, (h, w) = x.shape[-1], self.out_channels, x.shape[1:3]
+        if self.stride == 1 and c == co and c in (32, 64):
+            # (6 x 6 x 64 on 128 images is 13.6 us here against 10.7 for the library's kernel alone, but inside the EZ
+            # encoder the library's side kernels make the same layers 25 us dearer each: every size stays here)
+            tiles = (h * w + 15) // 16  # the library's choice of run length (mz_repr_host.h) -> its LDS bytes
+            run = 16 * (14 if tiles > 16 else (8 if tiles > 8 else 4))
+            if ((run + w - 1) // w + 3) * (w + 2) * (c + 4) * 4 > 160 * 1024:
+                return False
+        elif self.stride == 2 and (c, co) in ((4, 32), (32, 64)):
+            wo = -(-w // 2)
+            if (2 * ((64 + wo - 1) // wo) + 3) * ((wo - 1) * 2 + 3) * (max(c, 16) + 4) * 4 > 160 * 1024:
+                return False  # (even the shortest run, 4 tiles, does not fit)
+        else:
             return False
         if torch.is_grad_enabled() and (x.requires_grad or self.w.requires_grad):
             return False
         return self.w.is_cuda and self.w.dtype == torch.float32 and self.w.device == x.device
 
     def _packed(self):
-        """The HWIO kernel in the HIP kernels' order Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co]; rebuilt when the
-        parameter changes."""
+        """The HWIO kernel in the HIP kernels' order Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co] (fewer than 16 input
+        channels: zero rows up to 16); rebuilt when the parameter changes."""
         sig = (self.w.data_ptr(), self.w._version, self.w.device)
         if getattr(self, "_pack_sig", None) != sig:
-            c = self.out_channels
+            co, cin = self.out_channels, self.w.shape[2]
             with torch.no_grad():
-                self._pack = self.w.detach().reshape(9, c // 16, 4, 4, c).permute(0, 1, 2, 4, 3).contiguous()
+                w = self.w.detach().reshape(9, cin, co)
+                if cin % 16:
+                    w = torch.cat([w, w.new_zeros(9, 16 - cin % 16, co)], dim=1)
+                self._pack = w.reshape(9, w.shape[1] // 16, 4, 4, co).permute(0, 1, 2, 4, 3).contiguous()
             self._pack_sig = sig
         return self._pack
 
-    def _conv_hip(self, x):
+    def _conv_hip(self, x, in_div=None, relu=False):
         import ctypes as C
 
         from . import _lib
         L = _lib.load()
         xc = x.contiguous()
         wp = self._packed()
-        y = torch.empty_like(xc)
-        a = _lib.MzsConv3x3Args()
-        a.struct_size = C.sizeof(_lib.MzsConv3x3Args)
-        a.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        a.batch, a.height, a.width, a.channels, a.relu = xc.shape[0], xc.shape[1], xc.shape[2], xc.shape[3], 0
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        if self.stride == 1:
+            if in_div is not None:
+                xc = xc / in_div
+            y = torch.empty_like(xc)
+            a = _lib.MzsConv3x3Args()
+            a.struct_size = C.sizeof(_lib.MzsConv3x3Args)
+            a.device = dev
+            a.batch, a.height, a.width, a.channels, a.relu = xc.shape[0], xc.shape[1], xc.shape[2], xc.shape[3], int(relu)
+            a.x, a.w_packed, a.y = xc.data_ptr(), wp.data_ptr(), y.data_ptr()
+            with torch.cuda.device(x.device):
+                _lib.check(L.mzs_conv3x3_nhwc(C.byref(a), stream))
+            return y
+        y = torch.empty(xc.shape[0], -(-xc.shape[1] // 2), -(-xc.shape[2] // 2), self.out_channels, dtype=torch.float32, device=x.device)
+        a = _lib.MzsConv3x3sArgs()
+        a.struct_size = C.sizeof(_lib.MzsConv3x3sArgs)
+        a.device = dev
+        a.batch, a.height, a.width, a.in_channels, a.out_channels = xc.shape[0], xc.shape[1], xc.shape[2], xc.shape[3], self.out_channels
+        a.relu, a.in_div = int(relu), float(in_div) if in_div is not None else 0.0
         a.x, a.w_packed, a.y = xc.data_ptr(), wp.data_ptr(), y.data_ptr()
         with torch.cuda.device(x.device):
-            _lib.check(L.mzs_conv3x3_nhwc(C.byref(a), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+            _lib.check(L.mzs_conv3x3_stride2_nhwc(C.byref(a), stream))
         return y
+
+    def scaled(self, x, in_div=None, relu=False):
+        """[relu](conv(x [/ in_div])): the stems of the representation nets (muax/nn.py:189,299,303: observations / 255
+        in front, relu behind), the division and the relu inside the HIP kernel when it applies."""
+        self.materialize(x.shape[-1])
+        if self._hip_ok(x):
+            return self._conv_hip(x, in_div=in_div, relu=relu)
+        y = self.forward(x if in_div is None else x / in_div)
+        return torch.relu(y) if relu else y
 
     def forward(self, x):
         self.materialize(x.shape[-1])
@@ -580,7 +613,7 @@ class EZStateEncoder(nn.Module):
         self.block2, self.block3, self.block4 = Block(channels, 1, False, g), Block(channels, 1, False, g), Block(channels, 1, False, g)
 
     def forward(self, observations):
-        x = self.stem(observations.to(torch.float32) / 255.)
+        x = self.stem.scaled(observations.to(torch.float32), 255.)
         if not self.use_v2:
             x = ln_act(x, self.stem_ln, relu=True)
         x = self.block2(self.block1(self.block0(x)))
@@ -751,10 +784,10 @@ class ResNetRepresentation(nn.Module):
         self.blocks2 = nn.ModuleList([ResidualConvBlockV1(2 * c, 1, True, g) for _ in range(3)])
 
     def forward(self, obs):
-        x = torch.relu(self.stem0(obs.to(torch.float32) / 255.))
+        x = self.stem0.scaled(obs.to(torch.float32), 255., relu=True)
         for b in self.blocks0:
             x = b(x)
-        x = torch.relu(self.stem1(x))
+        x = self.stem1.scaled(x, relu=True)
         for b in self.blocks1:
             x = b(x)
         x = avg_pool_same(x)

@@ -532,6 +532,32 @@ def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
     assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_lib + floor, (e_hip, e_lib, floor)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B,div", [(4, 32, 84, 84, 5, 255.0), (32, 64, 42, 42, 7, None), (4, 32, 96, 96, 2, 255.0),
+                                                (32, 64, 21, 21, 3, None), (4, 32, 13, 29, 4, None), (32, 64, 2, 2, 3, None),
+                                                (4, 32, 1, 1, 2, 255.0)])
+def test_stem_conv3x3_stride2_against_fp64_and_the_library(cin, cout, H, W, B, div):
+    """mzs_conv3x3_stride2_nhwc (the stems of the representation nets: hk.Conv2D(32 | 64, 3, stride=2, 'SAME', no bias) on
+    raw frame stacks / on the 32-channel map, muax/nn.py:189,299,303, with the observations / 255 in front and the relu
+    behind fused) against an fp64 evaluation of [relu](conv(x / 255)) and the module's library path: odd sizes (haiku's
+    SAME padding puts the odd pixel after), a 1 x 1 image."""
+    g = torch.Generator().manual_seed(cin + H + W)
+    conv = mx.nn.HkConv2D(cout, 3, 2, in_channels=cin, generator=g).cuda()
+    x = (torch.rand(B, H, W, cin, generator=g) * (255.0 if div else 2.0) - (0.0 if div else 1.0)).cuda()
+    with torch.no_grad():
+        assert conv._hip_ok(x)
+        y = conv.scaled(x, div, relu=True)
+        conv.use_hip = False
+        y_lib = conv.scaled(x, div, relu=True)
+        conv.use_hip = True
+        (ht, hb), (wl, wr) = mx.nn._same_pad(H, 3, 2), mx.nn._same_pad(W, 3, 2)
+        xd = (x.double() / div if div else x.double()).permute(0, 3, 1, 2)
+        y64 = torch.relu(torch.nn.functional.conv2d(torch.nn.functional.pad(xd, (wl, wr, ht, hb)), conv.w.double().permute(3, 2, 0, 1),
+                                                     stride=2)).permute(0, 2, 3, 1)
+    e_hip, e_lib = float((y.double() - y64).abs().max()), float((y_lib.double() - y64).abs().max())
+    floor = 2e-6 * (9 * cin) ** 0.5 * max(1e-30, float(y64.abs().max()))
+    assert y.shape == y64.shape and e_hip <= floor and e_hip <= 2 * e_lib + floor, (e_hip, e_lib, floor)
+
+
 def test_representation_net_takes_the_hip_convolutions():
     """Root inference of the ResNet nets (muax/model.py:251-263) with its 8 residual blocks (24 C -> C convolutions at
     42 x 42 x 32, 21 x 21 x 64, 11 x 11 x 64 and their 24 LayerNorms) as mzs_resblock_v1 calls, against the same blocks on
@@ -544,14 +570,14 @@ def test_representation_net_takes_the_hip_convolutions():
     calls, convs = [], []
     orig, orig_c = mx.nn.ResidualConvBlockV1._forward_hip, mx.nn.HkConv2D._conv_hip
     mx.nn.ResidualConvBlockV1._forward_hip = lambda self, x: (calls.append(tuple(x.shape[1:])), orig(self, x))[1]
-    mx.nn.HkConv2D._conv_hip = lambda self, x: (convs.append(tuple(x.shape[1:])), orig_c(self, x))[1]
+    mx.nn.HkConv2D._conv_hip = lambda self, x, **kw: (convs.append(tuple(x.shape[1:])), orig_c(self, x, **kw))[1]
     try:
         pl, v, emb = m._root_inference(None, None, obs)
         assert calls.count((42, 42, 32)) == 2 and calls.count((21, 21, 64)) == 3 and calls.count((11, 11, 64)) == 3 and len(calls) == 8
-        assert convs == []
+        assert convs == [(84, 84, 4), (42, 42, 32)]  # the two stride-2 stems; the other 24 convolutions inside the blocks
         mx.nn.ResidualConvBlockV1.use_hip = False
         pl1, v1, emb1 = m._root_inference(None, None, obs)
-        assert convs.count((42, 42, 32)) == 6 and convs.count((21, 21, 64)) == 9 and convs.count((11, 11, 64)) == 9 and len(convs) == 24
+        assert convs.count((42, 42, 32)) == 8 and convs.count((21, 21, 64)) == 9 and convs.count((11, 11, 64)) == 9 and len(convs) == 28
         mx.nn.HkConv2D.use_hip = False
         pl0, v0, emb0 = m._root_inference(None, None, obs)
     finally:

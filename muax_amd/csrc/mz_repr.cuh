@@ -113,9 +113,21 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
           }
         }
         if constexpr (STRIDE != 1 || CIN != C) {
-          if (p.in_div != 0.0f) {
+          if (p.in_div != 0.0f && real_quad) {
+            // x / d for a small positive integer d (255): q0 = RN(x y), y = RN(1 / d); r = x - q0 d (exact, fma);
+            // RN(q0 + r y) is the correctly rounded quotient (Markstein; tests/test_oracle_kat.py checks it against the
+            // division for every mantissa and d <= 300) -- three operations instead of the IEEE expansion's eleven
+            const float d = p.in_div, y = 1.0f / d;
+            if (d >= 1.0f && d <= 300.0f && d == floorf(d)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = v[u][i] / p.in_div;
+              for (int i = 0; i < 4; ++i) {
+                const float q0 = v[u][i] * y;
+                v[u][i] = __builtin_fmaf(__builtin_fmaf(-q0, d, v[u][i]), y, q0);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[u][i] = v[u][i] / d;
+            }
           }
         }
         if (dst[u] >= 0) *reinterpret_cast<rc_f32x4*>(rc_lds + (size_t)dst[u] * PS + 4 * c4) = v[u];

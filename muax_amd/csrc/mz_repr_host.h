@@ -31,7 +31,10 @@ inline Geometry geometry_strided(int height, int width, int cin, int stride) {
   int bt = tiles > 16 ? 14 : (tiles > 8 ? 8 : 4);
   for (;;) {
     g.lds = sizeof(float) * (size_t)mz::repr_conv_rows(16 * bt, wo, stride) * ((wo - 1) * stride + 3) * (cin + 4);
-    if (g.lds <= 160 * 1024 || bt == 4) break;
+    // (the frame stem, 16 padded input channels: its matrix work per staged byte is small -- two workgroups per CU, each
+    // staging while the other multiplies, beat one long run: 49 against 60 us for 128 frames; the 32 -> 64 stem: 32 / 34)
+    const size_t cap = cin <= 16 ? 80 * 1024 : 160 * 1024;
+    if (g.lds <= cap || bt == 4) break;
     bt = bt == 14 ? 8 : 4;
   }
   g.tiles_per_block = bt;

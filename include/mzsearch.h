@@ -341,6 +341,23 @@ int mzs_resnet_tower(const mzs_tower_args *a, void *stream);
 /* bytes of pair_scratch for `batch` roots (0 if pair mode cannot run that batch) */
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch);
 
+/* The tail of root inference with those nets (muax/model.py:251-263), one launch: the last hk.AvgPool(3, 2, 'SAME') of
+ * ResNetRepresentation (muax/nn.py:308; the mean of the VALID elements under each window) on its [B, H, W, 64] map with
+ * H, W in {11, 12} -> 6 x 6, min_max_normalize2d (:47-56, :310; normalize != 0), ResNetPrediction on that embedding
+ * (:313-341; weights as in mzs_tower_args) and support_to_scalar(softmax(value logits)) (muax/model.py:254). */
+typedef struct mzs_root_tail_args {
+  int32_t struct_size;     /* = sizeof(mzs_root_tail_args) */
+  int32_t device;
+  int32_t batch, height, width;
+  int32_t num_actions, support_size, normalize;
+  const float *x;          /* [B, H, W, 64] */
+  const float *v_c1, *v_c2, *v_l1, *v_b1, *v_l2, *v_b2, *p_c1, *p_l1, *p_b1, *p_l2, *p_b2;
+  float *embedding;        /* [B, 6, 6, 64] out */
+  float *value;            /* [B] out */
+  float *prior_logits;     /* [B, num_actions] out */
+} mzs_root_tail_args;
+int mzs_resnet_root_tail(const mzs_root_tail_args *a, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * hk.Conv2D(C, kernel_shape=3, stride=1, padding='SAME', with_bias=False) on NHWC maps with C -> C channels, C = 32 or
  * 64: the convolutions inside the residual blocks of the representation nets at their 21 x 21 / 11 x 11 / 6 x 6 stages

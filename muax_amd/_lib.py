@@ -104,6 +104,13 @@ class MzsConv3x3Args(C.Structure):
                 ("x", _vp), ("w_packed", _vp), ("y", _vp)]
 
 
+class MzsRootTailArgs(C.Structure):
+    HEAD_FIELDS = ["v_c1", "v_c2", "v_l1", "v_b1", "v_l2", "v_b2", "p_c1", "p_l1", "p_b1", "p_l2", "p_b2"]
+    _fields_ = ([("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32),
+                 ("width", C.c_int32), ("num_actions", C.c_int32), ("support_size", C.c_int32), ("normalize", C.c_int32),
+                 ("x", _vp)] + [(n, _vp) for n in HEAD_FIELDS] + [("embedding", _vp), ("value", _vp), ("prior_logits", _vp)])
+
+
 class MzsConv3x3sArgs(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32),
                 ("width", C.c_int32), ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("relu", C.c_int32),
@@ -126,7 +133,7 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
                     "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
                     "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc",
-                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes", "mzs_conv3x3_stride2_nhwc"]
+                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes", "mzs_conv3x3_stride2_nhwc", "mzs_resnet_root_tail"]
 
 _lib = None
 
@@ -166,6 +173,7 @@ def load(build_if_missing: bool = True):
     L.mzs_conv3x3_nhwc.argtypes = [C.POINTER(MzsConv3x3Args), _vp]
     L.mzs_resblock_v1.argtypes = [C.POINTER(MzsResblockArgs), _vp]
     L.mzs_conv3x3_stride2_nhwc.argtypes = [C.POINTER(MzsConv3x3sArgs), _vp]
+    L.mzs_resnet_root_tail.argtypes = [C.POINTER(MzsRootTailArgs), _vp]
     L.mzs_resblock_workspace_bytes.argtypes = [C.c_int32] * 4
     L.mzs_resnet_search.argtypes = [_vp, C.POINTER(MzsTowerArgs), C.c_float, C.c_int32, C.c_int32, _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4

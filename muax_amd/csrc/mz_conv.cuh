@@ -1145,6 +1145,87 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
 }
 
 #ifndef MZ_NO_TOWER_KERNELS
+// The tail of root inference with the ResNet nets (muax/model.py:251-263): ResNetRepresentation's last
+// hk.AvgPool(3, 2, 'SAME') (the mean of the VALID elements under a window) of its [H][W][64] map (H, W in {11, 12}: 6 x 6
+// out) + min_max_normalize2d (muax/nn.py:47-56, :308-310), then ResNetPrediction on that embedding and the value's
+// support decode (muax/nn.py:313-341, muax/model.py:254) -- one workgroup per root; in the torch mirror these were ~35
+// small framework kernels (two library GEMMs per head among them), 0.17 of the 1.1 ms root inference.
+struct RootTailParams {
+  const float* x;     // [B][H][W][64]
+  float* embedding;   // [B][36][64]
+  int H, W, normalize;
+};
+__global__ __launch_bounds__(256) void mz_resnet_root_tail_kernel(const TowerParams p, const RootTailParams t) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = blockIdx.x;
+  float* cur = lds;
+  RedSlots red = {lds + 2 * kBufWords, 0};
+  HeadLds H;
+  H.hv = red.base + 32; H.hv2 = H.hv + 768; H.hp = H.hv2 + 768; H.part = H.hp + 768; H.part2 = H.part + 256;
+  H.vec = H.part2 + 256; H.lgt = H.vec + 64;
+  for (int i = tid; i < 2 * kBufWords + kHeadWords - kRhWords; i += 256) lds[i] = 0.0f;
+  __syncthreads();
+  // pooling: thread = (channel c, nine of the 36 output pixels); SAME geometry: window rows 2 oy - pt .. + 2
+  const int c = tid & 63, q = tid >> 6;
+  const int pt = max(5 * 2 + 3 - t.H, 0) / 2, pl = max(5 * 2 + 3 - t.W, 0) / 2;
+  const float* img = t.x + (size_t)r * t.H * t.W * kTowerC;
+  float v[9];
+  float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int px = 9 * q + k, oy = px / kTowerHW, ox = px - oy * kTowerHW;
+    float sum = 0.0f;
+    int cnt = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int y = 2 * oy - pt + ky, x = 2 * ox - pl + kx;
+        if (y >= 0 && y < t.H && x >= 0 && x < t.W) {
+          sum = sum + img[((size_t)y * t.W + x) * kTowerC + c];
+          cnt += 1;
+        }
+      }
+    v[k] = sum / (float)cnt;
+    mn = fminf(mn, v[k]);
+    mx = fmaxf(mx, v[k]);
+  }
+  // per-channel min / max over the 36 pixels: four partial pairs per channel through LDS
+  H.part[tid] = mn;
+  H.part2[tid] = mx;
+  __syncthreads();
+  mn = fminf(fminf(H.part[c], H.part[64 + c]), fminf(H.part[128 + c], H.part[192 + c]));
+  mx = fmaxf(fmaxf(H.part2[c], H.part2[64 + c]), fmaxf(H.part2[128 + c], H.part2[192 + c]));
+  float scale = mx - mn;
+  scale = scale < 1e-5f ? scale + 1e-5f : scale;
+  float* emb = t.embedding + (size_t)r * kTowerPix * kTowerC;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int px = 9 * q + k;
+    const float o = t.normalize ? (v[k] - mn) / scale : v[k];
+    cur[map_word(px) + c] = o;
+    emb[px * kTowerC + c] = o;
+  }
+  __syncthreads();
+  int rowc[3];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+    const int px = 16 * mt + (lane & 15);
+    rowc[mt] = (px < kTowerPix ? ((px / kTowerHW) * kHalo + px % kTowerHW) * kPixStride : kHalo * kHalo * kPixStride) +
+               4 * (lane >> 4) + (kHalo + 1) * kPixStride;
+  }
+  TowerIO io;
+  io.x = nullptr; io.y = nullptr; io.action = 0; io.reward = nullptr;
+  io.value = p.value + r;
+  io.prior_logits = p.prior_logits + (size_t)r * p.A;
+#if defined(MZ_PROFILE) && defined(MZ_PROF_HEADS)
+  unsigned long long pt_[16] = {0}, tlast_ = 0;
+  prediction_heads(p, io, cur, H, rowc, tid, lane, wave, pt_, tlast_);
+#else
+  prediction_heads(p, io, cur, H, rowc, tid, lane, wave);
+#endif
+}
+
 __global__ __launch_bounds__(256) void mz_resnet_tower_kernel(const TowerParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   PairLink L;  // (unused: one workgroup per root)

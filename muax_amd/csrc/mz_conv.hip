@@ -57,6 +57,46 @@ int mzs_debug_tower_profile(uint64_t* host_out, int32_t words) {
 }
 #endif
 
+// ---------------------------------------------------------------------------
+// tail of root inference with the ResNet nets: last pool + min-max + prediction heads
+// ---------------------------------------------------------------------------
+int mzs_resnet_root_tail(const mzs_root_tail_args* a, void* stream_) {
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_root_tail_args))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resnet_root_tail: null arguments or size mismatch (ABI)");
+  if (a->batch <= 0 || !a->x || !a->embedding || !a->value || !a->prior_logits)
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resnet_root_tail: batch / pointers");
+  if ((a->height + 1) / 2 != mz::kTowerHW || (a->width + 1) / 2 != mz::kTowerHW)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resnet_root_tail: the pooled map must be 6 x 6 (height, width in {11, 12})");
+  const float* const* hp = &a->v_c1;
+  for (int i = 0; i < 11; ++i)
+    if (!hp[i]) return mzh::fail_global(MZS_E_INVALID, "mzs_resnet_root_tail: the heads need all 11 weight arrays");
+  if (a->support_size <= 0 || 2 * a->support_size + 1 > 64 || a->num_actions <= 0 || a->num_actions > 64)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resnet_root_tail: support / action count above 64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return mzh::fail_global(MZS_E_NODEVICE, "mzs_resnet_root_tail: no HIP device (this library has no CPU fallback)");
+  if (a->device < 0 || a->device >= ndev) return mzh::fail_global(MZS_E_INVALID, "mzs_resnet_root_tail: bad device ordinal");
+  MZS_HIPG(hipSetDevice(a->device));
+  mz::TowerParams p;
+  memset(&p, 0, sizeof p);
+  p.heads = 1; p.A = a->num_actions; p.support = a->support_size; p.F = 2 * a->support_size + 1; p.B = a->batch;
+  p.v_c1 = a->v_c1; p.v_c2 = a->v_c2; p.v_l1 = a->v_l1; p.v_b1 = a->v_b1; p.v_l2 = a->v_l2; p.v_b2 = a->v_b2;
+  p.p_c1 = a->p_c1; p.p_l1 = a->p_l1; p.p_b1 = a->p_b1; p.p_l2 = a->p_l2; p.p_b2 = a->p_b2;
+  p.value = a->value; p.prior_logits = a->prior_logits;
+  mz::RootTailParams t;
+  t.x = a->x; t.embedding = a->embedding; t.H = a->height; t.W = a->width; t.normalize = a->normalize;
+  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords);
+  static bool attr_dev[64] = {};
+  if (!attr_dev[a->device & 63]) {
+    MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_root_tail_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_dev[a->device & 63] = true;
+  }
+  hipLaunchKernelGGL(mz::mz_resnet_root_tail_kernel, dim3(a->batch), dim3(256), lds, static_cast<hipStream_t>(stream_), p, t);
+  MZS_HIPG(hipGetLastError());
+  return MZS_OK;
+}
+
 int64_t mzs_tower_pair_scratch_bytes(int32_t batch) {
   if (batch <= 0 || batch > 128) return 0;  // 2 * batch workgroups have to be resident together
   return (int64_t)batch * (4 * mz::kPairSlot * 2 * (int64_t)sizeof(float) + 4 * (int64_t)sizeof(unsigned));

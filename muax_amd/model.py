@@ -209,6 +209,11 @@ class MuZero:
 
     def _root_inference_eager(self, obs):
         with torch.no_grad():
+            hip_root = getattr(self.repr_func, "hip_root", None)
+            if hip_root is not None:  # ResNet nets: last pool + min-max + prediction net + value decode in one launch
+                out = hip_root(obs, self.pred_func, self._support_size)
+                if out is not None:
+                    return out[2], out[1], out[0]
             s = self.repr_func(obs)
             v, logits = self.pred_func(s)
             v = mx_utils.support_to_scalar(torch.softmax(v, dim=-1), self._support_size).flatten()

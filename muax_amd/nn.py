@@ -783,7 +783,7 @@ class ResNetRepresentation(nn.Module):
         self.blocks1 = nn.ModuleList([ResidualConvBlockV1(2 * c, 1, True, g) for _ in range(3)])
         self.blocks2 = nn.ModuleList([ResidualConvBlockV1(2 * c, 1, True, g) for _ in range(3)])
 
-    def forward(self, obs):
+    def forward(self, obs, before_last_pool: bool = False):
         x = self.stem0.scaled(obs.to(torch.float32), 255., relu=True)
         for b in self.blocks0:
             x = b(x)
@@ -793,7 +793,53 @@ class ResNetRepresentation(nn.Module):
         x = avg_pool_same(x)
         for b in self.blocks2:
             x = b(x)
-        return min_max_normalize2d(avg_pool_same(x))
+        return x if before_last_pool else min_max_normalize2d(avg_pool_same(x))
+
+    use_hip_root = True  # last pool + min-max + the prediction net + the value decode as one launch (mzs_resnet_root_tail)
+
+    def hip_root(self, obs, pred, support_size: int):
+        """Root inference of muax/model.py:251-263 with the tail in ONE HIP launch: returns (embedding [B, 6, 6, 64],
+        value [B], prior_logits [B, A]) or None when the nets / the input are not what mzs_resnet_root_tail is built for
+        (the caller then runs the modules).  Inference only."""
+        def head_ok(seq, convs, hidden):
+            ws = [m for m in seq if isinstance(m, HkConv2D)]
+            ls = [m for m in seq if isinstance(m, LazyHkLinear)]
+            return (len(ws) == len(convs) and len(ls) == 2 and all(m.w is not None and m.w.is_cuda for m in ws + ls)
+                    and [tuple(m.w.shape[2:]) for m in ws] == convs and tuple(ls[0].w.shape) == (576, hidden)
+                    and all(m.with_bias for m in ls))
+        if not (self.use_hip_root and isinstance(pred, ResNetPrediction) and obs.is_cuda and obs.dim() == 4
+                and not torch.is_grad_enabled() and 2 * support_size + 1 <= 64 and pred.num_actions <= 64):
+            return None
+        if not (head_ok(pred.v_func, [(64, 16), (16, 16)], 16) and head_ok(pred.pi_func, [(64, 16)], 16)
+                and pred.v_func[7].w.shape[1] == 2 * support_size + 1 and pred.pi_func[5].w.shape[1] == pred.num_actions):
+            return None
+        x = self.forward(obs, before_last_pool=True)
+        if not (x.dtype == torch.float32 and x.shape[3] == 64 and -(-x.shape[1] // 2) == 6 and -(-x.shape[2] // 2) == 6):
+            return None
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        x = x.contiguous()
+        B = x.shape[0]
+        vf, pf = pred.v_func, pred.pi_func
+        heads = [vf[0].w, vf[2].w, vf[5].w, vf[5].b, vf[7].w, vf[7].b, pf[0].w, pf[3].w, pf[3].b, pf[5].w, pf[5].b]
+        keep = [h.detach().contiguous() for h in heads]
+        a = _lib.MzsRootTailArgs()
+        a.struct_size = C.sizeof(_lib.MzsRootTailArgs)
+        a.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        a.batch, a.height, a.width = B, x.shape[1], x.shape[2]
+        a.num_actions, a.support_size, a.normalize = pred.num_actions, support_size, 1
+        a.x = x.data_ptr()
+        for name, t in zip(_lib.MzsRootTailArgs.HEAD_FIELDS, keep):
+            setattr(a, name, t.data_ptr())
+        emb = torch.empty(B, 6, 6, 64, device=x.device)
+        value, logits = torch.empty(B, device=x.device), torch.empty(B, pred.num_actions, device=x.device)
+        a.embedding, a.value, a.prior_logits = emb.data_ptr(), value.data_ptr(), logits.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(L.mzs_resnet_root_tail(C.byref(a), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        self._root_keep = keep  # alive until the stream has consumed them
+        return emb, value, logits
 
 
 class ResNetPrediction(nn.Module):

@@ -589,6 +589,32 @@ def test_representation_net_takes_the_hip_convolutions():
             assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
 
 
+def test_root_inference_tail_in_one_launch():
+    """mzs_resnet_root_tail (the last AvgPool of ResNetRepresentation, min_max_normalize2d, ResNetPrediction and the value's
+    support decode: muax/nn.py:308-341, muax/model.py:251-263) against the modules on the same 11 x 11 x 64 maps: the
+    embedding to 2e-6 (a mean of <= 9 values and one division), value and prior logits to 1e-5 of their largest entries; the
+    root inference of the model takes it."""
+    m, mods = _nets(5)
+    obs = torch.from_numpy(_frames(7, seed=4)).cuda()
+    m._root_inference(None, None, obs)  # builds the layers
+    taken = []
+    orig = mx.nn.ResNetRepresentation.hip_root
+    mx.nn.ResNetRepresentation.hip_root = lambda self, *a: (lambda out: (taken.append(out is not None), out)[1])(orig(self, *a))
+    try:
+        pl, v, emb = m._root_inference(None, None, obs)
+        assert taken == [True]
+        mx.nn.ResNetRepresentation.use_hip_root = False
+        pl0, v0, emb0 = m._root_inference(None, None, obs)
+        assert taken == [True, False]
+    finally:
+        mx.nn.ResNetRepresentation.hip_root = orig
+        mx.nn.ResNetRepresentation.use_hip_root = True
+    assert emb.shape == emb0.shape == (7, 6, 6, 64) and pl.shape == pl0.shape and v.shape == v0.shape
+    assert float((emb - emb0).abs().max()) <= 2e-6
+    assert float((v - v0).abs().max()) <= 1e-5 * max(1.0, float(v0.abs().max()))
+    assert float((pl - pl0).abs().max()) <= 1e-5 * max(1.0, float(pl0.abs().max()))
+
+
 @pytest.mark.parametrize("C,H,W,B,proj", [(64, 21, 21, 5, True), (64, 11, 11, 9, True), (32, 42, 42, 3, True), (64, 21, 21, 4, False),
                                          (32, 13, 29, 2, True), (64, 10, 10, 130, False)])
 def test_residual_block_in_three_launches_against_fp64(C, H, W, B, proj):

@@ -97,6 +97,10 @@ struct TowerIO {
   float* reward;       // [1]
   float* value;        // [1]
   float* prior_logits; // [A]
+  // the workgroup's LDS is as a previous pass of THIS kernel left it (the one-launch search): the halos, the zero tails
+  // and the head maps' padding rows are still zero -- no pass writes them -- and every word a pass reads besides those it
+  // writes first, so the 66 KB zero fill (2 of the 2.5 us of "LDS init + state load") is needed once per launch only
+  bool lds_clean = false;
 };
 
 constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 68;  // 16-byte aligned pixels
@@ -809,8 +813,10 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
   const unsigned long long tstart = tlast;
 #endif
-  for (int i = tid; i < 2 * kBufWords + kHeadWords - kRhWords; i += 256) lds[i] = 0.0f;  // (rhmap is written before it is read)
-  __syncthreads();
+  if (!io.lds_clean) {
+    for (int i = tid; i < 2 * kBufWords + kHeadWords - kRhWords; i += 256) lds[i] = 0.0f;  // (rhmap is written before it is read)
+    __syncthreads();
+  }
   load_state(io.x, bufA, tid);
   __syncthreads();
   MZ_TT(0)

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
     io.x = s.embeddings + (rb + parent) * E;
     io.y = s.embeddings + (rb + newn) * E;
     io.action = action;
+    io.lds_clean = sim != loop.sim_begin;
     const bool more = sim + 1 < loop.sim_end && sim + 1 < s.S;
     int sel[3] = {0, 0, 0};
     if (!PAIRED || h == 0) {

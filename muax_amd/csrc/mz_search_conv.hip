@@ -51,6 +51,15 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   int* tree_lds = reinterpret_cast<int*>(lds + 2 * kBufWords + kHeadWords);
   __shared__ int lost_flag;
   const int tid = threadIdx.x;
+  // {sqrt(n) pb_c(n), RN(1 / n)} by visit count, behind the tree step's arrays (level_compute): while every count
+  // stays within Markstein's tested range
+  float* score_tbl = (!GUMBEL && s.S + 2 <= 300) ? reinterpret_cast<float*>(tree_lds + 15 * (s.S + 2)) : nullptr;
+  if (score_tbl) {
+    for (int n = tid; n < s.S + 2; n += 256) {
+      score_tbl[2 * n] = puct_scale(n, s.pb_c_init, s.pb_c_base);
+      score_tbl[2 * n + 1] = n > 0 ? 1.0f / (float)n : 0.0f;
+    }
+  }  // (the passes' barriers come before its first use)
   int r, h = 0;
   if constexpr (PAIRED) {  // 16 blocks = 8 roots x 2 halves, the halves of a root 8 blocks apart (same XCD)
     r = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
       const float val = *reinterpret_cast<const volatile float*>(io.value);
       const int known[4] = {parent, action, depth, newn};
       jump_expand_backup_body<GUMBEL>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
-                                      nullptr, sel, known, prefetched);
+                                      nullptr, sel, known, prefetched, score_tbl);
       MZ_ST(2)
       if (more) {
         parent = sel[0];
@@ -221,7 +230,7 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
     return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: simulation range");
   if (2 * a->blocks + 3 > mz::kPairMsgs)
     return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: too many blocks");
-  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 15 * ((size_t)sa.S + 2);
+  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 17 * ((size_t)sa.S + 2);  // (15 arrays of the tree step + the score table)
   if (lds > 160 * 1024) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: num_simulations too large for the LDS of a CU");
   if (sa.S + 1 > 4096 || sa.A > 255)
     return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: message T packs (node, action, node) as 12 + 8 + 12 bits");

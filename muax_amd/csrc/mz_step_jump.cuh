@@ -90,11 +90,15 @@ MZ_DEV void level_load(const StepArgs& s, size_t rb, int r, int node, int j, Lev
     }
   }
 }
+// `tbl` (optional, LDS): {sqrt(n) pb_c(n), RN(1 / n)} for n = 0 .. S + 1, built once per launch by a kernel that lives
+// for a whole search (mz_search_conv.hip) -- the same puct_scale() values, and x / n by Markstein's exact sequence for
+// n <= 300 (div_small, mz_fused.cuh; tests/test_oracle_kat.py): the refresh of a path's decisions is arithmetic-bound,
+// a log, a sqrt and three of its four IEEE divisions per level go
 MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc)[kMaxAS], int& best, int& child,
-                          bool& near) {
+                          bool& near, const float* tbl = nullptr) {
   const int A = s.A;
   const float nval = L.nval;
-  const float tn = puct_scale(L.nvis, s.pb_c_init, s.pb_c_base);
+  const float tn = tbl ? tbl[2 * L.nvis] : puct_scale(L.nvis, s.pb_c_init, s.pb_c_base);
   float q[kMaxAS];
   float lo = nval, hi = nval;
 #pragma unroll
@@ -121,7 +125,14 @@ MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc
     sc[t] = -INFINITY;
     if (16 * t < A) {
       const float value_score = ((L.cvis[t] > 0 ? q[t] : lo) - lo) / span;
-      const float policy_score = (tn * L.prob[t]) / (float)(L.cvis[t] + 1);
+      float policy_score;
+      if (tbl) {
+        const float x = tn * L.prob[t], d = (float)(L.cvis[t] + 1), y = tbl[2 * (L.cvis[t] + 1) + 1];
+        const float q0 = x * y;
+        policy_score = __builtin_fmaf(__builtin_fmaf(-q0, d, x), y, q0);
+      } else {
+        policy_score = (tn * L.prob[t]) / (float)(L.cvis[t] + 1);
+      }
       sc[t] = value_score + policy_score;
       if ((L.inv >> t) & 1) sc[t] = -INFINITY;
       if (!ok) sc[t] = -INFINITY;
@@ -390,7 +401,8 @@ template <bool GUMBEL>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
-                                    int* sel_out = nullptr, const int* known = nullptr, int prefetched = 0) {
+                                    int* sel_out = nullptr, const int* known = nullptr, int prefetched = 0,
+                                    const float* score_tbl = nullptr) {
   const int tid = opaque_tid(), j = tid & 15, row = tid >> 4;
   MZ_JT_BEGIN
   const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 1024 / 256 threads (64 / 16 levels in flight) or one wavefront (4)
@@ -522,11 +534,15 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
         const int e = base + u * nrows + row;
         level_load(s, rb, r, pn[e <= depth ? e : depth], j, L[u]);
       }
+#ifdef MZ_PROF_DECIDE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MZ_JT(7)
+#endif
 #pragma unroll
       for (int u = 0; u < kLevelsInFlight; ++u) {
         const int e = base + u * nrows + row;
         float sc[kMaxAS];
-        level_compute(s, j, L[u], sc, bestu[u], childu[u], nearu[u]);
+        level_compute(s, j, L[u], sc, bestu[u], childu[u], nearu[u], score_tbl);
         offu[u] = e <= depth && childu[u] >= 0 && !(e < depth && childu[u] == pn[e + 1]);
       }
 #pragma unroll

@@ -108,7 +108,8 @@ def run():
         jp = jp[jp.sum(1) > 0]
         names = ["path + expand", "per-level inputs", "discounted-return chain", "new values + write back", "decisions of the path",
                  "JUMP records (pointer jumping) + stores", "next selection"]
-        print(f"# tree step by phase ({len(jp)} workgroups): " + ", ".join(f"{nm} {jp[:, k].mean() / 2400:.2f}" for k, nm in enumerate(names)))
+        print(f"# tree step by phase ({len(jp)} workgroups): " + ", ".join(f"{nm} {jp[:, k].mean() / 2400:.2f}" for k, nm in enumerate(names))
+              + (f" [slot 7: {jp[:, 7].mean() / 2400:.2f}]" if jp[:, 7].any() else ""))
 
 
 if __name__ == "__main__":

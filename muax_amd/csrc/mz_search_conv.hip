@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
       const float rew = *reinterpret_cast<const volatile float*>(io.reward);
       const float val = *reinterpret_cast<const volatile float*>(io.value);
       const int known[4] = {parent, action, depth, newn};
-      jump_expand_backup_body<GUMBEL>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
+#ifndef MZ_SEARCH_LIF
+#define MZ_SEARCH_LIF kLevelsInFlight
+#endif
+      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
                                       nullptr, sel, known, prefetched, score_tbl);
       MZ_ST(2)
       if (more) {

@@ -397,7 +397,7 @@ MZ_DEV void jump_prefetch_levels(const StepArgs& s, int r, const JumpLds& L, int
 }
 
 // `prefetched`: bit 0 = jump_prefetch_path, bit 1 = jump_prefetch_levels have run for this simulation (and a barrier since)
-template <bool GUMBEL>
+template <bool GUMBEL, int LIF = kLevelsInFlight>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
@@ -505,11 +505,11 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
   }
   __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
   MZ_JT(3)
-  // -- decisions of the path nodes and the leaf: one row per level, kLevelsInFlight levels per row at once (all
+  // -- decisions of the path nodes and the leaf: one row per level, LIF (kLevelsInFlight) levels per row at once (all
   // their loads are issued before the first is used: a deep path costs one memory round trip, not one per 64 levels) --
-  for (int base = 0; base <= depth; base += nrows * kLevelsInFlight) {
+  for (int base = 0; base <= depth; base += nrows * LIF) {
     if constexpr (GUMBEL) {
-      for (int u = 0; u < kLevelsInFlight; ++u) {
+      for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
         if (e <= depth) {
           int best, child;
@@ -526,11 +526,11 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
         }
       }
     } else {
-      LevelIn L[kLevelsInFlight];
-      int bestu[kLevelsInFlight], childu[kLevelsInFlight], cj[kLevelsInFlight], cl[kLevelsInFlight];
-      bool nearu[kLevelsInFlight], offu[kLevelsInFlight];
+      LevelIn L[LIF];
+      int bestu[LIF], childu[LIF], cj[LIF], cl[LIF];
+      bool nearu[LIF], offu[LIF];
 #pragma unroll
-      for (int u = 0; u < kLevelsInFlight; ++u) {
+      for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
         level_load(s, rb, r, pn[e <= depth ? e : depth], j, L[u]);
       }
@@ -539,19 +539,19 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
       MZ_JT(7)
 #endif
 #pragma unroll
-      for (int u = 0; u < kLevelsInFlight; ++u) {
+      for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
         float sc[kMaxAS];
         level_compute(s, j, L[u], sc, bestu[u], childu[u], nearu[u], score_tbl);
         offu[u] = e <= depth && childu[u] >= 0 && !(e < depth && childu[u] == pn[e + 1]);
       }
 #pragma unroll
-      for (int u = 0; u < kLevelsInFlight; ++u) {  // the off-path children's stored records, all requested together
+      for (int u = 0; u < LIF; ++u) {  // the off-path children's stored records, all requested together
         cj[u] = offu[u] ? g.jump_pa[rb + childu[u]] : 0;
         cl[u] = offu[u] ? g.jump_lv[rb + childu[u]] : 0;
       }
 #pragma unroll
-      for (int u = 0; u < kLevelsInFlight; ++u) {
+      for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
         if (e <= depth && j == 0) {
           bst[e] = bestu[u];

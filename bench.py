@@ -203,7 +203,10 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     elapsed, kernel_ms = timed(True, ev_sets[0])
     for i in range(max(10, warmup)):  # (the secondary figure gets its own untimed warm-up: a different submission pattern)
         step(i)
-    pipelined, kernel_ms_pipelined = timed(False, ev_sets[1])
+    # (the median of three runs: with 200 launches in flight the runtime sometimes stalls the host once for ~17 ms --
+    # its queue / signal bookkeeping, box dependent -- which would double this secondary figure; `value` is one run)
+    runs = sorted(timed(False, ev_sets[1]) for _ in range(3))
+    pipelined, kernel_ms_pipelined = runs[1]
     depth_total = int(search.depth_sum.sum().item())  # last act's D (the same every act up to the key)
     actions = search.action.cpu()
     assert int(actions.min()) >= 0 and int(actions.max()) < A

@@ -1,9 +1,13 @@
-// mz_repr.cuh -- hk.Conv2D(C, kernel_shape=3, stride=1, padding='SAME', with_bias=False) on NHWC maps, C -> C channels
-// with C = 32 or 64: the convolutions inside the residual blocks of the reference's REPRESENTATION nets at their
-// 21 x 21, 11 x 11 and 6 x 6 stages (muax/nn.py:118-178 ResidualConvBlockV1 / V2 inside ResNetRepresentation :291-310
-// and EZStateEncoder :180-207) -- 18 of the 26 convolutions of config 4's root inference (muax/model.py:251-263), the
-// ones the library's implicit GEMM runs at 31 .. 47 TFLOP/s (profiles/r03_plugin_nets.txt).  The stride-2 stems and the
-// 42 x 42 x 32 layers (114 TFLOP/s in the library) stay where they are.
+// mz_repr.cuh -- hk.Conv2D(C, kernel_shape=3, padding='SAME', with_bias=False) on NHWC maps for the reference's
+// REPRESENTATION nets (muax/nn.py:118-178 ResidualConvBlockV1 / V2 inside ResNetRepresentation :291-310 and
+// EZStateEncoder :180-207): all 26 convolutions of config 4's root inference (muax/model.py:251-263) --
+//   * stride 1, C -> C channels with C = 32 or 64 (the 24 layers inside the residual blocks: 42 x 42 x 32, 21 x 21 x 64,
+//     11 x 11 x 64; 6 x 6 x 64 in the EZ encoder), which the library's implicit GEMM ran at 31 .. 75 TFLOP/s;
+//   * stride 2 with the channels changing (the stems: 4 raw frames -> 32, padded to 16 input channels, and 32 -> 64),
+//     haiku's SAME geometry, observations / 255 in front and relu behind fused;
+//   * variants for a whole residual block in three launches (mz_norm.hip, mzs_resblock_v1): two convolutions of one
+//     staged input (NW = 2), LayerNorm + relu applied to the input on its way into LDS (LNIN), fp64 moments of the outputs
+//     left for the LayerNorm that follows (MOM).
 //
 // Implicit GEMM on v_mfma_f32_16x16x4_f32, the recurrent kernel's tile (mz_conv.cuh):
 //     out[pixel][co] = sum_{tap, ci} in[pixel + tap][ci] W[tap][ci][co],   M = pixels in tiles of 16, N = C, K = 9 C.
@@ -12,7 +16,8 @@
 // w owns output channels 16 (w % NCB) .. + 15 (NCB = C / 16 channel blocks) and the TPW pixel tiles of its tile group
 // w / NCB; K is walked in 9 C / 16 groups of 16 input channels: per group a lane reads ONE ds_read_b128 of activations
 // per tile and ONE global_load_dwordx4 of weights from the host-packed array Wp[tap][c][g][co][i] = W[tap][16 c + 4 g + i][co]
-// (the recurrent kernel's layout), fetched one group ahead.  fp32 throughout, one accumulator chain per output.
+// (the recurrent kernel's layout), fetched two groups ahead (activations one): an explicit software pipeline, see the
+// loop.  fp32 throughout, one accumulator chain per output.
 //
 // Floating-point kernel: checked against the torch module it replaces (MIOpen) and an fp64 evaluation, tolerance in
 // tests/test_gpu_cfg4.py.

@@ -267,7 +267,9 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches up here: the scheduler otherwise sinks them
+#ifdef MZ_CONV_NO_INTERLEAVE
+    __builtin_amdgcn_sched_barrier(0);  // (rounds 1-4: everything ahead of the MFMA block)
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -283,6 +285,20 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
           cur = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], wbuf[s][grp % (AHEAD + 1)][i], cur, 0, 0, 0);
         }
       }
+#ifndef MZ_CONV_NO_INTERLEAVE
+    // the group's loads and arithmetic BETWEEN its first matrix instructions (each 16x16x4 covers eight issue slots):
+    // with everything ahead of the MFMA block (a hard scheduling barrier, until round 4) only the last MFMA of the
+    // previous group covered the ~16 other instructions of a group: 27.45 -> 27.15 ms per act of config 4
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   });
   // taps 7 (alt) and 8 (acc) are still in their accumulators: total = ((sum of taps 0..6) + tap 7) + tap 8

@@ -288,15 +288,17 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
 #ifndef MZ_CONV_NO_INTERLEAVE
     // the group's loads and arithmetic BETWEEN its first matrix instructions (each 16x16x4 covers eight issue slots):
     // with everything ahead of the MFMA block (a hard scheduling barrier, until round 4) only the last MFMA of the
-    // previous group covered the ~16 other instructions of a group: 27.45 -> 27.15 ms per act of config 4
+    // previous group covered the ~16 other instructions of a group: 27.45 -> 26.9 ms per act of config 4
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    // (one MFMA, then up to seven VALU / SALU instructions, twice; loads left to the scheduler -- pinning the VMEM and
+    // LDS reads to slots as well measured 0.25 ms per act worse, four groups of four no better)
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x006, 7, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x006, 7, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
 #endif
     __builtin_amdgcn_sched_barrier(0);

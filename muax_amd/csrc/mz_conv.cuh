@@ -264,6 +264,10 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
           f32x4& cur = P ? ralt[s] : rem[s];
           rtot[s] = seg == 2 ? cur : rtot[s] + cur;
           cur = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+          // the 4x4x1 chain of tap t - 2 ends HERE: left alone the compiler moves all 144 remainder MFMAs of a convolution
+          // into ONE block behind its 36 groups, parks their operands in accumulation registers on the way (~120 moves)
+          // and pays a hazard wait state between every two of the dependent chain: 26.9 -> 26.55 ms per act
+          asm volatile("" : "+v"(rtot[s]));
         }
       }
     }
@@ -283,6 +287,7 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
         if constexpr (REM) {
           f32x4& cur = P ? ralt[s] : rem[s];
           cur = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[grp & 1][i], wbuf[s][grp % (AHEAD + 1)][i], cur, 0, 0, 0);
+          if (i == 3 && (grp & 3) == 3 && tap >= 7) asm volatile("" : "+v"(cur));  // (taps 7, 8: never folded in the loop)
         }
       }
 #ifndef MZ_CONV_NO_INTERLEAVE

@@ -298,8 +298,9 @@ MZ_DEV void conv3x3_tiles(const float* in, const float* const (&Wp)[NW], const f
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-    // (one MFMA, then up to seven VALU / SALU instructions, twice; loads left to the scheduler -- pinning the VMEM and
-    // LDS reads to slots as well measured 0.25 ms per act worse, four groups of four no better)
+    // (... then one MFMA and up to seven VALU / SALU slots, twice, then the rest of the MFMAs: six-slot groups of VALU
+    // only measured 0.25 ms per act worse, four groups of four no better; the order of the MFMAs themselves -- tile and
+    // remainder alternating, or the tile chain first -- makes no measurable difference)
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x006, 7, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

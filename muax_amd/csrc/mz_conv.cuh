@@ -162,7 +162,10 @@ MZ_DEV void wg_sum(float (&v)[NV], RedSlots& R, int wave, int lane) {
 //   Wp[tap][c][g][co][i]            (any bijection of K is a valid order for the sum).
 // Weight quads are fetched kConvAhead groups ahead, activation quads one group ahead.
 typedef float f32x4u __attribute__((ext_vector_type(4)));
-constexpr int kConvAhead = 6;
+#ifndef MZ_CONV_AHEAD
+#define MZ_CONV_AHEAD 6
+#endif
+constexpr int kConvAhead = MZ_CONV_AHEAD;
 #ifndef MZ_CONV_FOLD_TAPS
 #define MZ_CONV_FOLD_TAPS 1
 #endif

@@ -491,6 +491,15 @@ int mzs_debug_profile(mzs_handle* h, uint64_t* device_buffer) {
   h->prof = device_buffer;
   return MZS_OK;
 }
+// ... and the tree-step phase counters of THIS translation unit's kernels (the generic one-launch search, the step-wise
+// launches): read and clear (tools/profile_generic.py)
+int mzs_debug_generic_jump_profile(uint64_t* host_out, int32_t words) {
+  static unsigned long long zero[1024 * 8];
+  if (words > 1024 * 8) words = 1024 * 8;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mz::g_jump_prof), sizeof(uint64_t) * (size_t)words) != hipSuccess) return MZS_E_RUNTIME;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mz::g_jump_prof), zero, sizeof(zero)) != hipSuccess) return MZS_E_RUNTIME;
+  return MZS_OK;
+}
 #endif
 
 // ---------------------------------------------------------------------------

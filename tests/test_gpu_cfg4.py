@@ -645,3 +645,49 @@ def test_residual_block_in_three_launches_against_fp64(C, H, W, B, proj):
     e_hip, e_mod = float((y.double() - y64).abs().max()), float((y_mod.double() - y64).abs().max())
     floor = 2e-5 * max(1.0, float(y64.abs().max()))
     assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_mod + floor, (e_hip, e_mod, floor)
+
+
+def test_c_abi_rejects_bad_representation_arguments():
+    """Error behaviour of round 4's root-inference entry points (mzs_conv3x3_nhwc, mzs_conv3x3_stride2_nhwc,
+    mzs_resblock_v1, mzs_resnet_root_tail): negative status + message, mapped to ValueError / RuntimeError -- never a launch
+    on bad pointers or unsupported shapes."""
+    import ctypes as C
+
+    from muax_amd import _lib
+    L = _lib.load()
+    x = torch.zeros(2, 12, 12, 64, device="cuda")
+    a = _lib.MzsConv3x3Args()
+    assert L.mzs_conv3x3_nhwc(C.byref(a), None) == _lib.MZS_E_INVALID  # struct_size not set
+    a.struct_size, a.batch, a.height, a.width, a.channels = C.sizeof(a), 2, 12, 12, 48
+    a.x = a.w_packed = a.y = x.data_ptr()
+    with pytest.raises((ValueError, RuntimeError), match="channels must be 32 or 64"):
+        _lib.check(L.mzs_conv3x3_nhwc(C.byref(a), None))
+    a.channels, a.width = 64, 4096
+    with pytest.raises((ValueError, RuntimeError), match="too wide"):
+        _lib.check(L.mzs_conv3x3_nhwc(C.byref(a), None))
+    s = _lib.MzsConv3x3sArgs()
+    assert L.mzs_conv3x3_stride2_nhwc(C.byref(s), None) == _lib.MZS_E_INVALID
+    s.struct_size, s.batch, s.height, s.width, s.in_channels, s.out_channels = C.sizeof(s), 2, 12, 12, 8, 32
+    s.x = s.w_packed = s.y = x.data_ptr()
+    with pytest.raises((ValueError, RuntimeError), match=r"\(4, 32\) or \(32, 64\)"):
+        _lib.check(L.mzs_conv3x3_stride2_nhwc(C.byref(s), None))
+    b = _lib.MzsResblockArgs()
+    assert L.mzs_resblock_v1(C.byref(b), None) == _lib.MZS_E_INVALID
+    b.struct_size, b.batch, b.height, b.width, b.channels, b.eps = C.sizeof(b), 2, 12, 12, 64, 1e-5
+    b.x = b.w0 = b.w1 = b.y = b.workspace = x.data_ptr()
+    with pytest.raises((ValueError, RuntimeError), match="scale and offset"):
+        _lib.check(L.mzs_resblock_v1(C.byref(b), None))
+    b.ln0_scale = b.ln0_offset = b.ln1_scale = b.ln1_offset = x.data_ptr()
+    b.workspace_bytes = 16
+    with pytest.raises((ValueError, RuntimeError), match="workspace too small"):
+        _lib.check(L.mzs_resblock_v1(C.byref(b), None))
+    assert L.mzs_resblock_workspace_bytes(2, 12, 12, 48) == 0 and L.mzs_resblock_workspace_bytes(2, 12, 12, 64) > 3 * 2 * 12 * 12 * 64 * 4
+    t = _lib.MzsRootTailArgs()
+    assert L.mzs_resnet_root_tail(C.byref(t), None) == _lib.MZS_E_INVALID
+    t.struct_size, t.batch, t.height, t.width, t.num_actions, t.support_size = C.sizeof(t), 2, 21, 21, 18, 10
+    t.x = t.embedding = t.value = t.prior_logits = x.data_ptr()
+    with pytest.raises((ValueError, RuntimeError), match="pooled map must be 6 x 6"):
+        _lib.check(L.mzs_resnet_root_tail(C.byref(t), None))
+    t.height = t.width = 11
+    with pytest.raises((ValueError, RuntimeError), match="11 weight arrays"):
+        _lib.check(L.mzs_resnet_root_tail(C.byref(t), None))

@@ -396,6 +396,27 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
   mx = row_max<STEPS>(mx);
   float scale = mx - mn;
   scale = scale < 1e-5f ? scale + 1e-5f : scale;
+#ifndef MZ_AB_NORMALIZE_IEEE
+  if constexpr (NSLOT == 2) {
+    // the two quotients share their denominator (>= 1e-5): one refined reciprocal, the pair in packed form (div_newton2, as
+    // the value scores of puct_scores) -- valid while every numerator is 0 or >= 2^-100 and the scale is below 2^41
+    // (mzs_selftest's range); a wave-uniform test, the IEEE divisions as the other branch.  4384 -> 3936 cycles per pass
+    // of the E = 32 instance, same bits (tools/ubench_netpass_e32.hip).  (A SINGLE quotient behind such a test is slower
+    // than its IEEE expansion: one-slot embeddings and the policy softmax keep the division, 1958 against 2244 cycles
+    // per CartPole pass.)
+    const float n0 = s[0] - mn, n1 = s[1] - mn;
+    const uint32_t low = min(f2u(n0) - 1u, f2u(n1) - 1u);  // 0 wraps to the top: only (0, 2^-100) fails the test
+    const bool risky = low < f2u(0x1p-100f) - 1u || !(scale < 0x1p41f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(risky) == 0, 1)) {
+      const float y0 = __builtin_amdgcn_rcpf(scale);
+      const float y = __builtin_fmaf(__builtin_fmaf(-scale, y0, 1.0f), y0, y0);
+      const f32x2 q = div_newton2((f32x2){n0, n1}, splat2(scale), splat2(y));
+      s[0] = q.x;
+      s[1] = q.y;
+      return;
+    }
+  }
+#endif
 #pragma unroll
   for (int t = 0; t < NSLOT; ++t) s[t] = (s[t] - mn) / scale;
 }

@@ -98,23 +98,53 @@ def cpu_baseline(weights, obs, noise, A, E, F, S, support, budget_s=12.0):
             reps += 1
         out[label] = (B * reps / t_total, reps, t_total)
     return {"value": round(out["all"][0], 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "third_party_probe": third_party_probe(w, obs, noise, A, E, F, S, support),
             "single_thread_value": round(out["1"][0], 1),
             "sample": f"{B} roots x S={S}, {out['all'][1]} acts on {cores} threads ({out['all'][2]:.1f}s) "
                       f"and {out['1'][1]} acts on 1 thread ({out['1'][2]:.1f}s); gcc -O2 C oracle, "
                       f"root-major OpenMP; {cores_note}"}
 
 
-def pmc_traffic(workload):
+def third_party_probe(weights, obs, noise, A, E, F, S, support, budget_s=20.0):
+    """SURVEY.md section 7 step 0 / BASELINE.md section 3's third row: is the reference's arithmetic source (jax + mctx)
+    importable on THIS host?  Recorded either way.  When both import, mctx.muzero_policy is jitted for the CPU backend
+    around this build's OWN jnp restatement of the default trio (tools/mctx_cpu_glue.py: no reference file travels) and
+    timed on the metric's workload -- a third-party baseline, never the thing measured -- and the same call's outputs
+    for seeds {0, 1, 2} at 8 roots are dumped under gpurun_out/mctx_capture/ in tests/golden/mctx_fixture.py's format."""
+    probe = {}
+    for name in ("jax", "mctx", "haiku"):
+        try:
+            mod = __import__(name)
+            probe[name] = getattr(mod, "__version__", "present")
+        except Exception as e:  # noqa: BLE001 -- ImportError, or a broken install: both are "absent" here
+            probe[name] = f"absent ({type(e).__name__})"
+    if not (probe["jax"].startswith("absent") or probe["mctx"].startswith("absent")):
+        try:
+            import jax
+            probe["threefry_partitionable"] = bool(jax.config.jax_threefry_partitionable)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import mctx_cpu_glue
+            probe.update(mctx_cpu_glue.time_and_capture(weights, obs, noise, A, E, F, S, support, budget_s,
+                                                        os.path.join(ROOT, "gpurun_out", "mctx_capture")))
+        except Exception as e:  # noqa: BLE001
+            probe["error"] = f"{type(e).__name__}: {e}"[:300]
+    else:
+        probe["threefry_partitionable"] = None
+    return probe
+
+
+def pmc_traffic(workload, field="hbm_bytes_per_launch"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(workload, {}).get(field)
     except Exception:
         return None
 
 
-def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl", settle_ms=30.0):
+def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl", settle_ms=30.0,
+              pipelined=True):
     """`steps` timed acts of the fused act() kernel on this rank's B roots of the global batch (inputs resident in
     HBM; every act followed by the host synchronisation; barrier + max over ranks for N > 1), then the same number of
     launches back to back with one synchronisation at the end (`pipelined`).
@@ -201,6 +231,9 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     # act's actions.  The same launches enqueued back to back with one synchronisation at the end are reported beside
     # it as `value_pipelined` (what a caller that keeps several acts in flight gets; rounds 1-3 reported that as `value`).
     elapsed, kernel_ms = timed(True, ev_sets[0])
+    if not pipelined:  # (the un-settled run: the synced figure only)
+        search.close()
+        return {"elapsed": elapsed, "kernel_ms": kernel_ms}
     for i in range(max(10, warmup)):  # (the secondary figure gets its own untimed warm-up: a different submission pattern)
         step(i)
     # (the median of three runs: with 200 launches in flight the runtime sometimes stalls the host once for ~17 ms --
@@ -394,6 +427,10 @@ def config4_atari(rk, roots=128, S=200, acts=3, tower_launches=200, global_roots
     flops = recurrent_flops_per_root(A, F) * roots
     tf = flops / (kernel_ms * 1e-3) / 1e12
     pair = bool(dy.use_pair_tower) and bool(getattr(dy, "_pair_scratch", None))
+    # pair mode (two workgroups per root meeting in one XCD's L2) rests on where the hardware places blocks; MuZero
+    # checks the status words after every search and drops to one workgroup per root for good when a rendezvous was
+    # lost -- `pair_mode_survived` says which launch shape the numbers of this leg were measured with
+    pair_wanted = roots <= 128 and os.environ.get("MZS_TOWER_PAIR", "1") != "0"
     shape = "2 workgroups per root" if pair else "1 workgroup per root"
     one_pass = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
@@ -407,6 +444,11 @@ def config4_atari(rk, roots=128, S=200, acts=3, tower_launches=200, global_roots
                           f"recurrent_fn pass + mctx's expand / backward / next simulate on the root's own workgroup(s)",
                 "kernel_ms": round(search_ms, 3), "launches_per_act": 1, "algorithmic_flops_per_launch": int(flops * S),
                 "flops_counted": "the recurrent_fn passes only (the tree step has none to speak of)", "measured_on": "rank 0"}
+        # committed counter passes of this kernel (profiles/pmc_traffic.json "atari"): HBM bytes per launch and how busy
+        # the matrix pipes were, each labelled with the simulation count its pass ran at; NOT re-measured in this run
+        roof["traffic"] = pmc_traffic("atari")
+        roof["traffic_source"] = pmc_traffic("atari", "source")
+        roof["mfma_busy"] = pmc_traffic("atari", "mfma_busy")
     else:
         roof = dict(one_pass, launches_per_act=S)
     out = {"value": round(roots * rk.world / dt_sync, 1), "unit": "env-steps/s", "ms_per_act": round(dt_sync * 1e3, 3),
@@ -415,6 +457,7 @@ def config4_atari(rk, roots=128, S=200, acts=3, tower_launches=200, global_roots
                        f"obs 84x84x4, ResNet nets (embedding 6x6x64), A={A}, support {support}, num_simulations={S}, "
                        f"MuZero policy, simulation loop in one launch; no collective on the path",
            "roots_per_gpu": roots, "global_batch": global_roots,
+           "pair_mode_wanted": pair_wanted, "pair_mode_survived": pair if pair_wanted else None,
            "mean_selection_depth": round(depth, 2), "dtype": "f32",
            "search_share_of_act": None if search_ms is None else round(search_ms / (dt * 1e3), 3),
            "roofline": roof, "recurrent_pass": one_pass}
@@ -538,6 +581,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the api / config-3 sub-objects of the JSON line")
     ap.add_argument("--settle-ms", type=float, default=30.0,
                     help="untimed launches before the warm-up steps until the GPU clocks have ramped (see fused_run)")
+    ap.add_argument("--no-unsettled", action="store_true", help="skip the un-settled run that precedes the settled one")
     ap.add_argument("--no-config45", action="store_true", help="skip the config4_atari / config5_gumbel_train sub-objects")
     ap.add_argument("--cfg4-sims", type=int, default=200, help="num_simulations of the config-4 leg (200 = BASELINE's; dry runs lower it)")
     ap.add_argument("--cfg4-acts", type=int, default=3)
@@ -585,6 +629,13 @@ def main():
         B = args.roots
     F = 2 * support + 1
     dev = torch.device("cuda", local_rank)
+    # BASELINE.md section 3's own protocol first ("5 warm-up + 20 timed", nothing before the warm-up): the same steps on
+    # a GPU that has not been brought to its working clocks -> `value_unsettled`; then the run `value` comes from
+    unsettled = None
+    if args.settle_ms > 0 and not args.no_unsettled:
+        r0 = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend, 0.0,
+                       pipelined=False)
+        unsettled = B * world * args.steps / r0["elapsed"]
     run = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend,
                     args.settle_ms)
     elapsed, kernel_ms, depth_total, weights, obs, noise = (run[k] for k in ("elapsed", "kernel_ms", "depth_total",
@@ -605,6 +656,8 @@ def main():
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "env-steps/s",
             # the same launches enqueued back to back, one synchronisation after the last
+            # the same steps run FIRST in this process with --settle-ms 0 (clocks not yet ramped: BASELINE.md's protocol)
+            "value_unsettled": None if unsettled is None else round(unsettled, 1),
             "value_pipelined": round(B * world * args.steps / run["pipelined"], 1),
             "ms_per_step_pipelined": round(run["pipelined"] / args.steps * 1e3, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

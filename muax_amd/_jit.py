@@ -63,11 +63,42 @@ def plan(A: int, E: int, F: int, S: int):
 
 
 def _source_hash() -> str:
+    # everything the side library's code depends on: its sources, the ABI header, the compiler flags (they name the
+    # offload arch) -- a cache directory shared across flag or header changes must not serve a stale instance
     h = hashlib.sha256()
-    for f in _SOURCES:
+    for f in _SOURCES + [_build._ABI]:
         with open(os.path.join(_build.CSRC, f), "rb") as fh:
             h.update(fh.read())
+    h.update("\0".join(_build.FLAGS + _build.UNIT_FLAGS["mz_fused_g0.hip"]).encode())
     return h.hexdigest()[:12]
+
+
+def _compile(cc, so, tag, A, E, FS, NMAX, W, verbose) -> bool:
+    """One translation unit for one shape -> `so` (under the cache directory's file lock).  OSError propagates."""
+    import fcntl
+    with open(os.path.join(JIT_DIR, ".jit.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)  # ranks that miss the same shape build it once
+        if os.path.exists(so):
+            return True
+        deff = os.path.join(JIT_DIR, f"inst_{tag}.def")
+        with open(deff, "w") as f:
+            f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, false)\n")
+        tmp = so + f".tmp{os.getpid()}"
+        cmd = [cc] + _build.FLAGS + _build.UNIT_FLAGS["mz_fused_g0.hip"] + [
+            f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
+            os.path.join(_build.CSRC, "mz_fused_jit.hip"), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL if not verbose else None,
+                                  stderr=subprocess.DEVNULL if not verbose else None)
+            os.replace(tmp, so)
+            return True
+        except subprocess.CalledProcessError:
+            return False
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
 
 def ensure_instance(A: int, E: int, F: int, S: int, verbose: bool = False) -> bool:
@@ -90,31 +121,14 @@ def ensure_instance(A: int, E: int, F: int, S: int, verbose: bool = False) -> bo
         return False
     tag = f"a{A}_e{E}_fs{FS}_n{NMAX}_w{W}-{_source_hash()}"
     so = os.path.join(JIT_DIR, f"mzfused_{tag}.so")
-    os.makedirs(JIT_DIR, exist_ok=True)
-    if not os.path.exists(so):
-        import fcntl
-        with open(os.path.join(JIT_DIR, ".jit.lock"), "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)  # ranks that miss the same shape build it once
-            if not os.path.exists(so):
-                deff = os.path.join(JIT_DIR, f"inst_{tag}.def")
-                with open(deff, "w") as f:
-                    f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, false)\n")
-                tmp = so + f".tmp{os.getpid()}"
-                cmd = [cc] + _build.FLAGS + _build.UNIT_FLAGS["mz_fused_g0.hip"] + [
-                    f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
-                    os.path.join(_build.CSRC, "mz_fused_jit.hip"), "-o", tmp]
-                if verbose:
-                    print(" ".join(cmd))
-                try:
-                    subprocess.check_call(cmd, stdout=subprocess.DEVNULL if not verbose else None,
-                                          stderr=subprocess.DEVNULL if not verbose else None)
-                    os.replace(tmp, so)
-                except (subprocess.CalledProcessError, OSError):
-                    _failed.add(shape)
-                    return False
-                finally:
-                    if os.path.exists(tmp):
-                        os.remove(tmp)
+    try:  # a read-only install (no cache directory, no lock file) is "no instance", not an exception out of act()
+        os.makedirs(JIT_DIR, exist_ok=True)
+        if not os.path.exists(so) and not _compile(cc, so, tag, A, E, FS, NMAX, W, verbose):
+            _failed.add(shape)
+            return False
+    except OSError:
+        _failed.add(shape)
+        return False
     from . import _lib
     L = _lib.load()
     side = C.CDLL(so)

@@ -141,13 +141,14 @@ void derive_keys(mzs_handle* h, const uint32_t key[2]) {
 
 namespace mzh {
 int fail_handle(mzs_handle* h, int code, const char* msg) { return fail(h, code, "%s", msg); }
-int step_view(mzs_handle* h, mz::StepArgs* sa, mz::JumpArgs* ja, int* policy, const char* who) {
+int step_view(mzs_handle* h, mz::StepArgs* sa, mz::JumpArgs* ja, int* policy, const char* who, int* device) {
   if (!h) return MZS_E_INVALID;
   if (!h->step.rooted) return fail(h, MZS_E_INVALID, "%s: call mzs_root first", who);
   if (!h->use_jump) return fail(h, MZS_E_UNSUPPORTED, "%s: this handle's tree has no cached decisions (too large, or MZS_STEP_WALK=1)", who);
   *sa = h->step.args(h->cfg);
   *ja = h->jump;
   *policy = h->cfg.policy;
+  if (device) *device = h->cfg.device;
   return MZS_OK;
 }
 }  // namespace mzh
@@ -261,6 +262,7 @@ static int act_mlp_generic(mzs_handle* h, const mzs_act_args* a, void* stream_) 
   if (F < 17 || F > 64 || A > 64)
     return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): support_size must be 8..31 and num_actions <= 64");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  MZS_HIP(h, hipSetDevice(c.device));  // (reached before mzs_act_mlp's own hipSetDevice when num_simulations > kMaxSims)
   if (int rc = ensure_step_state(h)) return rc;
   if (!h->use_jump)
     return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): tree beyond the cached-decision budget; use the step-wise path");

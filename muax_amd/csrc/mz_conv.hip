@@ -14,12 +14,11 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
   mz::TowerParams p;
   if (int rc = tower_params_from_args(a, p)) return rc;
   const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords);
-  static bool tower_attr_dev[64] = {};  // per device: one process may drive several GPUs
-  bool& tower_attr = tower_attr_dev[a->device & 63];
-  if (!tower_attr) {
+  static mzh::LdsGrant tower_attr;  // per device: one process may drive several GPUs
+  if (!tower_attr.covers(a->device, lds)) {
     MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    tower_attr = true;
+    tower_attr.note(a->device, lds);
   }
   if (a->pair_scratch) {
     const int64_t need = mzs_tower_pair_scratch_bytes(a->batch);
@@ -28,12 +27,11 @@ int mzs_resnet_tower(const mzs_tower_args* a, void* stream_) {
     if (2 * a->blocks + 1 > mz::kPairMsgs) return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resnet_tower: too many blocks for pair mode");
     p.pair_f = static_cast<float*>(a->pair_scratch);
     p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot * 2);  // (8-byte words)
-    static bool pair_attr_dev[64] = {};
-    bool& pair_attr = pair_attr_dev[a->device & 63];
-    if (!pair_attr) {
+    static mzh::LdsGrant pair_attr;
+    if (!pair_attr.covers(a->device, lds)) {
       MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_tower_pair_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      pair_attr = true;
+      pair_attr.note(a->device, lds);
     }
     const int groups = (a->batch + 7) / 8;  // 16 blocks = 8 roots x 2 halves
     hipLaunchKernelGGL(mz::mz_resnet_tower_pair_kernel, dim3(16 * groups), dim3(256), lds,
@@ -86,11 +84,11 @@ int mzs_resnet_root_tail(const mzs_root_tail_args* a, void* stream_) {
   mz::RootTailParams t;
   t.x = a->x; t.embedding = a->embedding; t.H = a->height; t.W = a->width; t.normalize = a->normalize;
   const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords);
-  static bool attr_dev[64] = {};
-  if (!attr_dev[a->device & 63]) {
+  static mzh::LdsGrant tail_attr;
+  if (!tail_attr.covers(a->device, lds)) {
     MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_resnet_root_tail_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_dev[a->device & 63] = true;
+    tail_attr.note(a->device, lds);
   }
   hipLaunchKernelGGL(mz::mz_resnet_root_tail_kernel, dim3(a->batch), dim3(256), lds, static_cast<hipStream_t>(stream_), p, t);
   MZS_HIPG(hipGetLastError());

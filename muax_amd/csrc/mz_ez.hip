@@ -10,12 +10,11 @@ namespace {
 template <int C>
 int launch_ez(const mz::EzParams& p, int device, hipStream_t stream) {
   const size_t lds = sizeof(float) * mz::EzGeom<C>::LDS_WORDS;
-  static bool attr_dev[64] = {};  // per device: one process may drive several GPUs
-  bool& attr = attr_dev[device & 63];
-  if (!attr) {
+  static mzh::LdsGrant attr;  // per device: one process may drive several GPUs
+  if (!attr.covers(device, lds)) {
     MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_ez_recurrent_kernel<C>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
+    attr.note(device, lds);
   }
   hipLaunchKernelGGL(mz::mz_ez_recurrent_kernel<C>, dim3(p.B), dim3(256), lds, stream, p);
   MZS_HIPG(hipGetLastError());

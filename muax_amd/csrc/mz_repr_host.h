@@ -44,13 +44,13 @@ inline Geometry geometry_strided(int height, int width, int cin, int stride) {
 
 template <int C, int TPW, int NW, bool LNIN, bool MOM, int CIN = C, int STRIDE = 1>
 int launch(const mz::ReprConvParams& p, int blocks, size_t lds, hipStream_t stream) {
-  static size_t granted[64] = {};
+  static mzh::LdsGrant granted;
   int dev = 0;
   MZS_HIPG(hipGetDevice(&dev));
-  if (lds > granted[dev & 63]) {
+  if (!granted.covers(dev, lds)) {
     MZS_HIPG(hipFuncSetAttribute(reinterpret_cast<const void*>(mz::mz_repr_conv3x3_kernel<C, TPW, NW, LNIN, MOM, CIN, STRIDE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    granted[dev & 63] = lds;
+    granted.note(dev, lds);
   }
   // images in grid y: at most 65535 per launch (larger batches go in slices; the moment arrays are [tensor][B][K][2], so
   // a slice keeps the full batch as its stride and only shifts the image index)

@@ -223,7 +223,11 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
   mz::StepArgs sa;
   mz::JumpArgs ja;
   int policy = 0;
-  if (int rc = mzh::step_view(h, &sa, &ja, &policy, "mzs_resnet_search")) return rc;
+  int tree_device = -1;
+  if (int rc = mzh::step_view(h, &sa, &ja, &policy, "mzs_resnet_search", &tree_device)) return rc;
+  // the tree belongs to the handle's device; the nets' arrays are named by a->device -- one launch cannot serve two
+  if (a && a->struct_size == (int32_t)sizeof(mzs_tower_args) && a->device != tree_device)
+    return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: the nets' device differs from the handle's");
   mz::TowerParams p;
   if (int rc = tower_params_from_args(a, p, true)) return mzh::fail_handle(h, rc, mzs_last_error(nullptr));
   if (!p.heads) return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: needs the heads (the whole recurrent_fn)");
@@ -258,12 +262,12 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
   }
   {
     // raise the kernel's dynamic-LDS limit once per (instance, device) and size
-    static size_t granted[4][64] = {};
-    size_t& have = granted[(gumbel ? 2 : 0) + (a->pair_scratch ? 1 : 0)][a->device & 63];
-    if (lds > have) {
+    static mzh::LdsGrant granted[4];
+    mzh::LdsGrant& have = granted[(gumbel ? 2 : 0) + (a->pair_scratch ? 1 : 0)];
+    if (!have.covers(a->device, lds)) {
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return mzh::fail_handle(h, MZS_E_RUNTIME, "mzs_resnet_search: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-      have = lds;
+      have.note(a->device, lds);
     }
   }
   void* args[] = {&p, &sa, &ja, const_cast<mz::SearchLoop*>(&loop)};

@@ -813,8 +813,18 @@ class ResNetRepresentation(nn.Module):
         if not (head_ok(pred.v_func, [(64, 16), (16, 16)], 16) and head_ok(pred.pi_func, [(64, 16)], 16)
                 and pred.v_func[7].w.shape[1] == 2 * support_size + 1 and pred.pi_func[5].w.shape[1] == pred.num_actions):
             return None
+        # the map before the last pool, from the input's size alone (two stride-2 stems and one pool, SAME: ceil
+        # division each) -- decided BEFORE any compute, so an unsupported size does not run the net twice
+        def half(n):
+            return -(-n // 2)
+        hw = [half(half(half(n))) for n in obs.shape[1:3]]
+        if not all(half(n) == 6 for n in hw):
+            return None
+        heads_t = [m.w for seq in (pred.v_func, pred.pi_func) for m in seq if isinstance(m, (HkConv2D, LazyHkLinear))]
+        if not all(t.dtype == torch.float32 and t.device == obs.device for t in heads_t):
+            return None
         x = self.forward(obs, before_last_pool=True)
-        if not (x.dtype == torch.float32 and x.shape[3] == 64 and -(-x.shape[1] // 2) == 6 and -(-x.shape[2] // 2) == 6):
+        if not (x.dtype == torch.float32 and x.shape[3] == 64 and list(x.shape[1:3]) == hw):
             return None
         import ctypes as C
 

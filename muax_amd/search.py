@@ -479,6 +479,8 @@ class MuZeroSearch:
                 nxt = self.expand_backup_select(sim, *recurrent_fn(*nxt))
 
         do_root()
+        if native_loop is not None and getattr(self, "_native_loop_unusable", False):
+            native_loop = None  # (found out on an earlier call: this handle's tree has no cached decisions)
         if native_loop is not None:
             self.select(0)  # simulate() of simulation 0; every later one is the tail of its predecessor inside the launch
             ev = getattr(self, "time_native_loop", None)  # (start, end) events of a profiler (bench.py), else None
@@ -492,6 +494,8 @@ class MuZeroSearch:
                 if "cached decisions" not in str(e):
                     raise
                 native_loop = None  # (trees beyond the cached-decision budget keep the per-simulation launches)
+                self._native_loop_unusable = True
+                do_root()  # select(0) above has already counted simulation 0's depth; the fall-back loop starts from the root again
         if native_loop is not None:
             pass
         elif not graph:

@@ -472,6 +472,65 @@ def test_one_launch_search_equals_the_per_simulation_launches(B, S, policy, max_
         assert int(t1["node_visits"][:, 1:].max()) > 1 and int((t1["parents"][:, 1:] == -1).sum()) > 0  # re-expansions happened
 
 
+@pytest.mark.parametrize("B,S", [(128, S_FULL), (144, 60)])
+def test_one_launch_search_replayed_in_the_oracle(oracle, B, S):
+    """mz_resnet_search_kernel (the bench line's dominant config-4 kernel) against the ORACLE directly, not through
+    the per-simulation HIP route: the tree the one launch leaves is replayed -- for every simulation the oracle's own
+    `step_select` (its tree, the same simulation key) must name the (parent, action) the kernel stored for node
+    sim + 1, then the oracle's `step_expand_backup` is fed that node's own stored reward / prior logits / raw value /
+    embedding -- and at the end every tree array, the sampled actions and the weights must be equal, bit for bit.
+    128 roots x 200 simulations x 18 actions is config 4's shard (pair mode); 144 roots take one workgroup per root.
+    A regression in the tree-step body the two HIP routes share (mz_step_jump.cuh) fails HERE."""
+    m, mods = _nets(5)
+    dy, pred = mods[2], mods[1]
+    obs = torch.from_numpy(_frames(B, seed=40 + B)).cuda()
+    pl, v, emb = m._root_inference(None, None, obs)
+    E = 2304
+    rng = np.random.default_rng(B + S)
+    noise = rng.dirichlet([0.3] * A, B).astype(F32)
+    invalid = (rng.uniform(size=(B, A)) < 0.1).astype(np.uint8)
+    invalid[np.arange(B), rng.integers(0, A, B)] = 0
+    key = [3, 1000 + B]
+    assert dy.hip_search_ok(pred, (6, 6, 64), SUPPORT)
+
+    def native(handle, b, e):
+        dy.hip_search(pred, handle, SUPPORT, 0.99, b, e)
+
+    s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, E, tiebreak=True))
+    out = s.search((pl, v, emb.reshape(B, -1)), None, key=key, invalid_actions=torch.from_numpy(invalid).cuda(),
+                   dirichlet_noise=torch.from_numpy(noise).cuda(), with_tree=True, native_loop=native)
+    torch.cuda.synchronize()
+    assert not getattr(s, "_native_loop_unusable", False)  # the one launch really ran
+    if B <= 128:
+        assert dy._pair_scratch and not dy.pair_lost()
+    t = out.search_tree
+    par, afp, rew, logit, raw, embs = (getattr(t, f).cpu().numpy() for f in
+                                       ("parents", "action_from_parent", "children_rewards", "children_prior_logits",
+                                        "raw_values", "embeddings"))
+    tree = oracle.Tree(B, S + 1, A, E)
+    cfg = oracle.SearchCfg(S, tiebreak=1)
+    oracle.tree_init(tree, oracle.root_prior(pl.cpu().numpy(), noise, 0.25, invalid), v.cpu().numpy(),
+                     emb.reshape(B, -1).cpu().numpy(), invalid)
+    k_sample, _, sims = oracle.sim_keys_from_act_key(key, S)
+    rows = np.arange(B)
+    disc = np.full(B, 0.99, F32)
+    for sim in range(S):
+        n = sim + 1
+        p_ref, a_ref, _ = oracle.step_select(tree, cfg, sim, sims[sim])
+        assert np.array_equal(p_ref, par[:, n]) and np.array_equal(a_ref, afp[:, n]), sim
+        oracle.step_expand_backup(tree, sim, p_ref, a_ref, rew[rows, p_ref, a_ref], disc, logit[:, n], raw[:, n], embs[:, n])
+    g = oracle.gumbel(k_sample, B * A).reshape(B, A)
+    a_ref, w_ref = oracle.summary_sample(tree, 1.0, g)
+    assert np.array_equal(a_ref, out.action.cpu().numpy())
+    assert np.array_equal(w_ref, out.action_weights.cpu().numpy())
+    assert_trees_equal(tree, out.search_tree, exact_floats=True)
+    depth = np.zeros_like(par)
+    for k in range(1, S + 1):
+        depth[:, k] = depth[rows, par[:, k]] + 1
+    assert np.array_equal(depth.sum(1), s.depth_sum.cpu().numpy())
+    s.close()
+
+
 def test_one_launch_search_in_two_halves_and_through_act():
     """[0, S/2) and [S/2, S) as two launches == one launch (the second continues from the selection the first one's
     tail left in the handle), and MuZero.act() takes the one-launch route by itself: same actions, weights and

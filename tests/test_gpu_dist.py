@@ -149,6 +149,37 @@ def test_bench_plain_invocation_launches_its_own_ranks():
     assert u["ms_allreduce_alone"] > 0 and u["allreduce_bytes"] == 4 * 1564  # the default trio's 18 arrays, one message
 
 
+def test_bench_eight_rank_dry_run_on_one_gpu():
+    """`python bench.py --gpus 8` as the driver's 8-GPU run will start it, dry-run on this box's one device
+    (MUAX_BENCH_SINGLE_DEVICE: eight processes on device 0 over gloo) -- eight library loads, eight handles, eight
+    pair-mode scratch allocations competing for the same CUs (pair mode is left ON: with eight processes on one GPU
+    a rendezvous may be lost, and then the automatic fall-back to one workgroup per root is what gets exercised;
+    `pair_mode_survived` says which), the rendezvous on a free port, and all three legs reporting n_gpus 8.  The
+    driver's first world-8 run must not be the first world-8 execution ever."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MZS_TOWER_PAIR")}
+    env["MUAX_BENCH_SINGLE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "3",
+                          "--cfg4-sims", "20", "--cfg4-acts", "1", "--cfg5-iters", "5"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["launcher"] == "self" and line["config"]["backend"] == "gloo"
+    assert len(line["config"]["ranks"]) == 8 and [r.split(":")[0] for r in line["config"]["ranks"]] == [f"rank {i}" for i in range(8)]
+    assert abs(line["value"] - 8 * 4096 * 10 / (line["ms_per_step"] * 10e-3)) < 0.01 * line["value"]
+    assert line["value_unsettled"] > 0
+    c4, c5 = line["config4_atari"], line["config5_gumbel_train"]
+    assert "error" not in c4 and "error" not in c5, (c4, c5)
+    assert c4["n_gpus"] == 8 and c4["global_batch"] == 1024 and c4["roots_per_gpu"] == 128 and len(c4["ranks"]) == 8
+    assert c4["pair_mode_wanted"] is True and c4["pair_mode_survived"] in (True, False)
+    assert c5["n_gpus"] == 8 and c5["update"]["weights_identical_on_all_ranks_after"] is True
+    assert c5["update"]["allreduce_in_timed_update"] is True and c5["update"]["ms_allreduce_alone"] > 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_8ranks_1gpu.json"), "w") as f:
+        f.write(lines[0] + "\n")
+
+
 def test_bench_refuses_more_gpus_than_the_box_has():
     """Without the dry-run switch a plain `--gpus 2` on a 1-GPU box must fail loudly, not print n_gpus: 1."""
     if torch.cuda.device_count() >= 2:
@@ -180,6 +211,14 @@ def test_bench_line_schema_at_one_gpu():
     assert abs(r["achieved"] - r["frac"] * 8000.0) < 0.5
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the import probe for the reference's arithmetic source is recorded either way
+    tp = c["third_party_probe"]
+    assert set(("jax", "mctx", "threefry_partitionable")) <= set(tp)
+    assert tp["jax"].startswith("absent") or "mctx_cpu" in tp or "error" in tp or tp["mctx"].startswith("absent")
+    assert line["value_unsettled"] > 0  # BASELINE.md's protocol without the clock-settling launches, beside `value`
+    c4 = line["config4_atari"]
+    assert c4["pair_mode_wanted"] is True and c4["pair_mode_survived"] is True
+    assert "mfma_busy" in c4["roofline"] and "traffic" in c4["roofline"]
     assert line["api"]["numpy"]["value"] > 0 and line["api"]["device"]["value"] > 0
     for r4 in (line["config4_atari"]["roofline"], line["config4_atari"]["recurrent_pass"]):
         assert r4["bound"] == "mfma" and r4["peak"] == 157.3

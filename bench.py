@@ -143,8 +143,26 @@ def pmc_traffic(workload, field="hbm_bytes_per_launch"):
         return None
 
 
+_SIGNAL_POOL_KEEPALIVE = []
+
+
+def grow_signal_pool(n=2048):
+    """The HIP runtime hands every synchronised launch a completion signal from a pool that grows on demand, and a
+    growth step stalls the host: tools/diag_stall.py shows ONE act of ~50 ms among thousands of 0.118 ms around the
+    1100th synchronised launch of a process (and a 1-3 ms one around the 420th) -- inside the timed region of a
+    200-step run that is the whole measurement.  Recording `n` throwaway events once, before anything is timed, makes
+    the pool grow there instead (2048 events: no step above 1 ms in 4000).  The events stay alive for the process."""
+    if _SIGNAL_POOL_KEEPALIVE:
+        return
+    for _ in range(n):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _SIGNAL_POOL_KEEPALIVE.append(e)
+    torch.cuda.synchronize()
+
+
 def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl", settle_ms=30.0,
-              pipelined=True):
+              unsettled_first=False):
     """`steps` timed acts of the fused act() kernel on this rank's B roots of the global batch (inputs resident in
     HBM; every act followed by the host synchronisation; barrier + max over ranks for N > 1), then the same number of
     launches back to back with one synchronisation at the end (`pipelined`).
@@ -155,6 +173,7 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     settle phase is `settle_ms` of untimed launches of the same kernel (--settle-ms 0 turns it off; it is named in
     the JSON line's config)."""
     from muax_amd import MuZeroSearch, SearchConfig
+    grow_signal_pool()
     _, obs_dim, E, A, support, S = WORKLOADS[workload]
     F = 2 * support + 1
     weights = haiku_style_weights(0, obs_dim, E, A, F)
@@ -168,15 +187,6 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     def step(i):
         search.act_mlp(d_obs, (0, i), dirichlet_noise=d_noise, dirichlet_fraction=0.25, temperature=1.0)
 
-    if settle_ms > 0:
-        step(0)
-        torch.cuda.synchronize()
-        t_s = time.perf_counter()
-        step(0)
-        torch.cuda.synchronize()
-        per = max(time.perf_counter() - t_s, 2e-5)
-        for i in range(min(5000, int(settle_ms * 1e-3 / per) + 1)):
-            step(i)
     # HIP events bracket a SAMPLE of the launches (every 10th): an event pair costs ~6 us of stream time, 5 % of the
     # kernel, so bracketing every launch would slow the very loop that is being timed.  They are created AND recorded
     # once up front: the first record() of an event makes the runtime allocate its completion signal, and a pool that
@@ -185,7 +195,7 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     ev_every = 10 if steps >= 20 else 1
     sampled = [i for i in range(steps) if i % ev_every == ev_every // 2]
     ev_sets = []
-    for _ in range(2):
+    for _ in range(3):
         evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sampled}
         for a_, b_ in evs.values():
             a_.record()
@@ -230,10 +240,24 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     # the host synchronisation the reference's np.asarray / .item() imply -- the next act of an RL loop needs this
     # act's actions.  The same launches enqueued back to back with one synchronisation at the end are reported beside
     # it as `value_pipelined` (what a caller that keeps several acts in flight gets; rounds 1-3 reported that as `value`).
+    # BASELINE.md section 3's own protocol first ("5 warm-up + 20 timed", nothing before the warm-up): the same steps
+    # on a GPU that has not yet been brought to its working clocks -> `elapsed_unsettled`; then the settling launches,
+    # the warm-up steps again, and the run `value` comes from.  (One handle, every event recorded up front: a second
+    # handle / a second set of fresh events in front of the timed region brought the 45 ms signal-pool stall back.)
+    elapsed_unsettled = None
+    if unsettled_first and settle_ms > 0:
+        elapsed_unsettled, _ = timed(True, ev_sets[2])
+    if settle_ms > 0:
+        t_s = time.perf_counter()
+        step(0)
+        torch.cuda.synchronize()
+        per = max(time.perf_counter() - t_s, 2e-5)
+        for i in range(min(5000, int(settle_ms * 1e-3 / per) + 1)):
+            step(i)
+        for i in range(warmup):
+            step(i)
+            torch.cuda.synchronize()
     elapsed, kernel_ms = timed(True, ev_sets[0])
-    if not pipelined:  # (the un-settled run: the synced figure only)
-        search.close()
-        return {"elapsed": elapsed, "kernel_ms": kernel_ms}
     for i in range(max(10, warmup)):  # (the secondary figure gets its own untimed warm-up: a different submission pattern)
         step(i)
     # (the median of three runs: with 200 launches in flight the runtime sometimes stalls the host once for ~17 ms --
@@ -244,7 +268,8 @@ def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None,
     actions = search.action.cpu()
     assert int(actions.min()) >= 0 and int(actions.max()) < A
     search.close()
-    return {"elapsed": elapsed, "kernel_ms": kernel_ms, "depth_total": depth_total, "weights": weights, "obs": obs,
+    return {"elapsed": elapsed, "elapsed_unsettled": elapsed_unsettled, "kernel_ms": kernel_ms, "depth_total": depth_total,
+            "weights": weights, "obs": obs,
             "noise": noise, "pipelined": pipelined, "kernel_ms_pipelined": kernel_ms_pipelined}
 
 
@@ -629,15 +654,9 @@ def main():
         B = args.roots
     F = 2 * support + 1
     dev = torch.device("cuda", local_rank)
-    # BASELINE.md section 3's own protocol first ("5 warm-up + 20 timed", nothing before the warm-up): the same steps on
-    # a GPU that has not been brought to its working clocks -> `value_unsettled`; then the run `value` comes from
-    unsettled = None
-    if args.settle_ms > 0 and not args.no_unsettled:
-        r0 = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend, 0.0,
-                       pipelined=False)
-        unsettled = B * world * args.steps / r0["elapsed"]
     run = fused_run(args.workload, B, rank, world, dev, args.steps, args.warmup, not args.no_tiebreak, dist, backend,
-                    args.settle_ms)
+                    args.settle_ms, unsettled_first=not args.no_unsettled)
+    unsettled = None if run["elapsed_unsettled"] is None else B * world * args.steps / run["elapsed_unsettled"]
     elapsed, kernel_ms, depth_total, weights, obs, noise = (run[k] for k in ("elapsed", "kernel_ms", "depth_total",
                                                                                "weights", "obs", "noise"))
     placement = [f"rank {rank}: cuda:{local_rank} ({torch.cuda.get_device_properties(local_rank).gcnArchName.split(':')[0]})"]
@@ -656,7 +675,8 @@ def main():
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "env-steps/s",
             # the same launches enqueued back to back, one synchronisation after the last
-            # the same steps run FIRST in this process with --settle-ms 0 (clocks not yet ramped: BASELINE.md's protocol)
+            # the same steps timed FIRST, right after the warm-up steps and before the clock-settling launches
+            # (BASELINE.md section 3's protocol as written)
             "value_unsettled": None if unsettled is None else round(unsettled, 1),
             "value_pipelined": round(B * world * args.steps / run["pipelined"], 1),
             "ms_per_step_pipelined": round(run["pipelined"] / args.steps * 1e3, 4),

@@ -418,6 +418,16 @@ typedef struct mzs_resblock_args {
 int mzs_resblock_v1(const mzs_resblock_args *a, void *stream);
 int64_t mzs_resblock_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels);
 
+/* A whole ResidualConvBlockV2 (muax/nn.py:151-178: the pre-activation block of the EfficientZero-style encoder,
+ * muax/nn.py:180-207) with the identity shortcut, stride 1, C -> C with C = 32 or 64, inference, in three launches:
+ *     y = x + conv_1(relu(LN_1(conv_0(relu(LN_0(x))))))
+ * fp64 moments of x; conv_0 normalising x on its way into LDS and leaving the moments of its outputs; conv_1
+ * normalising those on the way in and adding x in its epilogue.  Same argument block as mzs_resblock_v1 with
+ * w_proj / proj_scale / proj_offset NULL (the reference's projection block of this kind is strided: single calls);
+ * workspace >= mzs_resblock_v2_workspace_bytes(...); y must not alias x. */
+int mzs_resblock_v2(const mzs_resblock_args *a, void *stream);
+int64_t mzs_resblock_v2_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused-kernel instances built on demand.
  *

@@ -5,7 +5,7 @@ muax_amd/csrc/mz_instances.def; the reference's act() takes ANY num_simulations 
 muax/nn.py:59-115).  When mzs_act_mlp has no instance for a shape and a hipcc is present, `ensure_instance` compiles one
 translation unit for that shape (~25 s, once: cached as muax_amd/lib/jit/<shape>-<source hash>.so), loads it and registers
 it with the library (mzs_register_fused_dispatch) -- the shape then runs as ONE launch per act() like a listed one, same
-kernel source, same bits.  Shapes outside the kernel's own limits (more than 8 actions, more than 127 simulations,
+kernel source, same bits.  Shapes outside the kernel's own limits (more than 16 actions, more than 255 simulations,
 embeddings wider than 64) cannot be instantiated: they take the one-launch generic search (mzs_mlp_search) or the
 step-wise path.  MUAX_AMD_JIT=0 turns the on-demand build off.
 """
@@ -28,37 +28,49 @@ def _ceil_log2(n: int) -> int:
     return 0 if n <= 1 else 1 + _ceil_log2((n + 1) // 2)
 
 
-def lds_bytes(A: int, E: int, NMAX: int, WAVES: int) -> int:
-    """FusedCfg::LDS_BYTES of a plain (non-compact) instance, widest record (the Gumbel modes) -- mz_fused.cuh."""
+def lds_bytes(A: int, E: int, NMAX: int, WAVES: int, long_paths: bool = False) -> int:
+    """FusedCfg::LDS_BYTES of a plain (non-compact) instance, widest record (the Gumbel modes) -- mz_fused.cuh.
+    `long_paths`: FusedCfg::LONG (NMAX > 64) -- root paths in HBM, root Gumbel noise behind the tree."""
     selw = ((2 * A + 3) // 4) * 4
     st0 = selw + 4
     path0 = st0 + 5 * A + (E if E <= 16 else 0)
     entry = 8 if _ceil_log2(NMAX) + max(1, _ceil_log2(A)) <= 8 else 16
     pathw = (NMAX * entry + 31) // 32
-    ns = (path0 + pathw) | 1
-    tree = ((ns * NMAX + 3) // 4) * 4
+    ns = (path0 + (0 if long_paths else pathw)) | 1
+    tree = ((ns * NMAX + 3) // 4) * 4 + (((A + 3) // 4) * 4 if long_paths else 0)
     root = tree + ((8 - tree % 32 + 32) % 32)
     tbl = 2 * (((NMAX + 2 + 3) // 4) * 4)
     return 4 * (tbl + 4 * WAVES * root)
 
 
 def plan(A: int, E: int, F: int, S: int):
-    """(FS, NMAX, WAVES) of an instance that serves the shape, or None when the kernel's own limits rule it out."""
-    if not (1 <= A <= 8 and 17 <= F <= 63 and S >= 1):
+    """(FS, NMAX, WAVES, LONG) of an instance that serves the shape, or None when the kernel's own limits rule it out:
+    A <= 16 (all scores of a node in one lane's registers; four action bits per JUMP word), S <= 255 (depths are bytes).
+    Up to 127 simulations the nodes' root paths may live in the LDS record; beyond -- or when that lets a workgroup
+    hold more roots -- in HBM (FusedCfg::LONG)."""
+    if not (1 <= A <= 16 and 17 <= F <= 63 and 1 <= S <= 255):
         return None
     if E < 1 or E > 64 or (E > 16 and E % 8):
         return None
     FS = 2 if F <= 32 else 4
-    for NMAX in (51, 64, 101, 128):
+    for NMAX in (51, 64, 101, 128, 161, 201, 256):
         if S + 1 > NMAX:
             continue
         entry = 8 if _ceil_log2(NMAX) + max(1, _ceil_log2(A)) <= 8 else 16
         pathw = (NMAX * entry + 31) // 32
-        if (pathw + 15) // 16 > 4 or A > pathw:
-            continue
-        for W in (4, 3, 2, 1):
-            if lds_bytes(A, E, NMAX, W) <= 160 * 1024:
-                return FS, NMAX, W
+        best = None
+        for long_paths in (False, True):  # (paths in LDS are the faster record: taken unless HBM paths hold more roots)
+            if long_paths and NMAX <= 64:
+                continue
+            if (pathw + 15) // 16 > (8 if long_paths else 4) or (A > pathw and not long_paths):
+                continue
+            for W in (4, 3, 2, 1):
+                if lds_bytes(A, E, NMAX, W, long_paths) <= 160 * 1024:
+                    if best is None or W > best[2]:
+                        best = (FS, NMAX, W, long_paths)
+                    break
+        if best is not None:
+            return best
     return None
 
 
@@ -73,7 +85,7 @@ def _source_hash() -> str:
     return h.hexdigest()[:12]
 
 
-def _compile(cc, so, tag, A, E, FS, NMAX, W, verbose) -> bool:
+def _compile(cc, so, tag, A, E, FS, NMAX, W, LONG, verbose) -> bool:
     """One translation unit for one shape -> `so` (under the cache directory's file lock).  OSError propagates."""
     import fcntl
     with open(os.path.join(JIT_DIR, ".jit.lock"), "w") as lock:
@@ -82,7 +94,7 @@ def _compile(cc, so, tag, A, E, FS, NMAX, W, verbose) -> bool:
             return True
         deff = os.path.join(JIT_DIR, f"inst_{tag}.def")
         with open(deff, "w") as f:
-            f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, false)\n")
+            f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, {'true' if LONG else 'false'})\n")
         tmp = so + f".tmp{os.getpid()}"
         cmd = [cc] + _build.FLAGS + _build.UNIT_FLAGS["mz_fused_g0.hip"] + [
             f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
@@ -109,7 +121,7 @@ def ensure_instance(A: int, E: int, F: int, S: int, verbose: bool = False) -> bo
     pl = plan(A, E, F, S)
     if pl is None:
         return False
-    FS, NMAX, W = pl
+    FS, NMAX, W, LONG = pl
     shape = (A, E, FS, NMAX, W)
     if shape in _loaded:
         return True
@@ -123,7 +135,7 @@ def ensure_instance(A: int, E: int, F: int, S: int, verbose: bool = False) -> bo
     so = os.path.join(JIT_DIR, f"mzfused_{tag}.so")
     try:  # a read-only install (no cache directory, no lock file) is "no instance", not an exception out of act()
         os.makedirs(JIT_DIR, exist_ok=True)
-        if not os.path.exists(so) and not _compile(cc, so, tag, A, E, FS, NMAX, W, verbose):
+        if not os.path.exists(so) and not _compile(cc, so, tag, A, E, FS, NMAX, W, LONG, verbose):
             _failed.add(shape)
             return False
     except OSError:

@@ -133,7 +133,8 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
                     "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
                     "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc",
-                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes", "mzs_conv3x3_stride2_nhwc", "mzs_resnet_root_tail"]
+                    "mzs_resblock_v1", "mzs_resblock_workspace_bytes", "mzs_conv3x3_stride2_nhwc", "mzs_resnet_root_tail",
+                    "mzs_resblock_v2", "mzs_resblock_v2_workspace_bytes"]
 
 _lib = None
 
@@ -175,6 +176,8 @@ def load(build_if_missing: bool = True):
     L.mzs_conv3x3_stride2_nhwc.argtypes = [C.POINTER(MzsConv3x3sArgs), _vp]
     L.mzs_resnet_root_tail.argtypes = [C.POINTER(MzsRootTailArgs), _vp]
     L.mzs_resblock_workspace_bytes.argtypes = [C.c_int32] * 4
+    L.mzs_resblock_v2.argtypes = [C.POINTER(MzsResblockArgs), _vp]
+    L.mzs_resblock_v2_workspace_bytes.argtypes = [C.c_int32] * 4
     L.mzs_resnet_search.argtypes = [_vp, C.POINTER(MzsTowerArgs), C.c_float, C.c_int32, C.c_int32, _vp]
     L.mzs_mlp_num_params.argtypes = [C.c_int32] * 4
     L.mzs_mlp_train_workspace_bytes.argtypes = [C.c_int32] * 5
@@ -189,6 +192,7 @@ def load(build_if_missing: bool = True):
     L.mzs_layernorm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     L.mzs_layernorm_workspace_bytes.restype = C.c_int64
     L.mzs_resblock_workspace_bytes.restype = C.c_int64
+    L.mzs_resblock_v2_workspace_bytes.restype = C.c_int64
     L.mzs_tower_pair_scratch_bytes.argtypes = [C.c_int32]
     L.mzs_tower_pair_scratch_bytes.restype = C.c_int64
     if L.mzs_abi_version() != 1:

@@ -74,7 +74,8 @@ struct mzs_handle {
   uint64_t* prof = nullptr;        // MZ_PROFILE builds only
   int32_t* fused_table = nullptr;  // gumbel policy, fused path: seq_halving table on the device
   float* fused_emb = nullptr;      // fused path, embed_dim > 16: [B][S+1][E] embeddings in HBM
-  int32_t* fused_path = nullptr;   // fused path, compact instances: [B][S+1][kCompactPathWords] root paths in HBM
+  int32_t* fused_path = nullptr;   // fused path, instances with the root paths in HBM: [B][S+1][fused_path_words]
+  int fused_path_words = 0;
   int cu_count = 0;
   // mzs_act_mlp_host: pinned staging (in: obs | noise | invalid, out: action | weights | value) and their device twins
   void* host_in = nullptr; void* host_out = nullptr; void* dev_noise = nullptr;  // dev_noise: [B, A] drawn root noise
@@ -400,15 +401,22 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   if (h->allow_generic && getenv("MZS_FORCE_GENERIC") != nullptr) return act_mlp_generic(h, a, stream_);
   // more 16-root workgroups than CUs: prefer a compact-record instance (two workgroups per CU), if the shape has one
   for (int compact = (c.batch > 16 * h->cu_count) ? 1 : 0; compact >= 0; --compact) {
-    p.path_scratch = compact ? h->fused_path : nullptr;
+    // (handed over whenever it exists: an instance for 128..255 simulations keeps its root paths there at any batch size)
+    p.path_scratch = h->fused_path;
+    p.path_words = h->fused_path_words;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       std::string err;
       int rc = groups[gi](mode, c.device, p, stream, A, E, F, N, compact != 0, &err);
-      if (rc == mz::kNeedPathScratch) {  // first compact launch of this handle: the HBM array of the root paths
-        MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_path),
-                             (size_t)c.batch * N * mz::kCompactPathWords * sizeof(int32_t)));
+      if (rc >= mz::kNeedPathScratch) {  // first launch of an instance with its root paths in HBM: their array
+        const int words = rc - mz::kNeedPathScratch;
+        if (h->fused_path) MZS_HIP(h, hipFree(h->fused_path));
+        h->fused_path = nullptr;
+        h->fused_path_words = 0;
+        MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_path), (size_t)c.batch * N * words * sizeof(int32_t)));
+        h->fused_path_words = words;
         p.path_scratch = h->fused_path;
-        rc = groups[gi](mode, c.device, p, stream, A, E, F, N, true, &err);
+        p.path_words = words;
+        rc = groups[gi](mode, c.device, p, stream, A, E, F, N, compact != 0, &err);
       }
       if (rc == mz::kNoFusedInstance) continue;
       if (rc != MZS_OK) return fail(h, rc, "mzs_act_mlp: %s", err.c_str());

@@ -111,6 +111,7 @@ struct FusedParams {
   uint32_t k_gumbel[2];
   uint32_t sim_keys[kMaxSims][2];  // simulate_key of every simulation (mctx search body_fun)
   uint64_t* prof;  // MZ_PROFILE builds only: [waves][8] cycle counters
+  int32_t path_words;  // words per node `path_scratch` was allocated with (an instance needs FusedCfg::PATHW)
 };
 
 // MODE: 0 muzero policy without tie-break noise, 1 muzero policy with mctx's tie-break noise,
@@ -122,9 +123,15 @@ struct FusedParams {
 // which is known when the simulation starts, so the load runs behind the network pass; written once per node) and the
 // raw value leaves the header where no decision reads it: 16 roots then need < 80 KiB of LDS, TWO workgroups share a
 // CU and every SIMD has two wavefronts whose issue latencies and LDS round trips overlap.
+// LONG (PH_ with NMAX_ > 64): long searches / wide action sets.  A node's root path is up to 128 words (255 simulations)
+// -- 256 of them per root cannot live in LDS, and from ~100 simulations on they are most of the record -- so the paths
+// take the compact record's place in HBM (up to eight words per lane of the node's row instead of one), while the
+// launch shape stays the plain one (as many roots per workgroup as the LDS holds records for, any policy); the
+// dispatcher takes such an instance whatever the batch size.
 template <int A_, int E_, int FS_, int NMAX_, int MODE_, int WAVES_ = 4, bool PH_ = false>
 struct FusedCfg {
   static constexpr bool PH = PH_;
+  static constexpr bool LONG = PH_ && NMAX_ > 64;
   static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_;
   static constexpr int A = A_, E = E_, FS = FS_, NMAX = NMAX_, MODE = MODE_;
   static_assert(FS_ == 2 || FS_ == 4, "support logits are handled as one or two packed pairs of lane slots");
@@ -154,7 +161,7 @@ struct FusedCfg {
   // share a CU (8192 LunarLander roots are then ONE round of workgroups instead of two):
   //   [SEL0 ..) child index bytes | A cached pUCT scores   [HDR0 ..) visits, value, JUMP
   //   [ST0  ..) A probs | A values | A rewards | child visit bytes
-  static constexpr bool PK = PH_ && E_ > 16;
+  static constexpr bool PK = PH_ && E_ > 16 && !LONG;
   static_assert(!PK || (A_ <= 4 && NMAX_ <= 128 && MODE_ < 2), "packed record: four byte-sized children, MuZero policy");
   static constexpr int SEL0 = 0, SELW = PK ? 1 + A : ((2 * A + 3) / 4) * 4;
   static constexpr int HDR0 = SELW, JUMP = HDR0 + 2;
@@ -228,7 +235,7 @@ struct FusedCfg {
   static_assert(NMAX <= 4096 && A <= 16, "JUMP word fields");
   static_assert(PH_ || A <= PATHW, "the root's (empty) path slot holds its Gumbel noise");
   static constexpr int PATHS = (PATHW + 15) / 16;  // path words per lane when a node's path is copied
-  static_assert(PATHS <= 4, "a node's path is copied by the 16 lanes of its row");
+  static_assert(PATHS <= (LONG ? 8 : 4), "a node's path is copied by the 16 lanes of its row");
   // the four roots of a wave start 8 banks apart: row-uniform reads of the same field of four trees
   // (selection, expansion) then hit four different banks
   static constexpr int pad_root(int w) { return w + ((8 - w % 32 + 32) % 32); }
@@ -237,9 +244,10 @@ struct FusedCfg {
   static constexpr int TBL_WORDS = 2 * (((NMAX + 2 + 3) / 4) * 4);  // {sqrt(n) pb_c(n), 1/n} pairs
   static constexpr int LDS_BYTES = 4 * (TBL_WORDS + WLDS_WORDS + ROOTS_PER_WG * ROOT_WORDS);
   static_assert(LDS_BYTES <= 160 * 1024, "tree does not fit the 160 KiB LDS of a CU: lower WAVES");
-  static_assert(!PH_ || (2 * LDS_BYTES <= 160 * 1024 && WAVES_ == 4 && (PATHW + 15) / 16 == 1),
+  static_assert(!PH_ || LONG || (2 * LDS_BYTES <= 160 * 1024 && WAVES_ == 4 && (PATHW + 15) / 16 == 1),
                 "compact record: two 16-root workgroups per CU, one path word per lane");
-  static_assert(A <= 8, "selection keeps all A scores in registers");
+  static_assert(NMAX <= 256, "JUMP word: the depth of an end point is a byte; the argument block holds 256 simulation keys");
+  static_assert(A <= 16, "selection keeps all A scores in registers; a child's action is four bits of a JUMP word");
   static_assert(E <= 32 * 16, "row-distributed vectors");
 };
 
@@ -508,12 +516,24 @@ struct Nets {
       });
       return (f32x2){h0, h1};
     } else {
+#ifdef MZ_AB_SPLIT_CHAINS
+      // A/B build only (round 5, VERDICT r4 item 4: NOT the project's arithmetic spec): P = 2 interleaved partial sums
+      // (even / odd k), combined at the end -- half the dependent-chain depth for one more add per chain
+      f32x2 h = splat2(0.0f), h1 = splat2(0.0f);
+      StaticFor<0, C::E>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i & 1) h1 = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h1);
+        else h = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h);
+      });
+      return h + h1;
+#else
       f32x2 h = splat2(0.0f);
       StaticFor<0, C::E>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         h = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h);
       });
       return h;
+#endif
     }
   }
   // Prediction (muax/nn.py:73-90) + value decode
@@ -588,6 +608,32 @@ struct Nets {
       });
       rl[0] = (f32x2){r0, r1};
     } else {
+#ifdef MZ_AB_SPLIT_CHAINS
+      f32x2 rl1[NP];
+      float ns1[C::ES];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) rl1[q] = splat2(0.0f);
+#pragma unroll
+      for (int t = 0; t < C::ES; ++t) ns1[t] = 0.0f;
+      StaticFor<0, kHidden>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const f32x2 hr = splat2(bcast<i>(h.x));
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          if constexpr (i & 1) rl1[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl1[q]);
+          else rl[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl[q]);
+        }
+#pragma unroll
+        for (int t = 0; t < C::ES; ++t) {
+          if constexpr (i & 1) fmac_bcast<i, i == 1>(ns1[t], h.y, dn2.w[i][t]);
+          else fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
+        }
+      });
+#pragma unroll
+      for (int q = 0; q < NP; ++q) rl[q] = rl[q] + rl1[q];
+#pragma unroll
+      for (int t = 0; t < C::ES; ++t) ns[t] = ns[t] + ns1[t];
+#else
       StaticFor<0, kHidden>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const f32x2 hr = splat2(bcast<i>(h.x));
@@ -596,6 +642,7 @@ struct Nets {
 #pragma unroll
         for (int t = 0; t < C::ES; ++t) fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
       });
+#endif
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) rl[q] = rl[q] + (f32x2){dr2.b[2 * q], dr2.b[2 * q + 1]};
@@ -620,6 +667,26 @@ struct Nets {
       });
       vl[0] = (f32x2){v0, v1};
     } else {
+#ifdef MZ_AB_SPLIT_CHAINS
+      f32x2 vl1[NP];
+      float pl1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) vl1[q] = splat2(0.0f);
+      StaticFor<0, kHidden>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const f32x2 gv = splat2(bcast<i>(g.x));
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          if constexpr (i & 1) vl1[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl1[q]);
+          else vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
+        }
+        if constexpr (i & 1) fmac_bcast<i, i == 1>(pl1, g.y, pp2.w[i][0]);
+        else fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
+      });
+#pragma unroll
+      for (int q = 0; q < NP; ++q) vl[q] = vl[q] + vl1[q];
+      pl = pl + pl1;
+#else
       StaticFor<0, kHidden>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const f32x2 gv = splat2(bcast<i>(g.x));
@@ -627,6 +694,7 @@ struct Nets {
         for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
         fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
       });
+#endif
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) vl[q] = vl[q] + (f32x2){pv2.b[2 * q], pv2.b[2 * q + 1]};
@@ -782,13 +850,19 @@ MZ_DEV int jump_word(int node, int action, int depth, bool near_tie) {
 // one node inside a lane.  Sums follow the canonical 16-wide butterfly on the zero-padded vector. ----
 template <int A>
 MZ_DEV float sum16_inlane(const float (&x)[A]) {
-  static_assert(A <= 8, "");
-  float p[8];
+  static_assert(A <= 16, "");
+  float p[16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = i < A ? x[i] : 0.0f;
+  for (int i = 0; i < 16; ++i) p[i] = i < A ? x[i] : 0.0f;
   float q0 = p[0] + p[1], q1 = p[2] + p[3], q2 = p[4] + p[5], q3 = p[6] + p[7];
   float r0 = q0 + q1, r1 = q2 + q3;
-  return (r0 + r1) + 0.0f;  // last butterfly step adds the (all-zero) upper half row
+  if constexpr (A <= 8) {
+    return (r0 + r1) + 0.0f;  // last butterfly step adds the (all-zero) upper half row
+  } else {
+    float q4 = p[8] + p[9], q5 = p[10] + p[11], q6 = p[12] + p[13], q7 = p[14] + p[15];
+    float r2 = q4 + q5, r3 = q6 + q7;
+    return (r0 + r1) + (r2 + r3);
+  }
 }
 template <int A>
 MZ_DEV void softmax_inlane(const float (&x)[A], float (&p)[A]) {
@@ -880,7 +954,7 @@ MZ_DEV void gumbel_scores(bool is_root, float nval, float raw, const float (&log
 }
 
 template <class C>
-__global__ __launch_bounds__(C::THREADS, C::PH ? 2 : 1) void mz_act_fused_kernel(const FusedParams p) {
+__global__ __launch_bounds__(C::THREADS, (C::PH && !C::LONG) ? 2 : 1) void mz_act_fused_kernel(const FusedParams p) {
   constexpr int A = C::A, E = C::E, NS = C::NS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // One wavefront per SIMD owns the whole 512-entry unified register file.  LLVM infers "no AGPRs"

@@ -7,7 +7,9 @@
 
 namespace mz {
 constexpr int kNoFusedInstance = 1;  // dispatcher result: this group has no instance for the shape
-constexpr int kNeedPathScratch = 2;  // a compact instance fits, but p.path_scratch is not set: allocate it and call again
+// kNeedPathScratch + w: an instance with its root paths in HBM fits, but p.path_scratch is not set or was allocated with
+// fewer than w words per node (p.path_words): allocate [B][S + 1][w] words and call again
+constexpr int kNeedPathScratch = 1000;
 // mode: FusedCfg::MODE (0 muzero, 1 muzero + tie-break noise, 2 gumbel / parent-and-siblings, 3 gumbel / mix value).
 // Returns MZS_OK after the launch, kNoFusedInstance, or a negative MZS_E_* with *err set.
 // compact: take an instance with the compact tree record (FusedCfg::PH; needs p.path_scratch), else a plain one.
@@ -18,6 +20,4 @@ int fused_dispatch_g1(int mode, int device, const FusedParams& p, hipStream_t st
 int fused_dispatch_g2(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 int fused_dispatch_g3(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
 int fused_dispatch_g4(int mode, int device, const FusedParams& p, hipStream_t stream, int A, int E, int F, int N, bool compact, std::string* err);
-// words per node of the HBM path array of a compact instance (the same for every instance with NMAX <= 64, A <= 4)
-constexpr int kCompactPathWords = 13;
 }  // namespace mz

@@ -121,4 +121,63 @@ int mzs_resblock_v1(const mzs_resblock_args* a, void* stream_) {
   return MZS_OK;
 }
 
+// ---- ResidualConvBlockV2 (muax/nn.py:151-178), the pre-activation block of the EZ encoder (:180-207), stride 1,
+// identity shortcut, C -> C:   y = x + conv_1(relu(LN_1(conv_0(relu(LN_0(x))))))   in three launches --
+//   K0  (sum, sum of squares) of x per chunk in fp64 (mz_norm.cuh's moments kernel);
+//   K1  conv_0 with relu(LN_0(.)) applied to x on its way into LDS, leaving the moments of its raw outputs;
+//   K2  conv_1 with relu(LN_1(.)) applied on the way in, the shortcut x added to the outputs in the epilogue.
+// (Seven launches as single calls: moments + apply, convolution, moments + apply, convolution, add.)
+int64_t mzs_resblock_v2_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels) {
+  if (batch <= 0 || height <= 0 || width <= 0 || (channels != 32 && channels != 64)) return 0;
+  const mzr::Geometry g = mzr::geometry(height, width, channels);
+  const size_t n1 = (size_t)height * width * channels;
+  return (int64_t)((size_t)batch * n1 * sizeof(float)
+                   + (size_t)batch * ((size_t)mz::norm_chunks((int)n1) + g.blocks) * 2 * sizeof(double));
+}
+
+int mzs_resblock_v2(const mzs_resblock_args* a, void* stream_) {
+  if (!a || a->struct_size != (int32_t)sizeof(mzs_resblock_args))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: null arguments or size mismatch (ABI)");
+  if (a->batch <= 0 || a->height <= 0 || a->width <= 0 || !a->x || !a->w0 || !a->w1 || !a->y || !a->workspace)
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: batch / height / width / pointers");
+  if (!a->ln0_scale || !a->ln0_offset || !a->ln1_scale || !a->ln1_offset)
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: every LayerNorm needs its scale and offset");
+  if (a->w_proj || a->proj_scale || a->proj_offset)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v2: identity shortcut only (the projection block is strided: single calls)");
+  if (a->channels != 32 && a->channels != 64)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v2: channels must be 32 or 64 (in == out)");
+  if (a->y == a->x) return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: y must not alias x");
+  if (a->workspace_bytes < mzs_resblock_v2_workspace_bytes(a->batch, a->height, a->width, a->channels))
+    return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: workspace too small");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return mzh::fail_global(MZS_E_NODEVICE, "mzs_resblock_v2: no HIP device (this library has no CPU fallback)");
+  if (a->device < 0 || a->device >= ndev) return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: bad device ordinal");
+  MZS_HIPG(hipSetDevice(a->device));
+  const int C = a->channels, n1 = a->height * a->width * C;
+  const mzr::Geometry g = mzr::geometry(a->height, a->width, C);
+  if (g.lds > 160 * 1024) return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v2: image too wide for the LDS of a CU");
+  float* c0 = static_cast<float*>(a->workspace);
+  double* m_x = reinterpret_cast<double*>(c0 + (size_t)a->batch * n1);  // [B][Kx][2]
+  const int Kx = mz::norm_chunks(n1);
+  double* m_c0 = m_x + (size_t)a->batch * Kx * 2;                       // [B][g.blocks][2]
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  mz::NormParams q;
+  memset(&q, 0, sizeof q);
+  q.x = a->x; q.ws = m_x; q.B = a->batch; q.n = n1; q.C = C; q.K = Kx; q.eps = a->eps;
+  q.chunk = ((n1 / 4 + Kx - 1) / Kx) * 4;
+  hipLaunchKernelGGL(mz::ln_moments_kernel, dim3(a->batch, Kx, 1), dim3(mz::kNormThreads), 0, stream, q);
+  MZS_HIPG(hipGetLastError());
+  mz::ReprConvParams p;
+  memset(&p, 0, sizeof p);
+  p.B = a->batch; p.H = a->height; p.W = a->width; p.eps = a->eps;
+  p.x = a->x; p.wp = a->w0; p.y = c0; p.mom = m_c0;
+  p.in_mom = m_x; p.in_K = Kx; p.in_scale = a->ln0_scale; p.in_offset = a->ln0_offset;
+  if (int rc = mzr::conv<1, true, true>(p, C, g, stream)) return rc;
+  p.x = c0; p.wp = a->w1; p.y = a->y; p.mom = nullptr;
+  p.in_mom = m_c0; p.in_K = 0; p.in_scale = a->ln1_scale; p.in_offset = a->ln1_offset;
+  p.residual = a->x;
+  return mzr::conv<1, true, false>(p, C, g, stream);
+}
+
 }  // extern "C"

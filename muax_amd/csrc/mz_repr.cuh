@@ -50,6 +50,10 @@ struct ReprConvParams {
   // the way in (the reference's observations / 255)
   int cin_real;
   float in_div;
+  // --- a pre-activation block (mzs_resblock_v2): the input's moments may come from mz_norm.cuh's moments kernel, whose
+  // chunk count differs from this launch's grid; the block's shortcut is added to the outputs (before their moments)
+  int in_K;               // (sum, sum of squares) pairs per image in in_mom; 0: gridDim.x (a convolution's own MOM output)
+  const float* residual;  // [B][H][W][C] added to stream 0's outputs, or null
 };
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
     float in_mean = 0.0f, in_rstd = 1.0f;
     rc_f32x4 in_g = (rc_f32x4){1.0f, 1.0f, 1.0f, 1.0f}, in_o = (rc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (LNIN) {
-      ln_stats(p.in_mom + (size_t)(p.b0 + b) * gridDim.x * 2, (int)gridDim.x, H * W * CIN, p.eps, in_mean, in_rstd);
+      const int in_k = p.in_K > 0 ? p.in_K : (int)gridDim.x;
+      ln_stats(p.in_mom + (size_t)(p.b0 + b) * in_k * 2, in_k, H * W * CIN, p.eps, in_mean, in_rstd);
       in_g = *reinterpret_cast<const rc_f32x4*>(p.in_scale + 4 * c4);
       in_o = *reinterpret_cast<const rc_f32x4*>(p.in_offset + 4 * c4);
     }
@@ -209,6 +214,18 @@ __global__ __launch_bounds__(256) void mz_repr_conv3x3_kernel(const ReprConvPara
         wcur[s] = wn1[s];
         wn1[s] = wn2[s];
       }
+    }
+  }
+  if constexpr (NW == 1 && STRIDE == 1 && CIN == C) {
+    if (p.residual != nullptr) {  // ResidualConvBlockV2's identity shortcut (muax/nn.py:166-178): y = x + conv_1(.)
+      const float* res = p.residual + (size_t)b * npix * C;
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int px = p0 + 16 * (tg * TPW + mt) + 4 * g + v;
+          if (px < p1) acc[0][mt][v] = res[(size_t)px * C + ch] + acc[0][mt][v];
+        }
     }
   }
 #pragma unroll

@@ -706,6 +706,59 @@ def test_residual_block_in_three_launches_against_fp64(C, H, W, B, proj):
     assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_mod + floor, (e_hip, e_mod, floor)
 
 
+@pytest.mark.parametrize("C,H,W,B", [(32, 42, 42, 3), (64, 21, 21, 5), (64, 11, 11, 9), (64, 6, 6, 128), (32, 13, 29, 2), (64, 10, 10, 130)])
+def test_preactivation_block_in_three_launches_against_fp64(C, H, W, B):
+    """mzs_resblock_v2 (ResidualConvBlockV2 with the identity shortcut, muax/nn.py:151-178: the EZ encoder's block,
+    :180-207) -- moments of x, conv_0 normalising x on the way in, conv_1 normalising conv_0's outputs on the way in and
+    adding x -- against an fp64 evaluation of the block and against the module path (single LayerNorm / convolution calls
+    + a framework add): within 2e-5 of the fp64 result's largest entry and no further from it than twice the module path
+    + that floor.  Also: the error returns of the entry point."""
+    g = torch.Generator().manual_seed(C + H + B)
+    blk = mx.nn.ResidualConvBlockV2(C, 1, False, generator=g)
+    x = (torch.rand(B, H, W, C, generator=g) * 2 - 1).cuda()
+    with torch.no_grad():
+        blk.use_hip = False
+        blk(x[:1].cpu())  # builds the layers
+        blk.cuda()
+        for ln in (blk.ln_0, blk.ln_1):  # non-trivial scales and offsets
+            ln.scale.copy_(torch.rand(C, generator=g) + 0.5)
+            ln.offset.copy_(torch.rand(C, generator=g) - 0.5)
+        y_mod = blk(x)
+        blk.use_hip = True
+        assert blk._hip_ok(x)
+        y = blk(x)
+        mx.nn.HkConv2D.use_hip = mx.nn.HkLayerNorm.use_hip = False
+        blk.use_hip = False
+        try:
+            y64 = blk.double()(x.double())
+        finally:
+            mx.nn.HkConv2D.use_hip = mx.nn.HkLayerNorm.use_hip = True
+    e_hip, e_mod = float((y.double() - y64).abs().max()), float((y_mod.double() - y64).abs().max())
+    floor = 2e-5 * max(1.0, float(y64.abs().max()))
+    assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_mod + floor, (e_hip, e_mod, floor)
+    if C == 64 and H == 11:
+        import ctypes as Ct
+
+        from muax_amd import _lib
+        L = _lib.load()
+        b = _lib.MzsResblockArgs()
+        assert L.mzs_resblock_v2(Ct.byref(b), None) == _lib.MZS_E_INVALID  # struct_size not set
+        b.struct_size, b.batch, b.height, b.width, b.channels, b.eps = Ct.sizeof(b), B, H, W, C, 1e-5
+        b.x = b.w0 = b.w1 = b.workspace = x.data_ptr()
+        b.y = y.data_ptr()
+        with pytest.raises((ValueError, RuntimeError), match="scale and offset"):
+            _lib.check(L.mzs_resblock_v2(Ct.byref(b), None))
+        b.ln0_scale = b.ln0_offset = b.ln1_scale = b.ln1_offset = x.data_ptr()
+        b.workspace_bytes = 16
+        with pytest.raises((ValueError, RuntimeError), match="workspace too small"):
+            _lib.check(L.mzs_resblock_v2(Ct.byref(b), None))
+        b.w_proj = x.data_ptr()
+        with pytest.raises((ValueError, RuntimeError), match="identity shortcut only"):
+            _lib.check(L.mzs_resblock_v2(Ct.byref(b), None))
+        assert L.mzs_resblock_v2_workspace_bytes(2, 12, 12, 48) == 0
+        assert L.mzs_resblock_v2_workspace_bytes(2, 12, 12, 64) > 2 * 12 * 12 * 64 * 4
+
+
 def test_c_abi_rejects_bad_representation_arguments():
     """Error behaviour of round 4's root-inference entry points (mzs_conv3x3_nhwc, mzs_conv3x3_stride2_nhwc,
     mzs_resblock_v1, mzs_resnet_root_tail): negative status + message, mapped to ValueError / RuntimeError -- never a launch

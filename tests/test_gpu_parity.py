@@ -440,7 +440,13 @@ def _fused_any(case, tiebreak, key, route, policy="muzero", **kw):
 
 
 @pytest.mark.parametrize("A,E,S,B,support", [(5, 12, 30, 90, 10), (2, 8, 50, 70, 20), (7, 24, 80, 33, 10), (2, 24, 20, 40, 10),
-                                             (4, 24, 52, 59, 10), (3, 40, 60, 20, 12), (1, 56, 25, 17, 10)])
+                                             (4, 24, 52, 59, 10), (3, 40, 60, 20, 12), (1, 56, 25, 17, 10),
+                                             # round 5: nine to sixteen actions (all of a node's scores in one lane) ...
+                                             (9, 8, 50, 70, 10), (12, 16, 40, 37, 10), (16, 8, 50, 45, 10), (16, 32, 30, 21, 20),
+                                             # ... and 128 to 255 simulations (FusedCfg::LONG: the nodes' root paths in HBM,
+                                             # up to eight path words per lane), also where HBM paths only buy roots per CU
+                                             (2, 8, 160, 40, 10), (2, 8, 255, 23, 10), (4, 32, 200, 18, 10), (6, 8, 100, 26, 10),
+                                             (10, 8, 100, 19, 10), (3, 8, 128, 33, 12)])
 def test_fused_instance_built_on_demand_matches_oracle(oracle, A, E, S, B, support):
     """Shapes mz_instances.def does not list (5 actions x 12-wide embedding; support_size 20 with F = 41 at CartPole
     widths is listed, 7 actions x 24 at 80 simulations is not ...): mzs_act_mlp refuses, muax_amd/_jit.py compiles ONE
@@ -459,12 +465,41 @@ def test_fused_instance_built_on_demand_matches_oracle(oracle, A, E, S, B, suppo
             pytest.skip("the library already has an instance for this shape")
         raise
     _compare(_oracle(oracle, case, True, key), s, out)
+    if S >= 100:  # the same long search cut at max_depth (re-expansions: the cut reads the path array in HBM)
+        from muax_amd import MuZeroSearch, SearchConfig
+        s.close()
+        s2 = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True, max_depth=9))
+        s2.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"], support, 0.99)
+        out2 = s2.act_mlp(torch.from_numpy(case["obs"]), key, dirichlet_noise=torch.from_numpy(case["noise"]), with_tree=True,
+                          invalid_actions=None if case["invalid"] is None else torch.from_numpy(case["invalid"]),
+                          gumbel=torch.from_numpy(case["gumbel"]))
+        torch.cuda.synchronize()
+        _compare(_oracle(oracle, case, True, key, max_depth=9), s2, out2)
 
 
-@pytest.mark.parametrize("A,E,S,B,policy", [(18, 8, 50, 130, "muzero"), (2, 8, 160, 40, "muzero"), (4, 100, 40, 25, "muzero"),
-                                            (33, 20, 70, 21, "muzero"), (18, 8, 40, 50, "gumbel"), (2, 8, 200, 9, "gumbel")])
+@pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
+@pytest.mark.parametrize("A,E,S,B,maxc", [(12, 8, 50, 40, 16), (16, 8, 30, 25, 5), (2, 8, 160, 30, 16), (4, 8, 200, 12, 3)])
+def test_gumbel_fused_wide_and_long_instances_built_on_demand(oracle, A, E, S, B, maxc, qt):
+    """Gumbel MuZero on the round-5 instances: more than eight actions (sequential halving over up to 16 considered
+    actions, in-lane sums of 16 terms in the canonical butterfly order) and more than 127 simulations (root paths in
+    HBM, root Gumbel noise behind the tree) -- built on demand, every tree array equal to the oracle's."""
+    from muax_amd import MuZeroSearch, SearchConfig, _jit
+    kind = 1 if qt.endswith("mix_value") else 0
+    case = make_case(oracle, 170 + A + S, B, 5, E, A, S, invalid_frac=0.3 if A > 2 else 0.0)
+    key = [23, S]
+    assert _jit.ensure_instance(A, E, case["F"], S)
+    s = MuZeroSearch(B, SearchConfig(A, S, E, policy="gumbel", qtransform=qt, max_num_considered_actions=maxc, tiebreak=False))
+    s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"], 10, 0.99)
+    out = s.act_mlp(torch.from_numpy(case["obs"]), key, gumbel=torch.from_numpy(case["gumbel"]), with_tree=True,
+                    invalid_actions=None if case["invalid"] is None else torch.from_numpy(case["invalid"]))
+    torch.cuda.synchronize()
+    _compare(_gumbel_oracle_act(oracle, case, key, kind, maxc, gumbel=case["gumbel"]), s, out)
+
+
+@pytest.mark.parametrize("A,E,S,B,policy", [(18, 8, 50, 130, "muzero"), (2, 8, 300, 40, "muzero"), (4, 100, 40, 25, "muzero"),
+                                            (33, 20, 70, 21, "muzero"), (18, 8, 40, 50, "gumbel"), (2, 8, 260, 9, "gumbel")])
 def test_generic_one_launch_search_matches_oracle(oracle, A, E, S, B, policy):
-    """What no instance of the fused kernel can serve -- 18 / 33 actions, 160 / 200 simulations, a 100-wide embedding --
+    """What no instance of the fused kernel can serve -- 18 / 33 actions, 260 / 300 simulations, a 100-wide embedding --
     through mzs_act_mlp's generic route (mz_mlp_generic.cuh: the trio with run-time shapes, tree in HBM, one launch for
     all simulations): every tree array, actions, weights, values and depth sums equal to the oracle's, both policies."""
     case = make_case(oracle, 500 + A + E, B, 6, E, A, S, invalid_frac=0.2 if A > 2 else 0.0)
@@ -489,11 +524,11 @@ def test_generic_one_launch_search_matches_oracle(oracle, A, E, S, B, policy):
 
 
 def test_model_act_above_the_fused_kernels_limits_takes_the_generic_route(oracle):
-    """The reference's act() takes any num_simulations (muax/model.py:82-96): 160 simulations on the default trio (no
+    """The reference's act() takes any num_simulations (muax/model.py:82-96): 300 simulations on the default trio (no
     instance possible) go through the library's generic one-launch search -- no step-wise policy adapter, no torch
     modules -- and give the oracle's actions, weights and values for the same key; so does an 18-action trio."""
     import muax_amd as mx
-    for A, S in ((2, 160), (18, 50)):
+    for A, S in ((2, 300), (18, 50)):
         g = torch.Generator().manual_seed(0)
         net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(A, 21, generator=g),
                               mx.nn.Dynamic(8, A, 21, generator=g))

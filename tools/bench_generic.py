@@ -39,7 +39,37 @@ def run(B, obs_dim, E, A, S, force_generic):
     return dt, depth
 
 
+def run_jit(B, obs_dim, E, A, S):
+    """The same shape through an instance built on demand (muax_amd/_jit.py), or None when no instance can exist."""
+    from muax_amd import _jit
+    if _jit.plan(A, E, 21, S) is None or not _jit.ensure_instance(A, E, 21, S):
+        return None
+    return run(B, obs_dim, E, A, S, False) + (_jit.plan(A, E, 21, S),)
+
+
 if __name__ == "__main__":
+    if "--round5" in sys.argv:
+        # round 5: shapes beyond round 4's instance limits (A <= 8, S <= 127) -- generic one-launch search against the
+        # instance now built on demand (A <= 16; 128..255 simulations with the root paths in HBM), per simulation, next
+        # to the metric's own instance (4096 x (2, 8) x 50: the reference for "a listed instance's per-simulation cost")
+        t_ref, _ = run(4096, 4, 8, 2, 50, False)
+        print(f"reference: 4096 roots, A=2, E=8, S=50, listed instance {t_ref * 1e3:.3f} ms = {t_ref / 50 * 1e6:.2f} us/sim")
+        for (B, od, E, A, S) in ((4096, 4, 8, 2, 160), (4096, 4, 8, 2, 255), (4096, 4, 8, 9, 50), (4096, 4, 8, 12, 50),
+                                 (4096, 4, 8, 16, 50), (4096, 8, 32, 4, 200), (4096, 4, 8, 6, 100), (1024, 4, 8, 16, 50),
+                                 (1024, 4, 8, 2, 255)):
+            os.environ["MUAX_AMD_JIT"] = "0"
+            t_g, d = run(B, od, E, A, S, True)
+            os.environ["MUAX_AMD_JIT"] = "1"
+            r = run_jit(B, od, E, A, S)
+            if r is None:
+                print(f"{B} roots, A={A}, E={E}, S={S}: generic {t_g * 1e3:8.3f} ms = {t_g / S * 1e6:6.2f} us/sim | no instance possible")
+                continue
+            t_j, _, pl = r
+            print(f"{B} roots, A={A}, E={E}, S={S} (mean depth {d:.1f}): generic {t_g * 1e3:8.3f} ms = {t_g / S * 1e6:6.2f} us/sim | "
+                  f"on-demand instance (NMAX {pl[1]}, {4 * pl[2]} roots/workgroup, paths in {'HBM' if pl[3] else 'LDS'}) "
+                  f"{t_j * 1e3:8.3f} ms = {t_j / S * 1e6:6.2f} us/sim = x{(t_j / S) / (t_ref / 50) * 4096 / B:.1f} the listed instance's per-root-simulation cost "
+                  f"(generic: x{(t_g / S) / (t_ref / 50) * 4096 / B:.1f})")
+        sys.exit(0)
     for (B, od, E, A, S) in ((4096, 4, 8, 2, 50), (8192, 8, 32, 4, 50)):
         t_f, d = run(B, od, E, A, S, False)
         t_g, _ = run(B, od, E, A, S, True)

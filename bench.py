@@ -143,22 +143,11 @@ def pmc_traffic(workload, field="hbm_bytes_per_launch"):
         return None
 
 
-_SIGNAL_POOL_KEEPALIVE = []
-
-
-def grow_signal_pool(n=2048):
-    """The HIP runtime hands every synchronised launch a completion signal from a pool that grows on demand, and a
-    growth step stalls the host: tools/diag_stall.py shows ONE act of ~50 ms among thousands of 0.118 ms around the
-    1100th synchronised launch of a process (and a 1-3 ms one around the 420th) -- inside the timed region of a
-    200-step run that is the whole measurement.  Recording `n` throwaway events once, before anything is timed, makes
-    the pool grow there instead (2048 events: no step above 1 ms in 4000).  The events stay alive for the process."""
-    if _SIGNAL_POOL_KEEPALIVE:
-        return
-    for _ in range(n):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        _SIGNAL_POOL_KEEPALIVE.append(e)
-    torch.cuda.synchronize()
+def grow_signal_pool():
+    """muax_amd.utils.warm_runtime: the HIP runtime's completion-signal pool grown before anything is timed (a growth
+    step inside a timed region is a 50-70 ms host stall -- the whole measurement of a 200-step run; tools/diag_stall.py)."""
+    from muax_amd.utils import warm_runtime
+    warm_runtime()
 
 
 def fused_run(workload, B, rank, world, dev, steps, warmup, tiebreak, dist=None, backend="nccl", settle_ms=30.0,

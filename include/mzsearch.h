@@ -359,8 +359,8 @@ typedef struct mzs_root_tail_args {
 int mzs_resnet_root_tail(const mzs_root_tail_args *a, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * hk.Conv2D(C, kernel_shape=3, stride=1, padding='SAME', with_bias=False) on NHWC maps with C -> C channels, C = 32 or
- * 64: the convolutions inside the residual blocks of the representation nets at their 21 x 21 / 11 x 11 / 6 x 6 stages
+ * hk.Conv2D(C, kernel_shape=3, stride=1, padding='SAME', with_bias=False) on NHWC maps with C -> C channels, C = 16, 32
+ * or 64: the convolutions inside the residual blocks of the representation nets at their 21 x 21 / 11 x 11 / 6 x 6 stages
  * (muax/nn.py:118-178 inside ResNetRepresentation :291-310 and EZStateEncoder :180-207; root inference,
  * muax/model.py:251-263).  fp32 MFMA implicit GEMM (mz_repr.cuh); any height / width whose rows fit a CU's LDS.
  *   w_packed: the HWIO kernel w[3][3][C][C] re-ordered once by the caller to Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co]
@@ -377,7 +377,8 @@ typedef struct mzs_conv3x3_args {
 int mzs_conv3x3_nhwc(const mzs_conv3x3_args *a, void *stream);
 
 /* The stems of those nets: hk.Conv2D(out, kernel_shape=3, stride=2, padding='SAME', with_bias=False) with (in, out)
- * channels (4, 32) -- raw frame stacks, muax/nn.py:299 / :189 -- or (32, 64) (muax/nn.py:303); output
+ * channels (4, 32) / (4, 16) -- raw frame stacks, muax/nn.py:299 / :189 -- or (32, 64) / (16, 32) (muax/nn.py:303, and
+ * the strided convolutions of the EZ encoder's projection block, :151-178 inside :180-207); output
  * [B, ceil(H / 2), ceil(W / 2), out].  w_packed: Wp[tap][c][g][co][i] = w[tap][16 c + 4 g + i][co] with the 4 frame
  * channels padded to 16 by zero rows (9 * 16 * 32 floats).  in_div != 0: the input is divided by it on the way in (the
  * reference's observations / 255); relu != 0: max(., 0) on the way out. */
@@ -419,7 +420,7 @@ int mzs_resblock_v1(const mzs_resblock_args *a, void *stream);
 int64_t mzs_resblock_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels);
 
 /* A whole ResidualConvBlockV2 (muax/nn.py:151-178: the pre-activation block of the EfficientZero-style encoder,
- * muax/nn.py:180-207) with the identity shortcut, stride 1, C -> C with C = 32 or 64, inference, in three launches:
+ * muax/nn.py:180-207) with the identity shortcut, stride 1, C -> C with C = 16, 32 or 64, inference, in three launches:
  *     y = x + conv_1(relu(LN_1(conv_0(relu(LN_0(x))))))
  * fp64 moments of x; conv_0 normalising x on its way into LDS and leaving the moments of its outputs; conv_1
  * normalising those on the way in and adding x in its epilogue.  Same argument block as mzs_resblock_v1 with

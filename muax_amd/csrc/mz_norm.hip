@@ -128,7 +128,7 @@ int mzs_resblock_v1(const mzs_resblock_args* a, void* stream_) {
 //   K2  conv_1 with relu(LN_1(.)) applied on the way in, the shortcut x added to the outputs in the epilogue.
 // (Seven launches as single calls: moments + apply, convolution, moments + apply, convolution, add.)
 int64_t mzs_resblock_v2_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t channels) {
-  if (batch <= 0 || height <= 0 || width <= 0 || (channels != 32 && channels != 64)) return 0;
+  if (batch <= 0 || height <= 0 || width <= 0 || (channels != 16 && channels != 32 && channels != 64)) return 0;
   const mzr::Geometry g = mzr::geometry(height, width, channels);
   const size_t n1 = (size_t)height * width * channels;
   return (int64_t)((size_t)batch * n1 * sizeof(float)
@@ -144,8 +144,8 @@ int mzs_resblock_v2(const mzs_resblock_args* a, void* stream_) {
     return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: every LayerNorm needs its scale and offset");
   if (a->w_proj || a->proj_scale || a->proj_offset)
     return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v2: identity shortcut only (the projection block is strided: single calls)");
-  if (a->channels != 32 && a->channels != 64)
-    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v2: channels must be 32 or 64 (in == out)");
+  if (a->channels != 16 && a->channels != 32 && a->channels != 64)
+    return mzh::fail_global(MZS_E_UNSUPPORTED, "mzs_resblock_v2: channels must be 16, 32 or 64 (in == out)");
   if (a->y == a->x) return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: y must not alias x");
   if (a->workspace_bytes < mzs_resblock_v2_workspace_bytes(a->batch, a->height, a->width, a->channels))
     return mzh::fail_global(MZS_E_INVALID, "mzs_resblock_v2: workspace too small");

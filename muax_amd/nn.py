@@ -241,14 +241,14 @@ class HkConv2D(nn.Module):
         if not (self.use_hip and self.k == 3 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             return False
         c, co, (h, w) = x.shape[-1], self.out_channels, x.shape[1:3]
-        if self.stride == 1 and c == co and c in (32, 64):
+        if self.stride == 1 and c == co and c in (16, 32, 64):
             # (6 x 6 x 64 on 128 images is 13.6 us here against 10.7 for the library's kernel alone, but inside the EZ
             # encoder the library's side kernels make the same layers 25 us dearer each: every size stays here)
             tiles = (h * w + 15) // 16  # the library's choice of run length (mz_repr_host.h) -> its LDS bytes
-            run = 16 * (14 if tiles > 16 else (8 if tiles > 8 else 4))
+            run = 16 * ((16 if c == 16 else 14) if tiles > 16 else (8 if tiles > 8 else 4))
             if ((run + w - 1) // w + 3) * (w + 2) * (c + 4) * 4 > 160 * 1024:
                 return False
-        elif self.stride == 2 and (c, co) in ((4, 32), (32, 64)):
+        elif self.stride == 2 and (c, co) in ((4, 16), (4, 32), (16, 32), (32, 64)):
             wo = -(-w // 2)
             if (2 * ((64 + wo - 1) // wo) + 3) * ((wo - 1) * 2 + 3) * (max(c, 16) + 4) * 4 > 160 * 1024:
                 return False  # (even the shortest run, 4 tiles, does not fit)

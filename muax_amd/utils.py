@@ -105,3 +105,23 @@ def action2plane(action, shape):
     if isinstance(action, torch.Tensor):
         return action.expand(shape)
     return np.broadcast_to(action, shape)
+
+
+_SIGNAL_POOL_KEEPALIVE = []
+
+
+def warm_runtime(n_events: int = 2048, device=None):
+    """Grow the HIP runtime's completion-signal pool once, ahead of time (no reference counterpart: a property of the
+    ROCm runtime this path runs on).  Every synchronised launch takes a signal from a pool that grows on demand, and a
+    growth step stalls the host: tools/diag_stall.py shows ONE act of 50-70 ms among thousands of 0.118 ms around the
+    1100th synchronised launch of a process (and a 1-3 ms one around the 420th).  Recording `n_events` throwaway events
+    (kept alive for the process) makes the pool grow here instead: no step above 1 ms in 4000 afterwards.  bench.py and
+    the timing tools call it before anything is timed; a latency-sensitive caller of act() may do the same at start-up."""
+    if _SIGNAL_POOL_KEEPALIVE or not torch.cuda.is_available():
+        return
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        for _ in range(n_events):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _SIGNAL_POOL_KEEPALIVE.append(e)
+        torch.cuda.synchronize()

@@ -569,7 +569,7 @@ def test_one_launch_search_in_two_halves_and_through_act():
 
 
 @pytest.mark.parametrize("C,H,W,B", [(64, 21, 21, 9), (64, 11, 11, 16), (64, 6, 6, 5), (32, 21, 21, 7), (32, 11, 11, 3), (32, 6, 6, 130),
-                                     (64, 13, 29, 2), (32, 32, 32, 2), (64, 1, 1, 3)])
+                                     (64, 13, 29, 2), (32, 32, 32, 2), (64, 1, 1, 3), (16, 42, 42, 6), (16, 11, 5, 3), (16, 1, 1, 2)])
 def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
     """mzs_conv3x3_nhwc (the C -> C 3x3 stride-1 convolutions of the representation nets' residual blocks at their 21 x 21
     / 11 x 11 / 6 x 6 stages: muax/nn.py:118-178 inside :180-207, :291-310) against an fp64 evaluation of the same
@@ -593,7 +593,10 @@ def test_representation_conv3x3_against_fp64_and_the_library(C, H, W, B):
 
 @pytest.mark.parametrize("cin,cout,H,W,B,div", [(4, 32, 84, 84, 5, 255.0), (32, 64, 42, 42, 7, None), (4, 32, 96, 96, 2, 255.0),
                                                 (32, 64, 21, 21, 3, None), (4, 32, 13, 29, 4, None), (32, 64, 2, 2, 3, None),
-                                                (4, 32, 1, 1, 2, 255.0)])
+                                                (4, 32, 1, 1, 2, 255.0),
+                                                # round 5: the EZ encoder at embedding_dim 32 (muax/nn.py:189: 4 -> 16; :196: 16 -> 32)
+                                                (4, 16, 84, 84, 5, 255.0), (16, 32, 42, 42, 6, None), (4, 16, 13, 29, 3, None),
+                                                (16, 32, 7, 9, 2, None)])
 def test_stem_conv3x3_stride2_against_fp64_and_the_library(cin, cout, H, W, B, div):
     """mzs_conv3x3_stride2_nhwc (the stems of the representation nets: hk.Conv2D(32 | 64, 3, stride=2, 'SAME', no bias) on
     raw frame stacks / on the 32-channel map, muax/nn.py:189,299,303, with the observations / 255 in front and the relu
@@ -706,7 +709,8 @@ def test_residual_block_in_three_launches_against_fp64(C, H, W, B, proj):
     assert y.shape == x.shape and e_hip <= floor and e_hip <= 2 * e_mod + floor, (e_hip, e_mod, floor)
 
 
-@pytest.mark.parametrize("C,H,W,B", [(32, 42, 42, 3), (64, 21, 21, 5), (64, 11, 11, 9), (64, 6, 6, 128), (32, 13, 29, 2), (64, 10, 10, 130)])
+@pytest.mark.parametrize("C,H,W,B", [(32, 42, 42, 3), (64, 21, 21, 5), (64, 11, 11, 9), (64, 6, 6, 128), (32, 13, 29, 2), (64, 10, 10, 130),
+                                     (16, 42, 42, 5), (16, 9, 14, 3), (16, 6, 6, 20)])
 def test_preactivation_block_in_three_launches_against_fp64(C, H, W, B):
     """mzs_resblock_v2 (ResidualConvBlockV2 with the identity shortcut, muax/nn.py:151-178: the EZ encoder's block,
     :180-207) -- moments of x, conv_0 normalising x on the way in, conv_1 normalising conv_0's outputs on the way in and
@@ -772,7 +776,7 @@ def test_c_abi_rejects_bad_representation_arguments():
     assert L.mzs_conv3x3_nhwc(C.byref(a), None) == _lib.MZS_E_INVALID  # struct_size not set
     a.struct_size, a.batch, a.height, a.width, a.channels = C.sizeof(a), 2, 12, 12, 48
     a.x = a.w_packed = a.y = x.data_ptr()
-    with pytest.raises((ValueError, RuntimeError), match="channels must be 32 or 64"):
+    with pytest.raises((ValueError, RuntimeError), match="channels must be 16, 32 or 64"):
         _lib.check(L.mzs_conv3x3_nhwc(C.byref(a), None))
     a.channels, a.width = 64, 4096
     with pytest.raises((ValueError, RuntimeError), match="too wide"):
@@ -781,7 +785,7 @@ def test_c_abi_rejects_bad_representation_arguments():
     assert L.mzs_conv3x3_stride2_nhwc(C.byref(s), None) == _lib.MZS_E_INVALID
     s.struct_size, s.batch, s.height, s.width, s.in_channels, s.out_channels = C.sizeof(s), 2, 12, 12, 8, 32
     s.x = s.w_packed = s.y = x.data_ptr()
-    with pytest.raises((ValueError, RuntimeError), match=r"\(4, 32\) or \(32, 64\)"):
+    with pytest.raises((ValueError, RuntimeError), match=r"\(16, 32\) or \(32, 64\)"):
         _lib.check(L.mzs_conv3x3_stride2_nhwc(C.byref(s), None))
     b = _lib.MzsResblockArgs()
     assert L.mzs_resblock_v1(C.byref(b), None) == _lib.MZS_E_INVALID

@@ -11,6 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import haiku_style_weights  # noqa: E402
 from muax_amd import MuZeroSearch, SearchConfig  # noqa: E402
+from muax_amd.utils import warm_runtime  # noqa: E402
+
+warm_runtime()  # (the runtime's signal pool grown before anything is timed: tools/diag_stall.py)
 
 
 def run(B, obs_dim, E, A, S, force_generic):

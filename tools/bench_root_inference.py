@@ -10,9 +10,12 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import muax_amd as mx  # noqa: E402
+from muax_amd.utils import warm_runtime  # noqa: E402
+
+warm_runtime()  # (the runtime's signal pool grown before anything is timed: tools/diag_stall.py)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # "resnet_fused": one variant only (for a kernel trace)
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # "resnet_fused" / "ez_fused": one variant only (for a kernel trace)
 for name, make in (("ResNet", lambda g: (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(18, 21, generator=g),
                                          mx.nn.ResNetDynamic(18, 21, generator=g))),
                    ("EZ", lambda g: (mx.nn.EZRepresentation(32, generator=g), mx.nn.EZPrediction(18, 21, 1.0, generator=g),
@@ -20,7 +23,7 @@ for name, make in (("ResNet", lambda g: (mx.nn.ResNetRepresentation(32, generato
     g = torch.Generator().manual_seed(0)
     mods = make(g)
     obs = torch.randint(0, 256, (B, 84, 84, 4), generator=g).float().cuda()
-    if ONLY and name != "ResNet":
+    if ONLY and name != {"resnet_fused": "ResNet", "ez_fused": "EZ"}.get(ONLY, "ResNet"):
         continue
     for fused in ((True,) if ONLY else (False, True)):
         mx.nn.HkLayerNorm.use_hip = fused

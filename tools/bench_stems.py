@@ -7,6 +7,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import muax_amd as mx  # noqa: E402
+from muax_amd.utils import warm_runtime  # noqa: E402
+
+warm_runtime()  # (the runtime's signal pool grown before anything is timed: tools/diag_stall.py)
 
 B = 128
 for cin, cout, H, div in ((4, 32, 84, 255.0), (4, 32, 84, None), (32, 64, 42, None)):

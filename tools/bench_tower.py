@@ -9,6 +9,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import muax_amd as mx  # noqa: E402
+from muax_amd.utils import warm_runtime  # noqa: E402
+
+warm_runtime()  # (the runtime's signal pool grown before anything is timed: tools/diag_stall.py)
 
 g = torch.Generator().manual_seed(0)
 mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(18, 21, generator=g),

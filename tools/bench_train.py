@@ -11,6 +11,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import muax_amd as mx  # noqa: E402
+from muax_amd.utils import warm_runtime  # noqa: E402
+
+warm_runtime()  # (the runtime's signal pool grown before anything is timed: tools/diag_stall.py)
 
 
 def timeit(fn, n=20, warm=3):

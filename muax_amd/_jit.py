@@ -30,7 +30,7 @@ def _ceil_log2(n: int) -> int:
 
 def lds_bytes(A: int, E: int, NMAX: int, WAVES: int, long_paths: bool = False) -> int:
     """FusedCfg::LDS_BYTES of a plain (non-compact) instance, widest record (the Gumbel modes) -- mz_fused.cuh.
-    `long_paths`: FusedCfg::LONG (NMAX > 64) -- root paths in HBM, root Gumbel noise behind the tree."""
+    `long_paths`: FusedCfg::LONG -- root paths in HBM, root Gumbel noise behind the tree."""
     selw = ((2 * A + 3) // 4) * 4
     st0 = selw + 4
     path0 = st0 + 5 * A + (E if E <= 16 else 0)
@@ -60,8 +60,8 @@ def plan(A: int, E: int, F: int, S: int):
         pathw = (NMAX * entry + 31) // 32
         best = None
         for long_paths in (False, True):  # (paths in LDS are the faster record: taken unless HBM paths hold more roots)
-            if long_paths and NMAX <= 64:
-                continue
+            if long_paths and NMAX <= 64 and A <= 8:
+                continue  # (short searches over few actions: the LDS record is small; PH with 16 roots is the COMPACT instance)
             if (pathw + 15) // 16 > (8 if long_paths else 4) or (A > pathw and not long_paths):
                 continue
             for W in (4, 3, 2, 1):

@@ -29,14 +29,19 @@ def run():
     _lib._lib = None
     import bench
     from muax_amd import MuZeroSearch, SearchConfig
-    B, obs_dim, E, A, support, S = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else "cartpole"]
+    name = sys.argv[2] if len(sys.argv) > 2 else "cartpole"
+    if ":" in name:  # "A:E:S:B" -- a shape of the profiling build's own instance list (MZ_PROF_FLAGS=-DMZ_INSTANCES_FILE=...)
+        A, E, S, B = (int(x) for x in name.split(":"))
+        obs_dim, support = 4, 10
+    else:
+        B, obs_dim, E, A, support, S = bench.WORKLOADS[name]
     w = bench.haiku_style_weights(0, obs_dim, E, A, 2 * support + 1)
     g = torch.Generator().manual_seed(1000)
     obs = (torch.rand(B, obs_dim, generator=g) * 2 - 1).cuda()
     noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)).cuda()
     s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True))
     s.set_mlp_weights(w, obs_dim, support)
-    waves = B // 4
+    waves = (B + 3) // 4
     prof = torch.zeros(waves, 16, dtype=torch.int64, device="cuda")
     L = _lib.load()
     L.mzs_debug_profile.argtypes = [C.c_void_p, C.c_void_p]

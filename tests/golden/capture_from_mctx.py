@@ -280,6 +280,41 @@ def capture_rollout(model, params, w, out_dir, pred_on="child", steps=20, S=10):
     print("wrote tests/golden/mctx_rollout_cartpole_s10.npz")
 
 
+def _representation_stages(model, params, x, nn):
+    """One output per stage of the reference's ResNetRepresentation (muax/nn.py:291-310) -- the two stems (after their
+    relu), every residual block, the two average pools -- recorded with haiku's method interceptor while the
+    reference's own transformed function runs, in call order = mctx_fixture.STAGE_NAMES.  Returns None (no stage
+    digests in the file; everything else is still captured) when this haiku has no interceptor or the call order is
+    not the expected 2 stems + 8 blocks + 2 pools."""
+    import haiku as hk
+    import jax
+    calls = []
+
+    def interceptor(next_f, args, kwargs, context):
+        out = next_f(*args, **kwargs)
+        if context.method_name == "__call__":
+            cls = type(context.module).__name__
+            inside_block = "residual_conv_block" in context.module.module_name and cls != "ResidualConvBlockV1"
+            if cls in ("ResidualConvBlockV1", "AvgPool") or (cls == "Conv2D" and not inside_block):
+                calls.append((cls, out))
+        return out
+
+    try:
+        with hk.intercept_methods(interceptor):
+            model.repr_func.apply(params.representation, x)
+    except Exception as e:  # noqa: BLE001
+        print("no per-stage digests (haiku interceptor unavailable):", e)
+        return None
+    kinds = [c for c, _ in calls]
+    want = ["Conv2D", "ResidualConvBlockV1", "ResidualConvBlockV1", "Conv2D"] + ["ResidualConvBlockV1"] * 3 + ["AvgPool"] + \
+           ["ResidualConvBlockV1"] * 3 + ["AvgPool"]
+    if kinds != want:
+        print("no per-stage digests: the representation net's call order is", kinds)
+        return None
+    return [(name, np.asarray(jax.nn.relu(out) if kind == "Conv2D" else out))
+            for name, (kind, out) in zip(fx.STAGE_NAMES, calls)]
+
+
 def capture_resnet(ref, nn, policy_mod, out_dir, seed=0, B=2, A=18, F=21):
     """One capture of the convolutional plugin nets (muax/nn.py:118-148,313-395): root inference on B Atari-shaped
     frames and ONE recurrent_fn call, through the reference's own `_root_inference` / `_recurrent_inference`
@@ -311,6 +346,7 @@ def capture_resnet(ref, nn, policy_mod, out_dir, seed=0, B=2, A=18, F=21):
     key = jax.random.PRNGKey(0)
     x = jnp.asarray(obs, jnp.float32)
     root = model._root_inference(params, key, x)
+    stages = _representation_stages(model, params, x, nn)
     v_lg, p_lg = model.pred_func.apply(params.prediction, root.embedding)
     rec, ns = model._recurrent_inference(params, key, jnp.asarray(action), root.embedding)
     r_lg, ns2 = model.dy_func.apply(params.dynamic, root.embedding, jnp.asarray(action))
@@ -322,7 +358,7 @@ def capture_resnet(ref, nn, policy_mod, out_dir, seed=0, B=2, A=18, F=21):
     fx.save_resnet(path, meta, obs, action,
                    {"embedding": root.embedding, "value_logits": v_lg, "prior_logits": root.prior_logits, "value": root.value},
                    {"reward_logits": r_lg, "next_embedding": ns, "value_logits": v2, "prior_logits": rec.prior_logits,
-                    "reward": rec.reward, "value": rec.value})
+                    "reward": rec.reward, "value": rec.value}, stages)
     print(f"wrote {os.path.relpath(path)}  ({os.path.getsize(path) / 1024:.0f} KB; {len(manifest)} parameter arrays by manifest)")
 
 

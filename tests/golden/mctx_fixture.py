@@ -377,17 +377,86 @@ def resnet_assign(mods, manifest, seed):
 def load_resnet(path=RESNET_PATH):
     z = np.load(path, allow_pickle=False)
     meta = json.loads(str(z["meta"]))
+    stages = None
+    if "stage_names" in z.files:
+        stages = {"names": [str(n) for n in z["stage_names"]], "stats": z["stage_stats"], "samples": z["stage_samples"]}
     return {"meta": meta, "manifest": [tuple(x) for x in meta["manifest"]], "seed": meta["weights_seed"],
-            "obs": z["obs"], "action": z["action"],
+            "obs": z["obs"], "action": z["action"], "stages": stages,
             "root": {k: z["root_" + k] for k in ("embedding", "value_logits", "prior_logits", "value")},
             "rec": {k: z["rec_" + k] for k in ("reward_logits", "next_embedding", "value_logits", "prior_logits", "reward", "value")}}
 
 
-def save_resnet(path, meta, obs, action, root, rec):
+# --- one digest per STAGE of the representation net's root inference (round 5): when a capture exists and the
+# embedding disagrees, the first stage whose digest differs names the layer group (stem / block / pool) at fault --
+# haiku's SAME geometry of a strided stem, a LayerNorm axis, the AvgPool's counting -- instead of "the net".
+STAGE_NAMES = ("stem0", "blocks0[0]", "blocks0[1]", "stem1", "blocks1[0]", "blocks1[1]", "blocks1[2]", "pool0",
+               "blocks2[0]", "blocks2[1]", "blocks2[2]", "pool1")
+STAGE_SAMPLES = 256
+
+
+def stage_digest(x):
+    """(mean, std, max |x|) and a fixed pseudo-random sample of 256 elements of one stage's output [B, H, W, C]."""
+    x = np.asarray(x, np.float32).reshape(-1)
+    idx = np.random.default_rng(x.size).integers(0, x.size, STAGE_SAMPLES)
+    return np.array([x.mean(dtype=np.float64), x.std(dtype=np.float64), np.abs(x).max()], np.float32), x[idx]
+
+
+def resnet_mirror_stages(mx, rep, obs):
+    """The torch mirror's ResNetRepresentation, stage by stage (muax_amd/nn.py; the same calls as its forward()):
+    [(name, tensor)] in STAGE_NAMES' order.  A stem's entry is relu(conv(x)), as the reference applies it
+    (muax/nn.py:299-303)."""
+    import torch
+    out = []
+    with torch.no_grad():
+        x = rep.stem0.scaled(obs.to(torch.float32), 255., relu=True)
+        out.append(x)
+        for b in rep.blocks0:
+            x = b(x)
+            out.append(x)
+        x = rep.stem1.scaled(x, relu=True)
+        out.append(x)
+        for b in rep.blocks1:
+            x = b(x)
+            out.append(x)
+        x = mx.nn.avg_pool_same(x)
+        out.append(x)
+        for b in rep.blocks2:
+            x = b(x)
+            out.append(x)
+        out.append(mx.nn.avg_pool_same(x))
+    assert len(out) == len(STAGE_NAMES)
+    return list(zip(STAGE_NAMES, out))
+
+
+def compare_resnet_stages(case, stages, tol=2e-4):
+    """`stages`: [(name, array)] of the side under test; the capture's digests in case["stages"] (absent in captures
+    written before round 5: nothing to compare).  Messages name the FIRST diverging stage."""
+    want = case.get("stages")
+    if not want:
+        return []
+    if list(want["names"]) != [n for n, _ in stages]:
+        return [f"stages: the capture recorded {list(want['names'])}, this side has {[n for n, _ in stages]}"]
+    for i, (name, arr) in enumerate(stages):
+        stats, sample = stage_digest(arr.detach().cpu().numpy() if hasattr(arr, "detach") else arr)
+        lim = tol * max(1.0, float(want["stats"][i][2]))
+        e_s = float(np.abs(sample.astype(np.float64) - want["samples"][i]).max())
+        e_m = float(np.abs(stats.astype(np.float64) - want["stats"][i]).max())
+        if e_s > lim or e_m > lim:
+            return [f"stage {i} ({name}) is the first to diverge: sample error {e_s:.3g}, (mean, std, max) error {e_m:.3g}, "
+                    f"beyond {lim:.3g}; stages before it agree"]
+    return []
+
+
+def save_resnet(path, meta, obs, action, root, rec, stages=None):
     data = {"meta": np.array(json.dumps(dict(meta, format_version=FORMAT_VERSION), sort_keys=True)),
             "obs": np.asarray(obs, np.uint8), "action": np.asarray(action, np.int32)}
     data.update({"root_" + k: np.asarray(v, np.float32) for k, v in root.items()})
     data.update({"rec_" + k: np.asarray(v, np.float32) for k, v in rec.items()})
+    if stages:  # [(name, array)]
+        digests = [stage_digest(np.asarray(a)) for _, a in stages]
+        data["stage_names"] = np.array([n for n, _ in stages])
+        data["stage_stats"] = np.stack([d[0] for d in digests])
+        data["stage_samples"] = np.stack([d[1] for d in digests])
     np.savez_compressed(path, **data)
 
 
@@ -448,7 +517,8 @@ def synthetic_resnet(mx, path, seed=0, B=1, hw=32, A=6, F=21, c=8, dc=16, device
     resnet_assign(mods, manifest, seed)
     case = {"obs": obs, "action": act}
     root, rec = resnet_mirror_outputs(mx, mods, case, device=device)
+    stages = [(n, t.cpu().numpy()) for n, t in resnet_mirror_stages(mx, mods[0], torch.as_tensor(obs.astype(np.float32), device=device))]
     meta = {"manifest": manifest, "weights_seed": seed, "A": A, "F": F, "support_size": 10, "input_channels": c,
             "dynamic_channels": dc, "route": "synthetic (torch mirror output in the capture format; not a reference output)"}
-    save_resnet(path, meta, obs, act, root, rec)
+    save_resnet(path, meta, obs, act, root, rec, stages)
     return path

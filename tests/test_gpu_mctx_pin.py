@@ -131,6 +131,10 @@ def _check_resnet(mx, case):
     for hip in (False, True):  # the torch mirrors (MIOpen convolutions), then the one-launch HIP recurrent kernel
         root, rec = fx.resnet_mirror_outputs(mx, mods, case, device="cuda", hip=hip)
         msgs += [("hip kernel: " if hip else "torch mirror: ") + m for m in fx.compare_resnet(case, root, rec)]
+    # the representation net stage by stage (HIP convolutions / residual blocks in inference): the first diverging stage
+    import torch
+    obs = torch.as_tensor(case["obs"].astype(np.float32), device="cuda")
+    msgs += ["representation: " + m for m in fx.compare_resnet_stages(case, fx.resnet_mirror_stages(mx, mods[0], obs))]
     assert not msgs, "\n  ".join(msgs)
 
 

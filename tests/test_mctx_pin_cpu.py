@@ -173,6 +173,17 @@ def test_resnet_capture_harness_on_a_synthetic_file(tmp_path):
     assert not fx.compare_resnet(case, root, rec, tol=1e-6)
     rec["next_embedding"] = rec["next_embedding"] + np.float32(1e-2)
     assert any("next_embedding" in m for m in fx.compare_resnet(case, root, rec))
+    # per-stage digests of the representation net (round 5): all twelve agree; a bent parameter in blocks1[1] is named as
+    # the FIRST diverging stage, the stages before it still agree
+    obs = torch.as_tensor(case["obs"].astype(np.float32))
+    assert case["stages"]["names"] == list(fx.STAGE_NAMES)
+    assert not fx.compare_resnet_stages(case, fx.resnet_mirror_stages(mx, mods[0], obs), tol=1e-6)
+    with torch.no_grad():
+        mods[0].blocks1[1].ln_0.offset.add_(0.05)
+    msgs = fx.compare_resnet_stages(case, fx.resnet_mirror_stages(mx, mods[0], obs))
+    assert len(msgs) == 1 and "stage 5 (blocks1[1]) is the first to diverge" in msgs[0], msgs
+    with torch.no_grad():
+        mods[0].blocks1[1].ln_0.offset.sub_(0.05)
     swapped = list(case["manifest"])
     i = next(k for k, e in enumerate(swapped) if e[2] == "scale")
     swapped[i], swapped[i - 1] = swapped[i - 1], swapped[i]  # a LayerNorm scale where a convolution weight belongs

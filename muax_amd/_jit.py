@@ -33,7 +33,7 @@ def lds_bytes(A: int, E: int, NMAX: int, WAVES: int, long_paths: bool = False) -
     `long_paths`: FusedCfg::LONG -- root paths in HBM, root Gumbel noise behind the tree."""
     selw = ((2 * A + 3) // 4) * 4
     st0 = selw + 4
-    path0 = st0 + 5 * A + (E if E <= 16 else 0)
+    path0 = st0 + 5 * A + (E if (E <= 16 and not long_paths) else 0)  # (LONG: embeddings in HBM too)
     entry = 8 if _ceil_log2(NMAX) + max(1, _ceil_log2(A)) <= 8 else 16
     pathw = (NMAX * entry + 31) // 32
     ns = (path0 + (0 if long_paths else pathw)) | 1

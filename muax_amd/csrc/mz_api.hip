@@ -364,7 +364,9 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.global_batch = (uint64_t)c.global_batch; p.root_offset = (uint64_t)c.root_offset;
   p.prof = h->prof;
   p.emb_scratch = nullptr;
-  if (c.embed_dim > 16 && !p.export_tree) {
+  // (embeddings wider than 16 -- and those of every instance with its root paths in HBM, FusedCfg::LONG: long searches,
+  // wide action sets -- live in HBM: the caller's export buffer when a tree is exported, else this scratch)
+  if ((c.embed_dim > 16 || c.num_simulations + 1 > 64 || c.num_actions > 8) && !p.export_tree) {
     if (!h->fused_emb)
       MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_emb),
                            (size_t)c.batch * (c.num_simulations + 1) * c.embed_dim * sizeof(float)));

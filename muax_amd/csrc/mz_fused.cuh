@@ -172,7 +172,9 @@ struct FusedCfg {
   static constexpr int ST0 = HDR0 + HDRW, STW = MODE_ >= 2 ? 5 : 4, ST_LOGIT = 4;
   // embeddings: in the LDS record while 16 roots per workgroup still fit the CU's LDS with them, else in
   // HBM ([root][node][E], one coalesced E*4-byte row per access, L2-resident while the root is active)
-  static constexpr bool EMB_LDS = E_ <= 16;
+  // (LONG instances keep them in HBM whatever their width: the record without the embedding lets twice as many roots
+  // of a 128 .. 255-simulation search share a CU -- 23 -> 15 words per node for CartPole's shape)
+  static constexpr bool EMB_LDS = E_ <= 16 && !LONG;
   static constexpr int EMB0 = PK ? ST0 + 3 * A + 1 : ST0 + STW * A;
   // field offsets inside a record (a: child)
   static constexpr int off_score(int a) { return PK ? SEL0 + 1 + a : SEL0 + 2 * a + 1; }

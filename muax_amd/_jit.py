@@ -60,8 +60,8 @@ def plan(A: int, E: int, F: int, S: int):
         pathw = (NMAX * entry + 31) // 32
         best = None
         for long_paths in (False, True):  # (paths in LDS are the faster record: taken unless HBM paths hold more roots)
-            if long_paths and NMAX <= 64 and A <= 8:
-                continue  # (short searches over few actions: the LDS record is small; PH with 16 roots is the COMPACT instance)
+            if long_paths and NMAX <= 51 and A <= 8:
+                continue  # (short searches over few actions: the LDS record is small and the faster one)
             if (pathw + 15) // 16 > (8 if long_paths else 4) or (A > pathw and not long_paths):
                 continue
             for W in (4, 3, 2, 1):
@@ -94,7 +94,7 @@ def _compile(cc, so, tag, A, E, FS, NMAX, W, LONG, verbose) -> bool:
             return True
         deff = os.path.join(JIT_DIR, f"inst_{tag}.def")
         with open(deff, "w") as f:
-            f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, {'true' if LONG else 'false'})\n")
+            f.write(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, {'2' if LONG else 'false'})\n")
         tmp = so + f".tmp{os.getpid()}"
         cmd = [cc] + _build.FLAGS + _build.UNIT_FLAGS["mz_fused_g0.hip"] + [
             f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",

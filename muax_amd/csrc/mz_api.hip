@@ -363,15 +363,9 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   p.dirichlet_fraction = a->dirichlet_fraction; p.discount = w.discount; p.temperature = a->temperature;
   p.global_batch = (uint64_t)c.global_batch; p.root_offset = (uint64_t)c.root_offset;
   p.prof = h->prof;
-  p.emb_scratch = nullptr;
-  // (embeddings wider than 16 -- and those of every instance with its root paths in HBM, FusedCfg::LONG: long searches,
-  // wide action sets -- live in HBM: the caller's export buffer when a tree is exported, else this scratch)
-  if ((c.embed_dim > 16 || c.num_simulations + 1 > 64 || c.num_actions > 8) && !p.export_tree) {
-    if (!h->fused_emb)
-      MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_emb),
-                           (size_t)c.batch * (c.num_simulations + 1) * c.embed_dim * sizeof(float)));
-    p.emb_scratch = h->fused_emb;
-  }
+  // (embeddings wider than 16 -- and those of every FusedCfg::LONG instance: long searches, wide action sets -- live in
+  // HBM: the caller's export buffer when a tree is exported, else this scratch, allocated when a dispatcher asks for it)
+  p.emb_scratch = p.export_tree ? nullptr : h->fused_emb;
   if (c.policy == 1) {
     // gumbel policy: seq_halving table on the device (once), root Gumbel key = split(key)[1]
     const int rows = c.max_num_considered_actions + 1;
@@ -409,15 +403,21 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       std::string err;
       int rc = groups[gi](mode, c.device, p, stream, A, E, F, N, compact != 0, &err);
-      if (rc >= mz::kNeedPathScratch) {  // first launch of an instance with its root paths in HBM: their array
-        const int words = rc - mz::kNeedPathScratch;
-        if (h->fused_path) MZS_HIP(h, hipFree(h->fused_path));
-        h->fused_path = nullptr;
-        h->fused_path_words = 0;
-        MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_path), (size_t)c.batch * N * words * sizeof(int32_t)));
-        h->fused_path_words = words;
-        p.path_scratch = h->fused_path;
-        p.path_words = words;
+      for (int tries = 0; tries < 2 && (rc == mz::kNeedEmbScratch || rc >= mz::kNeedPathScratch); ++tries) {
+        if (rc == mz::kNeedEmbScratch) {  // first launch (without a tree export) of an instance with its embeddings in HBM
+          MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_emb),
+                               (size_t)c.batch * (c.num_simulations + 1) * c.embed_dim * sizeof(float)));
+          p.emb_scratch = h->fused_emb;
+        } else {  // first launch of an instance with its root paths in HBM: their array
+          const int words = rc - mz::kNeedPathScratch;
+          if (h->fused_path) MZS_HIP(h, hipFree(h->fused_path));
+          h->fused_path = nullptr;
+          h->fused_path_words = 0;
+          MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fused_path), (size_t)c.batch * N * words * sizeof(int32_t)));
+          h->fused_path_words = words;
+          p.path_scratch = h->fused_path;
+          p.path_words = words;
+        }
         rc = groups[gi](mode, c.device, p, stream, A, E, F, N, compact != 0, &err);
       }
       if (rc == mz::kNoFusedInstance) continue;

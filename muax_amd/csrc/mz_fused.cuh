@@ -123,15 +123,18 @@ struct FusedParams {
 // which is known when the simulation starts, so the load runs behind the network pass; written once per node) and the
 // raw value leaves the header where no decision reads it: 16 roots then need < 80 KiB of LDS, TWO workgroups share a
 // CU and every SIMD has two wavefronts whose issue latencies and LDS round trips overlap.
-// LONG (PH_ on anything but a compact instance): long searches / wide action sets.  A node's root path is up to 128 words (255 simulations)
+// LONG (REC_ = 2): long searches / wide action sets.  A node's root path is up to 128 words (255 simulations)
 // -- 256 of them per root cannot live in LDS, and from ~100 simulations on they are most of the record -- so the paths
 // take the compact record's place in HBM (up to eight words per lane of the node's row instead of one), while the
 // launch shape stays the plain one (as many roots per workgroup as the LDS holds records for, any policy); the
 // dispatcher takes such an instance whatever the batch size.
-template <int A_, int E_, int FS_, int NMAX_, int MODE_, int WAVES_ = 4, bool PH_ = false>
+// REC_: 0 the plain record (paths in LDS), 1 (`true` in an instance list) the compact record, 2 LONG
+template <int A_, int E_, int FS_, int NMAX_, int MODE_, int WAVES_ = 4, int REC_ = 0>
 struct FusedCfg {
+  static_assert(REC_ >= 0 && REC_ <= 2, "record kind");
+  static constexpr bool PH_ = REC_ != 0;
   static constexpr bool PH = PH_;
-  static constexpr bool LONG = PH_ && !(WAVES_ == 4 && NMAX_ <= 64 && A_ <= 4);  // (the compact instances: 16 roots, short searches, few actions)
+  static constexpr bool LONG = REC_ == 2;
   static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_;
   static constexpr int A = A_, E = E_, FS = FS_, NMAX = NMAX_, MODE = MODE_;
   static_assert(FS_ == 2 || FS_ == 4, "support logits are handled as one or two packed pairs of lane slots");

@@ -10,6 +10,9 @@ constexpr int kNoFusedInstance = 1;  // dispatcher result: this group has no ins
 // kNeedPathScratch + w: an instance with its root paths in HBM fits, but p.path_scratch is not set or was allocated with
 // fewer than w words per node (p.path_words): allocate [B][S + 1][w] words and call again
 constexpr int kNeedPathScratch = 1000;
+// an instance that keeps its embeddings in HBM fits, no tree export was asked for and p.emb_scratch is not set: allocate
+// [B][S + 1][E] floats and call again
+constexpr int kNeedEmbScratch = 2;
 // mode: FusedCfg::MODE (0 muzero, 1 muzero + tie-break noise, 2 gumbel / parent-and-siblings, 3 gumbel / mix value).
 // Returns MZS_OK after the launch, kNoFusedInstance, or a negative MZS_E_* with *err set.
 // compact: take an instance with the compact tree record (FusedCfg::PH; needs p.path_scratch), else a plain one.

@@ -477,6 +477,32 @@ def test_fused_instance_built_on_demand_matches_oracle(oracle, A, E, S, B, suppo
         _compare(_oracle(oracle, case, True, key, max_depth=9), s2, out2)
 
 
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 63, 77), (2, 8, 127, 40), (2, 8, 200, 21), (4, 32, 100, 19), (12, 8, 50, 33), (2, 8, 50, 64)])
+def test_fused_without_tree_export_long_instances(oracle, A, E, S, B):
+    """act() WITHOUT a tree export on the instances that keep their embeddings (and root paths) in HBM: the search then
+    runs on the handle's own scratch arrays (allocated when the dispatcher asks for them: kNeedEmbScratch /
+    kNeedPathScratch), not on the caller's export buffers -- actions, weights, values and depth sums equal to the
+    oracle's, twice in a row on the same handle (the scratch is reused).  (2, 8, 50) is the plain record, for contrast."""
+    from muax_amd import MuZeroSearch, SearchConfig, _jit
+    case = make_case(oracle, 640 + A + S, B, 6, E, A, S, invalid_frac=0.2 if A > 2 else 0.0)
+    _jit.ensure_instance(A, E, case["F"], S)
+    s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True))
+    s.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"], 10, 0.99)
+    inv = None if case["invalid"] is None else torch.from_numpy(case["invalid"])
+    for key in ([5, S], [6, A]):
+        out = s.act_mlp(torch.from_numpy(case["obs"]), key, dirichlet_noise=torch.from_numpy(case["noise"]), invalid_actions=inv,
+                        gumbel=torch.from_numpy(case["gumbel"]))
+        torch.cuda.synchronize()
+        ref = _oracle(oracle, case, True, key)
+        assert out.search_tree is None
+        assert np.array_equal(ref["action"], out.action.cpu().numpy())
+        assert np.array_equal(ref["action_weights"], out.action_weights.cpu().numpy())
+        assert np.array_equal(ref["root_value"], s.root_value.cpu().numpy())
+        assert np.array_equal(ref["depth_sum"], s.depth_sum.cpu().numpy().astype(np.int64))
+        assert np.array_equal(ref["tree"].node_values[:, 0], s.search_value.cpu().numpy())
+    s.close()
+
+
 @pytest.mark.parametrize("qt", ["qtransform_completed_by_mix_value", "qtransform_by_parent_and_siblings"])
 @pytest.mark.parametrize("A,E,S,B,maxc", [(12, 8, 50, 40, 16), (16, 8, 30, 25, 5), (2, 8, 160, 30, 16), (4, 8, 200, 12, 3)])
 def test_gumbel_fused_wide_and_long_instances_built_on_demand(oracle, A, E, S, B, maxc, qt):

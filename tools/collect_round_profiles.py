@@ -69,6 +69,10 @@ if os.path.exists(os.path.join(R, "generic.txt")):  # round 4: default-trio shap
     write("generic_route.txt", rd("generic.txt"),
           f"# {tag} -- act() of the default MLP trio: tuned fused instance vs the generic one-launch search (mz_mlp_generic.cuh),\n"
           f"# and shapes only the generic route serves (tools/bench_generic.py)\n\n")
+if os.path.exists(os.path.join(R, "bench_long.txt")):
+    with open(os.path.join(P, f"{tag}_generic_route.txt"), "a") as f:
+        f.write("\n## long searches / wide action sets through mzs_act_mlp at several batch sizes: median ms per act (tools/bench_long.py);\n"
+                "## plan = (support slots, tree size, wavefronts per workgroup, LONG record)\n" + rd("bench_long.txt"))
 if os.path.exists(os.path.join(R, "bench_2ranks_1gpu.json")):
     with open(os.path.join(P, f"{tag}_bench_2ranks_1gpu.json"), "w") as f:
         f.write(open(os.path.join(R, "bench_2ranks_1gpu.json")).read())

@@ -11,7 +11,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "bin", "libmzsearch_prof.so")
+# MZ_PROF_HEADS=1 (build AND run): slots 3..9 time the pieces of "heads after the tower" instead of the passes
+HEADS = bool(os.environ.get("MZ_PROF_HEADS"))
+LIB = os.path.join(ROOT, "tools", "bin", "libmzsearch_prof_heads.so" if HEADS else "libmzsearch_prof.so")
 PHASES = ["LDS init + state load", "reward head (single: up front; pair half 0: front convs + one pixel per pass)", "stem", "conv pass A (projection + conv_0)",
           "moments (both passes)", "message stores + post (both)", "wait for the partner (both)",
           "normalise + boundary + store A", "conv pass B (conv_1)", "normalise + boundary + residual + store B",
@@ -20,9 +22,16 @@ PHASES = ["LDS init + state load", "reward head (single: up front; pair half 0: 
           "half 0 / single: post the next selection", "recurrent_fn passes (sum)"]
 
 
+if HEADS:
+    PHASES[3:10] = ["heads: reward head's tail (partial sums -> vector -> logits -> decode)",
+                    "heads: the partner's 20 pixels received and normalised", "-",
+                    "heads: first 1x1 convolutions (64 -> 16, both heads)", "heads: value head's second 1x1 convolution",
+                    "heads: flatten -> Linear(576 -> 16), both heads", "heads: last layers + value decode"]
+
+
 def build():
     from muax_amd import _build
-    print(_build.build(extra_flags=["-DMZ_PROFILE"], out=LIB))
+    print(_build.build(extra_flags=["-DMZ_PROFILE"] + (["-DMZ_PROF_HEADS"] if HEADS else []), out=LIB))
 
 
 def act_times(mx, np, torch, B, S, deep):

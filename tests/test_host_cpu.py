@@ -433,3 +433,38 @@ def test_bench_refuses_to_run_without_the_devices_it_was_asked_for():
                              env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "{" not in out.stdout
         assert "ROCm" in out.stderr
+
+
+def test_jit_planner_agrees_with_the_kernels_own_limits(tmp_path):
+    """muax_amd/_jit.py::plan restates FusedCfg's LDS arithmetic in Python; a disagreement would make an on-demand build
+    fail its static_asserts on the user's machine (act() would then fall to the generic route: silent, 5x slower).  The
+    plan table's invariants, then hipcc (it cross-compiles without a GPU) on boundary shapes of both record kinds: the
+    widest action set on the plain record, the longest search, a LONG instance that just fits four roots, the E = 32 one."""
+    import subprocess
+    from muax_amd import _jit
+    for A in (1, 2, 4, 8, 9, 12, 16):
+        for S in (1, 50, 63, 100, 127, 128, 200, 255):
+            for E in (8, 32):
+                pl = _jit.plan(A, E, 21, S)
+                if pl is None:
+                    continue
+                FS, NMAX, W, LONG = pl
+                assert FS == 2 and NMAX >= S + 1 and 1 <= W <= 4 and _jit.lds_bytes(A, E, NMAX, W, LONG) <= 160 * 1024
+                assert LONG or NMAX <= 128  # beyond 127 simulations the root paths cannot live in LDS
+    assert _jit.plan(17, 8, 21, 50) is None and _jit.plan(2, 8, 21, 256) is None and _jit.plan(2, 8, 65, 50) is None
+    assert _jit.plan(2, 8, 21, 255) == (2, 256, 2, True) and _jit.plan(2, 8, 41, 50)[0] == 4
+    try:
+        cc = _build.hipcc()
+    except RuntimeError:
+        pytest.skip("no hipcc")
+    procs = []
+    for k, (A, E, S) in enumerate([(16, 8, 63), (2, 8, 255), (6, 8, 160), (4, 32, 200)]):
+        FS, NMAX, W, LONG = _jit.plan(A, E, 21, S)
+        deff = tmp_path / f"inst{k}.def"
+        deff.write_text(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, {'2' if LONG else 'false'})\n")
+        cmd = [cc] + _build.FLAGS + [f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
+                                     os.path.join(_build.CSRC, "mz_fused_jit.hip"), "-o", str(tmp_path / f"inst{k}.so")]
+        procs.append(((A, E, S), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for shape, p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, (shape, err[-1500:])

@@ -1380,12 +1380,16 @@ __global__ __launch_bounds__(C::THREADS, (C::PH && !C::LONG) ? 2 : 1) void mz_ac
           // word (ec * ENTRY_BITS) / 32 of the parent's path sits in that lane (and slot) of this row's ppw, loaded
           // before the network pass: a cross-lane fetch, not a second LDS read behind the expansion's stores
           const int widx = (ec * C::ENTRY_BITS) >> 5;
-          int pword = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + (widx & 15)), ppw[0]);
+          // the entries of chunk c lie in ONE of the row's path registers (16 entries are 4 or 8 words; a register slot is
+          // 16 words): picked with a wave-uniform select, then ONE cross-lane fetch -- round 5: a fetch per slot and a
+          // per-lane select cost a 255-simulation instance (eight slots) 1700 cycles per simulation in this phase.  (The
+          // lanes at and past the leaf, whose clamped entry 0 sits in slot 0, fetch a word they never use: their (pn, pa)
+          // are overridden below.)
+          const int slot_c = ((16 * c * C::ENTRY_BITS) >> 5) >> 4;
+          int psrc = ppw[0];
 #pragma unroll
-          for (int t = 1; t < C::PATHS; ++t) {
-            const int o = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + (widx & 15)), ppw[t]);
-            pword = (widx >> 4) == t ? o : pword;
-          }
+          for (int t = 1; t < C::PATHS; ++t) psrc = (slot_c == t) ? ppw[t] : psrc;
+          const int pword = __builtin_amdgcn_ds_bpermute(4 * ((lane & ~15) + (widx & 15)), psrc);
           const int ent = (pword >> ((ec * C::ENTRY_BITS) & 31)) & ((1 << C::ENTRY_BITS) - 1);
           pn = ent & ((1 << C::ENTRY_ACT_SHIFT) - 1);
           pa = ent >> C::ENTRY_ACT_SHIFT;

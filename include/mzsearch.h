@@ -440,7 +440,16 @@ int64_t mzs_resblock_v2_workspace_bytes(int32_t batch, int32_t height, int32_t w
  * built-in ones.  `jit_abi` must equal mzs_fused_jit_abi() (same kernel-argument layout). */
 int mzs_register_fused_dispatch(void *dispatch, int32_t jit_abi);
 int mzs_fused_jit_abi(void);
-/* Shapes the fused kernel cannot be instantiated for at all (more than 8 actions, more than 127 simulations, embeddings
+/* The same for the training step (round 5): mzs_mlp_loss_grad carries mz_train_kernel for a list of (num_actions,
+ * embedding_dim, 2 support_size + 1) triples and returns MZS_E_UNSUPPORTED for others, although the reference's
+ * update() takes whatever widths its nets have (muax/model.py:181-201).  muax_amd/csrc/mz_train_jit.hip compiled for
+ * the missing triple gives a side library whose `mzs_jit_train_launch` is passed here together with its
+ * `mzs_jit_train_shape` values and the value of its `mzs_jit_train_abi` (must equal mzs_train_jit_abi(): same argument
+ * layout); later
+ * mzs_mlp_loss_grad calls of that triple take it. */
+int mzs_register_train_dispatch(void *launch, int32_t num_actions, int32_t embed_dim, int32_t full_support_size, int32_t jit_abi);
+int mzs_train_jit_abi(void);
+/* Shapes the fused kernel cannot be instantiated for at all (more than 16 actions, more than 255 simulations, embeddings
  * wider than 64): allow != 0 lets mzs_act_mlp / mzs_act_mlp_host serve them through the generic route instead of
  * returning MZS_E_UNSUPPORTED -- the trio with run-time shapes (num_actions <= 64, support_size 8..31), tree in HBM with
  * cached decisions, ONE launch for all simulations plus root / select / finish launches (mz_mlp_generic.cuh).  Same

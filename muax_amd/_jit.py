@@ -22,6 +22,7 @@ JIT_DIR = os.path.join(_build.LIB_DIR, "jit")
 _SOURCES = ["mz_fused_jit.hip", "mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh"]
 _loaded = {}   # shape -> CDLL (kept alive: the library calls into it)
 _failed = set()
+_TRAIN_SOURCES = ["mz_train_jit.hip", "mz_train.cuh", "mz_spec.cuh"]
 
 
 def _ceil_log2(n: int) -> int:
@@ -147,5 +148,70 @@ def ensure_instance(A: int, E: int, F: int, S: int, verbose: bool = False) -> bo
     side.mzs_jit_dispatch.restype = C.c_void_p
     side.mzs_jit_abi.restype = C.c_int
     _lib.check(L.mzs_register_fused_dispatch(C.c_void_p(side.mzs_jit_dispatch()), side.mzs_jit_abi()))
+    _loaded[shape] = side
+    return True
+
+
+def _train_hash() -> str:
+    h = hashlib.sha256()
+    for f in _TRAIN_SOURCES + [_build._ABI]:
+        with open(os.path.join(_build.CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update("\0".join(_build.FLAGS).encode())
+    return h.hexdigest()[:12]
+
+
+def ensure_train_instance(A: int, E: int, F: int, verbose: bool = False) -> bool:
+    """Make sure mzs_mlp_loss_grad can serve (num_actions, embedding_dim, F = 2 support_size + 1): True when an on-demand
+    instance of the fused training-step kernel (muax_amd/csrc/mz_train_jit.hip) is registered -- built now (one
+    translation unit, cached as muax_amd/lib/jit/mztrain_<shape>-<source hash>.so) or earlier --, False when the shape is
+    outside the kernel's limits (more than 16 actions, embeddings wider than 64, F outside 17..63), there is no compiler,
+    the build fails, or MUAX_AMD_JIT=0.  Round 5: a model whose act() runs on an on-demand instance keeps the fused
+    update() too (the reference's update() takes any widths, muax/model.py:181-201)."""
+    if os.environ.get("MUAX_AMD_JIT", "1") == "0":
+        return False
+    if not (1 <= A <= 16 and 1 <= E <= 64 and 17 <= F <= 63):
+        return False
+    shape = ("train", A, E, F)
+    if shape in _loaded:
+        return True
+    if shape in _failed:
+        return False
+    try:
+        cc = _build.hipcc()
+    except RuntimeError:
+        return False
+    so = os.path.join(JIT_DIR, f"mztrain_a{A}_e{E}_f{F}-{_train_hash()}.so")
+    try:
+        os.makedirs(JIT_DIR, exist_ok=True)
+        if not os.path.exists(so):
+            import fcntl
+            with open(os.path.join(JIT_DIR, ".jit.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)  # ranks that miss the same shape build it once
+                if not os.path.exists(so):
+                    tmp = so + f".tmp{os.getpid()}"
+                    cmd = [cc] + _build.FLAGS + [f"-DMZ_TRAIN_A={A}", f"-DMZ_TRAIN_E={E}", f"-DMZ_TRAIN_F={F}", "-shared",
+                                                 os.path.join(_build.CSRC, "mz_train_jit.hip"), "-o", tmp]
+                    if verbose:
+                        print(" ".join(cmd))
+                    try:
+                        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if not verbose else None,
+                                              stderr=subprocess.DEVNULL if not verbose else None)
+                        os.replace(tmp, so)
+                    except subprocess.CalledProcessError:
+                        _failed.add(shape)
+                        return False
+                    finally:
+                        if os.path.exists(tmp):
+                            os.remove(tmp)
+    except OSError:
+        _failed.add(shape)
+        return False
+    from . import _lib
+    L = _lib.load()
+    side = C.CDLL(so)
+    side.mzs_jit_train_abi.restype = C.c_int
+    fn = C.cast(side.mzs_jit_train_launch, C.c_void_p)
+    _lib.check(L.mzs_register_train_dispatch(fn, A, E, F, side.mzs_jit_train_abi()))
     _loaded[shape] = side
     return True

@@ -29,6 +29,13 @@ using mzh::g_create_error;
 // fused-kernel instances built on demand and registered at run time (mzs_register_fused_dispatch; muax_amd/_jit.py)
 std::mutex g_jit_mutex;
 std::vector<mz::FusedDispatch> g_jit_dispatch;
+// training-step instances built on demand (mz_train_jit.hip): launcher of one (A, E, F = 2 support + 1) each
+using JitTrainLaunch = int (*)(const void* train_params, void* stream, char* err, int errlen);
+struct JitTrain {
+  int A, E, F;
+  JitTrainLaunch launch;
+};
+std::vector<JitTrain> g_jit_train;
 
 // ---- host-side JAX threefry (key bookkeeping only: 3 blocks per simulation) ----
 inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -178,6 +185,18 @@ extern "C" {
 
 int mzs_abi_version(void) { return MZS_ABI_VERSION; }
 int mzs_fused_jit_abi(void) { return MZS_ABI_VERSION * 1000 + (int)(sizeof(mz::FusedParams) % 1000); }
+int mzs_train_jit_abi(void) { return MZS_ABI_VERSION * 1000 + (int)(sizeof(mz::TrainParams) % 1000); }
+
+int mzs_register_train_dispatch(void* launch, int32_t num_actions, int32_t embed_dim, int32_t full_support, int32_t jit_abi) {
+  if (!launch) return fail(nullptr, MZS_E_INVALID, "mzs_register_train_dispatch: null");
+  if (jit_abi != mzs_train_jit_abi())
+    return fail(nullptr, MZS_E_INVALID, "mzs_register_train_dispatch: the side library was built from other sources (ABI)");
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  for (const JitTrain& t : g_jit_train)
+    if (t.A == num_actions && t.E == embed_dim && t.F == full_support) return MZS_OK;
+  g_jit_train.push_back({num_actions, embed_dim, full_support, reinterpret_cast<JitTrainLaunch>(launch)});
+  return MZS_OK;
+}
 
 const char* mzs_last_error(const mzs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -800,6 +819,19 @@ int mzs_mlp_loss_grad(const mzs_mlp_weights* w, const mzs_train_args* a, void* s
   if (A == 2 && E == 32 && F == 21) return launch_train<mz::TrainCfg<2, 32, 21>>(p, stream);
   if (A == 2 && E == 8 && F == 31) return launch_train<mz::TrainCfg<2, 8, 31>>(p, stream);  // support_size 15, 20
   if (A == 2 && E == 8 && F == 41) return launch_train<mz::TrainCfg<2, 8, 41>>(p, stream);
+  {
+    JitTrainLaunch fn = nullptr;  // an instance built on demand (mzs_register_train_dispatch; muax_amd/_jit.py)
+    {
+      std::lock_guard<std::mutex> lock(g_jit_mutex);
+      for (const JitTrain& t : g_jit_train)
+        if (t.A == A && t.E == E && t.F == F) fn = t.launch;
+    }
+    if (fn) {
+      char msg[256] = "";
+      const int rc = fn(&p, stream_, msg, (int)sizeof msg);
+      return rc == MZS_OK ? MZS_OK : fail(nullptr, rc, "mzs_mlp_loss_grad (on-demand instance): %s", msg);
+    }
+  }
   return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: no kernel instance for this (A, E, F)");
 }
 

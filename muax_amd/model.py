@@ -528,7 +528,16 @@ class MuZero:
             try:
                 if self._fused_train is None:
                     self._fused_train = mz_loss.FusedLossGrad(self)
-                loss, flat = self._fused_train(batch, divide_by_length=kwargs.get("divide_by_length", False))
+                try:
+                    loss, flat = self._fused_train(batch, divide_by_length=kwargs.get("divide_by_length", False))
+                except ValueError as e:
+                    # a shape of the default trio the library lists no training instance for: build one on demand
+                    # (muax_amd/_jit.py::ensure_train_instance, once per shape, cached on disk) and call again
+                    from . import _jit
+                    ft = self._fused_train
+                    if "no kernel instance" not in str(e) or not _jit.ensure_train_instance(ft.A, ft.E, 2 * ft.S + 1):
+                        raise
+                    loss, flat = ft(batch, divide_by_length=kwargs.get("divide_by_length", False))
                 if dp_mean:
                     allreduce_mean_flat([flat])
                 for p, g in zip(self._fused_train.params, self._fused_train.views):

@@ -105,6 +105,39 @@ def test_fused_loss_and_gradients_other_support_sizes(support):
         assert np.abs(gh - gd).max() <= 2e-4 * max(np.abs(gd).max(), 1e-6)
 
 
+@pytest.mark.parametrize("A,E,obs_dim,support,B,L", [(3, 16, 5, 12, 40, 4), (5, 12, 6, 10, 33, 3), (12, 8, 4, 10, 24, 3),
+                                                     (2, 24, 8, 10, 19, 2), (7, 40, 8, 15, 16, 2)])
+def test_fused_training_instance_built_on_demand(A, E, obs_dim, support, B, L):
+    """Shapes of the default trio mzs_mlp_loss_grad lists no instance for (round 5: act() serves them through on-demand
+    instances of the search kernel; the training step follows): the first call returns "no kernel instance",
+    muax_amd/_jit.py::ensure_train_instance compiles mz_train_jit.hip for the triple with this box's hipcc and registers it,
+    and the same call then gives loss and gradients that agree with fp64 autograd to the tolerance of the listed
+    instances; MuZero.update() takes that route by itself and steps like the torch route."""
+    from muax_amd import _jit
+    m, b = _model(A, E, obs_dim, seed=A + E, support=support), _batch(B, L, A, obs_dim, seed=B)
+    fused = mx.loss.FusedLossGrad(m)
+    if ("train", A, E, 2 * support + 1) not in _jit._loaded:
+        with pytest.raises(ValueError, match="no kernel instance"):
+            fused(b)
+    assert _jit.ensure_train_instance(A, E, 2 * support + 1)
+    loss, flat = fused(b)
+    loss, views = float(loss.item()), [v.detach().cpu().double().numpy() for v in fused.views]
+    l64, g64 = _autograd(m, b, torch.float64, "cpu")
+    assert abs(loss - l64) <= 1e-5 * abs(l64), (loss, l64)
+    from muax_amd._lib import MLP_WEIGHT_NAMES
+    for n, gh, gd in zip(MLP_WEIGHT_NAMES, views, g64):
+        assert gh.shape == gd.shape and np.abs(gh - gd).max() <= 2e-4 * max(np.abs(gd).max(), 1e-6), n
+    loss2, flat2 = fused(b)
+    assert float(loss2.item()) == loss and torch.equal(flat2, flat)
+    out = {}
+    for backend in ("auto", "torch"):
+        m2 = _model(A, E, obs_dim, seed=A + E, support=support)
+        losses = [m2.update(b, backend=backend)["loss"] for _ in range(10)]
+        out[backend] = losses
+        assert (m2._fused_train is not None) == (backend == "auto")
+    assert np.allclose(out["auto"], out["torch"], rtol=5e-4)
+
+
 def test_update_hip_and_torch_routes_take_the_same_step():
     b = _batch(256, 6, 2, 4, seed=3)
     out = {}

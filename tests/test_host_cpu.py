@@ -465,6 +465,17 @@ def test_jit_planner_agrees_with_the_kernels_own_limits(tmp_path):
         cmd = [cc] + _build.FLAGS + [f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
                                      os.path.join(_build.CSRC, "mz_fused_jit.hip"), "-o", str(tmp_path / f"inst{k}.so")]
         procs.append(((A, E, S), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    # ... and one on-demand instance of the training-step kernel (mz_train_jit.hip), with the entry points _jit binds
+    cmd = [cc] + _build.FLAGS + ["-DMZ_TRAIN_A=5", "-DMZ_TRAIN_E=12", "-DMZ_TRAIN_F=25", "-shared",
+                                 os.path.join(_build.CSRC, "mz_train_jit.hip"), "-o", str(tmp_path / "train.so")]
+    procs.append((("train", 5, 12, 25), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     for shape, p in procs:
         _, err = p.communicate(timeout=600)
         assert p.returncode == 0, (shape, err[-1500:])
+    side = ctypes.CDLL(str(tmp_path / "train.so"))
+    a, e, f = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    side.mzs_jit_train_shape(ctypes.byref(a), ctypes.byref(e), ctypes.byref(f))
+    assert (a.value, e.value, f.value) == (5, 12, 25) and side.mzs_jit_train_launch
+    L = ctypes.CDLL(_build.LIB_PATH)
+    assert side.mzs_jit_train_abi() == L.mzs_train_jit_abi()
+    assert not _jit.ensure_train_instance(17, 8, 21) and not _jit.ensure_train_instance(2, 8, 65)

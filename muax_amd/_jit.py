@@ -51,8 +51,8 @@ def plan(A: int, E: int, F: int, S: int):
     hold more roots -- in HBM (FusedCfg::LONG)."""
     if not (1 <= A <= 16 and 17 <= F <= 63 and 1 <= S <= 255):
         return None
-    if E < 1 or E > 64 or (E > 16 and E % 8):
-        return None
+    if E < 1 or E > 64:  # (round 5: any width up to 64; widths above 16 that are no multiple of 8 take the packed-fma
+        return None      # first layers instead of the eight-input v_fmac_f32_dpp blocks)
     FS = 2 if F <= 32 else 4
     for NMAX in (51, 64, 101, 128, 161, 201, 256):
         if S + 1 > NMAX:

@@ -145,7 +145,7 @@ struct FusedCfg {
   static constexpr int ES = (E + 15) / 16;
   // first layers over a long embedding: two v_fmac_f32_dpp chains per input instead of broadcast move + packed fma
   // (under register pressure the compiler funnels every broadcast through one temporary and pads each term)
-  static constexpr bool L1_DPP = E_ > 16;
+  static constexpr bool L1_DPP = E_ > 16 && E_ % 8 == 0;  // (eight inputs per asm statement; other widths take the packed-fma chains)
   // ... and the second layers as blocks of v_fmac_f32_dpp chains (two logit slots, two state slots, one policy slot)
   static constexpr bool L2_BLOCK = L1_DPP && FS_ == 2 && (E_ + 15) / 16 == 2 && A_ <= 16;
   // ---- node record in LDS (32-bit words, 16-byte aligned) ----

@@ -446,7 +446,9 @@ def _fused_any(case, tiebreak, key, route, policy="muzero", **kw):
                                              # ... and 128 to 255 simulations (FusedCfg::LONG: the nodes' root paths in HBM,
                                              # up to eight path words per lane), also where HBM paths only buy roots per CU
                                              (2, 8, 160, 40, 10), (2, 8, 255, 23, 10), (4, 32, 200, 18, 10), (6, 8, 100, 26, 10),
-                                             (10, 8, 100, 19, 10), (3, 8, 128, 33, 12)])
+                                             (10, 8, 100, 19, 10), (3, 8, 128, 33, 12),
+                                             # embeddings above 16 that are no multiple of 8 (packed-fma first layers)
+                                             (4, 20, 40, 31, 10), (2, 50, 30, 17, 10), (3, 17, 50, 29, 12), (5, 33, 100, 12, 10)])
 def test_fused_instance_built_on_demand_matches_oracle(oracle, A, E, S, B, support):
     """Shapes mz_instances.def does not list (5 actions x 12-wide embedding; support_size 20 with F = 41 at CartPole
     widths is listed, 7 actions x 24 at 80 simulations is not ...): mzs_act_mlp refuses, muax_amd/_jit.py compiles ONE

@@ -22,7 +22,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2025
 rng = np.random.default_rng(seed)
 # (A, E, obs_dim, largest S of the instance): wide action sets, long searches, both at once where an instance exists
 shapes = [(9, 8, 4, 50), (12, 8, 5, 50), (16, 8, 4, 50), (13, 16, 6, 63), (16, 32, 8, 50), (10, 8, 4, 100),
-          (2, 8, 4, 160), (2, 8, 4, 255), (4, 32, 8, 200), (6, 8, 6, 160), (3, 8, 4, 128), (4, 8, 5, 200)]
+          (2, 8, 4, 160), (2, 8, 4, 255), (4, 32, 8, 200), (6, 8, 6, 160), (3, 8, 4, 128), (4, 8, 5, 200),
+          (4, 20, 6, 50), (3, 17, 5, 100), (2, 50, 8, 40)]  # (embeddings above 16 that are no multiple of 8)
 bad = total = 0
 for c in range(n):
     A, E, obs_dim, smax = shapes[rng.integers(len(shapes))]

@@ -16,7 +16,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libmzsearch.so")
 _ABI = os.path.join("..", "..", "include", "mzsearch.h")
-_FUSED = ["mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_instances.def", _ABI]
+_FUSED = ["mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_instances.def", "mz_host.h", _ABI]
 # translation unit -> the headers it is rebuilt for
 UNITS = {
     "mz_api.hip": ["mz_host.h", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_step.cuh", "mz_step_jump.cuh",

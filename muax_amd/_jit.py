@@ -19,7 +19,7 @@ import subprocess
 from . import _build
 
 JIT_DIR = os.path.join(_build.LIB_DIR, "jit")
-_SOURCES = ["mz_fused_jit.hip", "mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh"]
+_SOURCES = ["mz_fused_jit.hip", "mz_fused_group.inc", "mz_fused_launch.h", "mz_fused.cuh", "mz_spec.cuh", "mz_host.h"]
 _loaded = {}   # shape -> CDLL (kept alive: the library calls into it)
 _failed = set()
 _TRAIN_SOURCES = ["mz_train_jit.hip", "mz_train.cuh", "mz_spec.cuh"]

@@ -173,7 +173,13 @@ static int launch_train(const mz::TrainParams& p, hipStream_t stream) {
   const size_t lds = sizeof(float) * ((size_t)C::WEIGHT_WORDS + (size_t)p.L * C::CK_WORDS_PER_STEP);
   if (lds > 160 * 1024) return fail(nullptr, MZS_E_UNSUPPORTED, "mzs_mlp_loss_grad: unroll_steps too large for the LDS");
   auto kern = mz::mz_train_kernel<C>;
-  MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static mzh::LdsGrant granted;  // (per device and instance: the attribute call is not free, update() runs every step)
+  int dev = 0;
+  MZS_HIP(nullptr, hipGetDevice(&dev));
+  if (!granted.covers(dev, lds)) {
+    MZS_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted.note(dev, lds);
+  }
   hipLaunchKernelGGL(kern, dim3(p.waves / 4), dim3(256), lds, stream, p);
   MZS_HIP(nullptr, hipGetLastError());
   hipLaunchKernelGGL(mz::mz_train_reduce_kernel, dim3((p.off[18] + 31) / 32), dim3(256), 0, stream, p);

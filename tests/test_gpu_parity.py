@@ -556,7 +556,9 @@ def test_model_act_above_the_fused_kernels_limits_takes_the_generic_route(oracle
     instance possible) go through the library's generic one-launch search -- no step-wise policy adapter, no torch
     modules -- and give the oracle's actions, weights and values for the same key; so does an 18-action trio."""
     import muax_amd as mx
-    for A, S in ((2, 300), (18, 50)):
+    # ((2, 127) / (2, 200) / (12, 50): LONG instances -- listed, and built on demand -- through the NumPy entry point, i.e.
+    # without a tree export, on the handle's own path / embedding scratch)
+    for A, S in ((2, 300), (18, 50), (2, 127), (2, 200), (12, 50)):
         g = torch.Generator().manual_seed(0)
         net = mx.nn.MZNetwork(mx.nn.Representation(8, generator=g), mx.nn.Prediction(A, 21, generator=g),
                               mx.nn.Dynamic(8, A, 21, generator=g))

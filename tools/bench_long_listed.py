@@ -1,5 +1,7 @@
+"""Per-act medians (ms) of the long-search shapes that have LISTED instances, at 64 .. 4096 roots.  Run once with the product
+library and once with MUAX_AMD_LIB=tools/bin/libmzsearch_r04inst.so (a variant library built from round 4's instance list:
+plain records) to compare the LONG instances with the lines they replaced (profiles/r05_generic_route.txt)."""
 import os, sys, time, torch
-"""(also: the listed LONG instances against a variant library built from round 4's instance list: MUAX_AMD_LIB=tools/bin/libmzsearch_r04inst.so)"""
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from bench import haiku_style_weights
 from muax_amd import MuZeroSearch, SearchConfig

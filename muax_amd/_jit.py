@@ -61,8 +61,7 @@ def plan(A: int, E: int, F: int, S: int):
         pathw = (NMAX * entry + 31) // 32
         best = None
         for long_paths in (False, True):  # (paths in LDS are the faster record: taken unless HBM paths hold more roots)
-            if long_paths and NMAX <= 51 and A <= 8:
-                continue  # (short searches over few actions: the LDS record is small and the faster one)
+            # (ties go to the LDS record, the faster one; the LONG record is taken where it holds more roots per workgroup)
             if (pathw + 15) // 16 > (8 if long_paths else 4) or (A > pathw and not long_paths):
                 continue
             for W in (4, 3, 2, 1):

@@ -648,7 +648,11 @@ def main():
     unsettled = None if run["elapsed_unsettled"] is None else B * world * args.steps / run["elapsed_unsettled"]
     elapsed, kernel_ms, depth_total, weights, obs, noise = (run[k] for k in ("elapsed", "kernel_ms", "depth_total",
                                                                                "weights", "obs", "noise"))
-    placement = [f"rank {rank}: cuda:{local_rank} ({torch.cuda.get_device_properties(local_rank).gcnArchName.split(':')[0]})"]
+    # every rank states the device it runs on AND the LOCAL_RANK it was launched with (the ordinal it takes on a real node:
+    # in the single-device dry run they differ, on an 8-GPU node a placement bug would show here as text)
+    env_local = int(os.environ.get("LOCAL_RANK", "0"))
+    placement = [f"rank {rank}: cuda:{local_rank} ({torch.cuda.get_device_properties(local_rank).gcnArchName.split(':')[0]}); "
+                 f"LOCAL_RANK={env_local}" + (f" (dry run on one device: cuda:{env_local} on a real node)" if single else "")]
     if dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, placement[0])

@@ -439,6 +439,11 @@ int64_t mzs_resblock_v2_workspace_bytes(int32_t batch, int32_t height, int32_t w
  * two entry points (the values of `mzs_jit_dispatch` and `mzs_jit_abi`) here; later mzs_act_mlp calls (any handle) try the registered instances after the
  * built-in ones.  `jit_abi` must equal mzs_fused_jit_abi() (same kernel-argument layout). */
 int mzs_register_fused_dispatch(void *dispatch, int32_t jit_abi);
+/* Round 6: an instance compiled with -DMZ_FUSED_MUZERO_ONLY=1 serves the MuZero policy's modes alone (its record has four
+ * words per child instead of the Gumbel modes' five: more roots per workgroup, muax_amd/_jit.py::plan(gumbel=False)) and
+ * declines a Gumbel handle.  Registered here it is tried BEFORE the instances registered with the call above, so that a
+ * MuZero-policy handle takes it even when an all-modes instance of the same shape is present. */
+int mzs_register_fused_dispatch_muzero(void *dispatch, int32_t jit_abi);
 int mzs_fused_jit_abi(void);
 /* The same for the training step (round 5): mzs_mlp_loss_grad carries mz_train_kernel for a list of (num_actions,
  * embedding_dim, 2 support_size + 1) triples and returns MZS_E_UNSUPPORTED for others, although the reference's

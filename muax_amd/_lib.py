@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = ["mzs_abi_version", "mzs_last_error", "mzs_create", "mzs_dest
                     "mzs_mlp_train_workspace_bytes", "mzs_resnet_tower", "mzs_tower_pair_scratch_bytes",
                     "mzs_dirichlet", "mzs_act_mlp_host", "mzs_selftest", "mzs_layernorm_act",
                     "mzs_layernorm_workspace_bytes", "mzs_ez_recurrent", "mzs_resnet_search",
-                    "mzs_register_fused_dispatch", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc",
+                    "mzs_register_fused_dispatch", "mzs_register_fused_dispatch_muzero", "mzs_fused_jit_abi", "mzs_mlp_allow_generic", "mzs_conv3x3_nhwc",
                     "mzs_resblock_v1", "mzs_resblock_workspace_bytes", "mzs_conv3x3_stride2_nhwc", "mzs_resnet_root_tail",
                     "mzs_resblock_v2", "mzs_resblock_v2_workspace_bytes", "mzs_register_train_dispatch", "mzs_train_jit_abi"]
 
@@ -170,6 +170,7 @@ def load(build_if_missing: bool = True):
     L.mzs_mlp_loss_grad.argtypes = [C.POINTER(MzsMlpWeights), C.POINTER(MzsTrainArgs), _vp]
     L.mzs_resnet_tower.argtypes = [C.POINTER(MzsTowerArgs), _vp]
     L.mzs_register_fused_dispatch.argtypes = [_vp, C.c_int32]
+    L.mzs_register_fused_dispatch_muzero.argtypes = [_vp, C.c_int32]
     L.mzs_register_train_dispatch.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.mzs_mlp_allow_generic.argtypes = [_vp, C.c_int32]
     L.mzs_conv3x3_nhwc.argtypes = [C.POINTER(MzsConv3x3Args), _vp]

@@ -29,6 +29,7 @@ using mzh::g_create_error;
 // fused-kernel instances built on demand and registered at run time (mzs_register_fused_dispatch; muax_amd/_jit.py)
 std::mutex g_jit_mutex;
 std::vector<mz::FusedDispatch> g_jit_dispatch;
+std::vector<mz::FusedDispatch> g_jit_dispatch_muzero;  // MuZero-policy-only instances: tried before the all-modes ones
 // training-step instances built on demand (mz_train_jit.hip): launcher of one (A, E, F = 2 support + 1) each
 using JitTrainLaunch = int (*)(const void* train_params, void* stream, char* err, int errlen);
 struct JitTrain {
@@ -90,6 +91,8 @@ struct mzs_handle {
   mz::JumpArgs jump = {nullptr, nullptr, nullptr, nullptr};  // step-wise path with cached decisions
   void* jump_slab = nullptr;
   bool use_jump = false;
+  int jump_roots = 0;              // roots the cached-decision slab holds: the batch (use_jump), or -- generic route of trees whose
+                                   // B N^2 path words exceed the budget -- the chunk of roots act() searches at a time
   bool allow_generic = false;      // mzs_mlp_allow_generic: shapes without a fused instance take the generic one-launch search
   float* gen_scratch = nullptr;    // generic route: prior logits [B, A] | embeddings [B, E] | actions [B]
 };
@@ -278,6 +281,75 @@ int mzs_mlp_set_weights(mzs_handle* h, const mzs_mlp_weights* w) {
 }
 
 static int ensure_step_state(mzs_handle* h);
+static int step_block(int batch);
+static int step_grid(int batch);
+// rows [rb, rb + n) of the step-wise tree as a batch of their own: every per-root array starts at row rb, the PRNG streams
+// stay those of the global root index (root_offset + rb)
+static mz::StepArgs slice_rows(mz::StepArgs s, size_t rb, int n) {
+  const size_t N = (size_t)s.N, A = (size_t)s.A, E = (size_t)s.E;
+  s.B = n;
+  s.root_offset += rb;
+  s.node_visits += rb * N; s.raw_values += rb * N; s.node_values += rb * N; s.parents += rb * N;
+  s.action_from_parent += rb * N; s.path += rb * N;
+  s.children_index += rb * N * A; s.children_prior_logits += rb * N * A; s.children_prior_probs += rb * N * A;
+  s.children_values += rb * N * A; s.children_visits += rb * N * A; s.children_rewards += rb * N * A;
+  s.children_discounts += rb * N * A; s.embeddings += rb * N * E;
+  s.root_invalid += rb * A; s.root_gumbel += rb * A;
+  s.sel_parent += rb; s.sel_action += rb; s.sel_depth += rb; s.depth_sum += rb; s.xfer_node += rb;
+  return s;
+}
+// The generic route for a tree whose B N^2 cached path words exceed the slab budget (4096 roots x 1000 simulations would
+// be 16 GB): the handle's slab holds `jump_roots` roots and the batch is searched in chunks of that many -- root /
+// select(0) / ONE search launch / finish per chunk on the caller's stream, the slab reused chunk after chunk (stream order),
+// the tree arrays those of the whole batch (an export copies them as ever).  Same kernels, same per-root PRNG streams
+// (root_offset + row), hence the same bits as the undivided launch.
+static int act_mlp_generic_chunks(mzs_handle* h, const mzs_act_args* a, const mz::MlpGen& g, float* pl, float* emb,
+                                  int32_t* act0, size_t lds_search, hipStream_t stream) {
+  const mzs_config& c = h->cfg;
+  const size_t A = (size_t)c.num_actions, E = (size_t)c.embed_dim;
+  const int S = c.num_simulations;
+  uint32_t zero[2] = {0, 0}, gk[2] = {0, 0};
+  if (c.policy == 1) {
+    h_split(a->key ? a->key : zero, 2, 1, gk);  // mctx gumbel_muzero_policy: rng_key, gumbel_rng = split(rng_key)
+  } else {
+    derive_keys(h, a->key ? a->key : zero);
+    if (c.tiebreak)
+      MZS_HIP(h, hipMemcpyAsync(h->step.sim_keys, h->sim_keys.data(), sizeof(uint32_t) * 2 * (size_t)S, hipMemcpyHostToDevice,
+                                stream));
+  }
+  const mz::StepArgs whole = h->step.args(c);
+  for (size_t rb = 0; rb < (size_t)c.batch; rb += (size_t)h->jump_roots) {
+    const int n = (int)std::min((size_t)h->jump_roots, (size_t)c.batch - rb);
+    const mz::StepArgs sa = slice_rows(whole, rb, n);
+    const dim3 grid(step_grid(n)), blk(step_block(n));
+    const uint8_t* inv = a->invalid_actions ? a->invalid_actions + rb * A : nullptr;
+    if (c.policy == 1) {
+      hipLaunchKernelGGL(mz::step_root_kernel, grid, blk, 0, stream, sa, pl + rb * A, a->root_value + rb, emb + rb * E, inv,
+                         static_cast<const float*>(nullptr), 0.0f, 1, a->gumbel ? a->gumbel + rb * A : nullptr, gk[0], gk[1]);
+      hipLaunchKernelGGL(mz::jump_root_kernel<true>, grid, blk, 0, stream, sa, h->jump);
+    } else {
+      hipLaunchKernelGGL(mz::step_root_kernel, grid, blk, 0, stream, sa, pl + rb * A, a->root_value + rb, emb + rb * E, inv,
+                         a->dirichlet_noise ? a->dirichlet_noise + rb * A : nullptr, a->dirichlet_fraction, 0,
+                         static_cast<const float*>(nullptr), 0u, 0u);
+      hipLaunchKernelGGL(mz::jump_root_kernel<false>, grid, blk, 0, stream, sa, h->jump);
+    }
+    hipLaunchKernelGGL(mz::jump_select_kernel<false>, grid, blk, 0, stream, sa, h->jump, 0, act0 + rb, emb + rb * E);
+    if (c.policy == 1) {
+      hipLaunchKernelGGL(mz::mz_mlp_search_kernel<true>, dim3(n), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
+      hipLaunchKernelGGL(mz::step_finish_gumbel_kernel, grid, blk, 0, stream, sa, a->action + rb, a->action_weights + rb * A,
+                         a->search_value ? a->search_value + rb : nullptr, a->depth_sum ? a->depth_sum + rb : nullptr);
+    } else {
+      hipLaunchKernelGGL(mz::mz_mlp_search_kernel<false>, dim3(n), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
+      hipLaunchKernelGGL(mz::step_finish_kernel, grid, blk, 0, stream, sa, a->temperature, a->gumbel ? a->gumbel + rb * A : nullptr,
+                         h->k_sample[0], h->k_sample[1], a->action + rb, a->action_weights + rb * A,
+                         a->search_value ? a->search_value + rb : nullptr, a->depth_sum ? a->depth_sum + rb : nullptr);
+    }
+    MZS_HIP(h, hipGetLastError());
+  }
+  h->step.rooted = true;
+  if (a->tree) return mzs_tree_export(h, a->tree, stream);
+  return MZS_OK;
+}
 // act() of the default MLP trio for shapes the fused kernel has no instance for (mz_mlp_generic.cuh): root inference,
 // mzs_root, mzs_select(0), ONE launch for all simulations, mzs_finish -- five launches per act instead of two per
 // simulation, the nets evaluated by the library to the project's arithmetic spec (== the oracle for any shape).
@@ -290,8 +362,9 @@ static int act_mlp_generic(mzs_handle* h, const mzs_act_args* a, void* stream_) 
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MZS_HIP(h, hipSetDevice(c.device));  // (reached before mzs_act_mlp's own hipSetDevice when num_simulations > kMaxSims)
   if (int rc = ensure_step_state(h)) return rc;
-  if (!h->use_jump)
-    return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): tree beyond the cached-decision budget; use the step-wise path");
+  if (h->jump_roots < 1 || (!h->use_jump && E >= mz::kWideEmb))
+    return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): no cached-decision slab for this tree (more than 1023 "
+                                      "simulations, MZS_STEP_WALK=1, or out of device memory); use the step-wise path");
   const size_t B = (size_t)c.batch;
   if (!h->gen_scratch) MZS_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->gen_scratch), (B * A + B * E + B) * sizeof(float)));
   float* pl = h->gen_scratch;
@@ -312,6 +385,7 @@ static int act_mlp_generic(mzs_handle* h, const mzs_act_args* a, void* stream_) 
     return fail(h, MZS_E_UNSUPPORTED, "mzs_act_mlp (generic route): num_simulations / embedding too large for the LDS of a workgroup");
   hipLaunchKernelGGL(mz::mz_mlp_root_kernel, dim3(c.batch), dim3(64), lds_root, stream, g, c.batch, a->obs, pl, a->root_value, emb);
   MZS_HIP(h, hipGetLastError());
+  if (!h->use_jump) return act_mlp_generic_chunks(h, a, g, pl, emb, act0, lds_search, stream);
   int rc = c.policy == 1 ? mzs_root_gumbel(h, pl, a->root_value, emb, a->invalid_actions, a->gumbel, a->key, stream_)
                          : mzs_root(h, pl, a->root_value, emb, a->invalid_actions, a->dirichlet_noise, a->dirichlet_fraction,
                                     a->key, stream_);
@@ -330,14 +404,18 @@ static int act_mlp_generic(mzs_handle* h, const mzs_act_args* a, void* stream_) 
   return MZS_OK;
 }
 
-int mzs_register_fused_dispatch(void* dispatch, int32_t jit_abi) {
+static int register_dispatch(std::vector<mz::FusedDispatch>& list, void* dispatch, int32_t jit_abi) {
   if (!dispatch) return fail(nullptr, MZS_E_INVALID, "mzs_register_fused_dispatch: null");
   if (jit_abi != mzs_fused_jit_abi()) return fail(nullptr, MZS_E_INVALID, "mzs_register_fused_dispatch: the side library was built from other sources (ABI)");
   std::lock_guard<std::mutex> lock(g_jit_mutex);
-  for (auto f : g_jit_dispatch)
+  for (auto f : list)
     if (reinterpret_cast<void*>(f) == dispatch) return MZS_OK;
-  g_jit_dispatch.push_back(reinterpret_cast<mz::FusedDispatch>(dispatch));
+  list.push_back(reinterpret_cast<mz::FusedDispatch>(dispatch));
   return MZS_OK;
+}
+int mzs_register_fused_dispatch(void* dispatch, int32_t jit_abi) { return register_dispatch(g_jit_dispatch, dispatch, jit_abi); }
+int mzs_register_fused_dispatch_muzero(void* dispatch, int32_t jit_abi) {
+  return register_dispatch(g_jit_dispatch_muzero, dispatch, jit_abi);
 }
 
 int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
@@ -415,7 +493,8 @@ int mzs_act_mlp(mzs_handle* h, const mzs_act_args* a, void* stream_) {
   std::vector<mz::FusedDispatch> groups = {mz::fused_dispatch_g0, mz::fused_dispatch_g1, mz::fused_dispatch_g2,
                                            mz::fused_dispatch_g3, mz::fused_dispatch_g4};
   {
-    std::lock_guard<std::mutex> lock(g_jit_mutex);  // instances built on demand (mzs_register_fused_dispatch)
+    std::lock_guard<std::mutex> lock(g_jit_mutex);  // instances built on demand (mzs_register_fused_dispatch[_muzero])
+    if (mode < 2) groups.insert(groups.end(), g_jit_dispatch_muzero.begin(), g_jit_dispatch_muzero.end());
     groups.insert(groups.end(), g_jit_dispatch.begin(), g_jit_dispatch.end());
   }
   // (tools/bench_generic.py: MZS_FORCE_GENERIC=1 sends a shape that HAS an instance through the generic route, for A/B timing)
@@ -559,18 +638,27 @@ static int ensure_step_state(mzs_handle* h) {
   const int table_words = rows * c.num_simulations;
   hipError_t e = h->step.allocate(c.batch, c.num_simulations + 1, c.num_actions, c.embed_dim, table_words);
   if (e != hipSuccess) return fail(h, MZS_E_RUNTIME, "tree allocation: %s", hipGetErrorString(e));
-  // cached-decision kernels (mz_step_jump.cuh): MuZero policy, bounded tree, B N^2 path words within 1 GiB;
-  // MZS_STEP_WALK=1 keeps the level-by-level kernels (A/B testing)
+  // cached-decision kernels (mz_step_jump.cuh): bounded tree, B N^2 path words within the slab budget (8 GiB of the
+  // 288 GB: 4096 roots x 300 simulations are 1.5 GB; MZS_JUMP_BUDGET_MB overrides); MZS_STEP_WALK=1 keeps the
+  // level-by-level kernels (A/B testing).  A tree beyond the budget gets a slab for a CHUNK of roots: the step-wise
+  // entry points then walk level by level (they address the whole batch), the generic one-launch search of mzs_act_mlp
+  // runs the batch chunk by chunk (roots never interact; muax/model.py:222-243 takes any num_simulations).
   {
     const size_t B = (size_t)c.batch, N = (size_t)c.num_simulations + 1;
     const char* walk = getenv("MZS_STEP_WALK");
-    if (N <= (size_t)mz::kJumpMaxNodes && B * N * N * 4 <= ((size_t)1 << 30) && !(walk && walk[0] == '1')) {
-      const size_t words = 3 * B * N + B * N * N;
-      if (hipMalloc(&h->jump_slab, words * 4) == hipSuccess) {
+    const char* mb = getenv("MZS_JUMP_BUDGET_MB");
+    const size_t budget = mb && atoll(mb) > 0 ? (size_t)atoll(mb) << 20 : (size_t)8 << 30;
+    const size_t per_root = (3 * N + N * N) * 4;
+    if (N <= (size_t)mz::kJumpMaxNodes && !(walk && walk[0] == '1')) {
+      const bool whole = B * per_root <= budget;
+      size_t roots = whole ? B : budget / per_root;
+      if (roots > B) roots = B;
+      if (roots >= 1 && hipMalloc(&h->jump_slab, roots * per_root) == hipSuccess) {
         int32_t* w = static_cast<int32_t*>(h->jump_slab);
-        h->jump.jump_pa = w; h->jump.jump_lv = w + B * N; h->jump.node_depth = w + 2 * B * N;
-        h->jump.node_path = reinterpret_cast<uint32_t*>(w + 3 * B * N);
-        h->use_jump = true;
+        h->jump.jump_pa = w; h->jump.jump_lv = w + roots * N; h->jump.node_depth = w + 2 * roots * N;
+        h->jump.node_path = reinterpret_cast<uint32_t*>(w + 3 * roots * N);
+        h->use_jump = whole;
+        h->jump_roots = (int)roots;
       }
     }
   }

@@ -409,7 +409,6 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
   mx = row_max<STEPS>(mx);
   float scale = mx - mn;
   scale = scale < 1e-5f ? scale + 1e-5f : scale;
-#ifndef MZ_AB_NORMALIZE_IEEE
   if constexpr (NSLOT == 2) {
     // the two quotients share their denominator (>= 1e-5): one refined reciprocal, the pair in packed form (div_newton2, as
     // the value scores of puct_scores) -- valid while every numerator is 0 or >= 2^-100 and the scale is below 2^41
@@ -429,7 +428,6 @@ MZ_DEV void row_min_max_normalize(float (&s)[(E + 15) / 16], int j) {
       return;
     }
   }
-#endif
 #pragma unroll
   for (int t = 0; t < NSLOT; ++t) s[t] = (s[t] - mn) / scale;
 }
@@ -521,24 +519,12 @@ struct Nets {
       });
       return (f32x2){h0, h1};
     } else {
-#ifdef MZ_AB_SPLIT_CHAINS
-      // A/B build only (round 5, VERDICT r4 item 4: NOT the project's arithmetic spec): P = 2 interleaved partial sums
-      // (even / odd k), combined at the end -- half the dependent-chain depth for one more add per chain
-      f32x2 h = splat2(0.0f), h1 = splat2(0.0f);
-      StaticFor<0, C::E>::run([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (i & 1) h1 = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h1);
-        else h = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h);
-      });
-      return h + h1;
-#else
       f32x2 h = splat2(0.0f);
       StaticFor<0, C::E>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         h = fma2(splat2(bcast<(i & 15)>(x[i >> 4])), w[i], h);
       });
       return h;
-#endif
     }
   }
   // Prediction (muax/nn.py:73-90) + value decode
@@ -613,32 +599,6 @@ struct Nets {
       });
       rl[0] = (f32x2){r0, r1};
     } else {
-#ifdef MZ_AB_SPLIT_CHAINS
-      f32x2 rl1[NP];
-      float ns1[C::ES];
-#pragma unroll
-      for (int q = 0; q < NP; ++q) rl1[q] = splat2(0.0f);
-#pragma unroll
-      for (int t = 0; t < C::ES; ++t) ns1[t] = 0.0f;
-      StaticFor<0, kHidden>::run([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const f32x2 hr = splat2(bcast<i>(h.x));
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          if constexpr (i & 1) rl1[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl1[q]);
-          else rl[q] = fma2(hr, (f32x2){dr2.w[i][2 * q], dr2.w[i][2 * q + 1]}, rl[q]);
-        }
-#pragma unroll
-        for (int t = 0; t < C::ES; ++t) {
-          if constexpr (i & 1) fmac_bcast<i, i == 1>(ns1[t], h.y, dn2.w[i][t]);
-          else fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
-        }
-      });
-#pragma unroll
-      for (int q = 0; q < NP; ++q) rl[q] = rl[q] + rl1[q];
-#pragma unroll
-      for (int t = 0; t < C::ES; ++t) ns[t] = ns[t] + ns1[t];
-#else
       StaticFor<0, kHidden>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const f32x2 hr = splat2(bcast<i>(h.x));
@@ -647,7 +607,6 @@ struct Nets {
 #pragma unroll
         for (int t = 0; t < C::ES; ++t) fmac_bcast<i, i == 0>(ns[t], h.y, dn2.w[i][t]);
       });
-#endif
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) rl[q] = rl[q] + (f32x2){dr2.b[2 * q], dr2.b[2 * q + 1]};
@@ -672,26 +631,6 @@ struct Nets {
       });
       vl[0] = (f32x2){v0, v1};
     } else {
-#ifdef MZ_AB_SPLIT_CHAINS
-      f32x2 vl1[NP];
-      float pl1 = 0.0f;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) vl1[q] = splat2(0.0f);
-      StaticFor<0, kHidden>::run([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const f32x2 gv = splat2(bcast<i>(g.x));
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          if constexpr (i & 1) vl1[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl1[q]);
-          else vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
-        }
-        if constexpr (i & 1) fmac_bcast<i, i == 1>(pl1, g.y, pp2.w[i][0]);
-        else fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
-      });
-#pragma unroll
-      for (int q = 0; q < NP; ++q) vl[q] = vl[q] + vl1[q];
-      pl = pl + pl1;
-#else
       StaticFor<0, kHidden>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const f32x2 gv = splat2(bcast<i>(g.x));
@@ -699,7 +638,6 @@ struct Nets {
         for (int q = 0; q < NP; ++q) vl[q] = fma2(gv, (f32x2){pv2.w[i][2 * q], pv2.w[i][2 * q + 1]}, vl[q]);
         fmac_bcast<i, i == 0>(pl, g.y, pp2.w[i][0]);
       });
-#endif
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) vl[q] = vl[q] + (f32x2){pv2.b[2 * q], pv2.b[2 * q + 1]};

@@ -15,6 +15,7 @@
 #include <cstdio>
 
 #include "../../include/mzsearch.h"
+#include "mz_host.h"
 #include "mz_train.cuh"
 
 namespace {
@@ -35,8 +36,16 @@ extern "C" int mzs_jit_train_launch(const void* params, void* stream_, char* err
     return MZS_E_UNSUPPORTED;
   }
   auto kern = mz::mz_train_kernel<C>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return put(err, errlen, "hipFuncSetAttribute", e);
+  // (per device, as the built-in launcher does: the attribute call is not free and update() runs every step)
+  static mzh::LdsGrant granted;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return put(err, errlen, "hipGetDevice", e);
+  if (!granted.covers(dev, lds)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return put(err, errlen, "hipFuncSetAttribute", e);
+    granted.note(dev, lds);
+  }
   hipLaunchKernelGGL(kern, dim3(p.waves / 4), dim3(256), lds, stream, p);
   if ((e = hipGetLastError()) != hipSuccess) return put(err, errlen, "training kernel launch", e);
   hipLaunchKernelGGL(mz::mz_train_reduce_kernel, dim3((p.off[18] + 31) / 32), dim3(256), 0, stream, p);

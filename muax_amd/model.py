@@ -51,6 +51,11 @@ def _dirichlet(key_words, alpha: float, shape, device, global_batch=None, root_o
     return out
 
 
+def _jit_tail():
+    from . import _jit
+    return _jit.build_log_tail(3)
+
+
 class MuZero:
     r"""MuZero algorithm (muax/model.py:16-50).
 
@@ -236,20 +241,27 @@ class MuZero:
             discount = torch.ones_like(r) * self._discount
         return (r, discount, logits, v), next_embedding
 
-    def _with_jit(self, A, E, S, call, handle=None):
+    def _with_jit(self, A, E, S, call, handle=None, gumbel=False):
         """call() -- a fused act(); when the library has no instance of the kernel for this shape, build one on demand
-        (muax_amd/_jit.py: one translation unit, cached on disk) and call again; a shape outside the kernel's limits (more
-        than 8 actions, more than 127 simulations, ...) switches `handle` to the library's generic one-launch search
-        (mzs_mlp_allow_generic).  Re-raises the ValueError when neither applies: the caller then runs the step-wise
-        path with the torch modules."""
+        (muax_amd/_jit.py: one translation unit, cached on disk, planned for the policy class `gumbel` names) and call
+        again; a shape outside the kernel's limits (more than 16 actions, more than 255 simulations, embeddings wider than
+        64) switches `handle` to the library's generic one-launch search (mzs_mlp_allow_generic).  Re-raises the
+        ValueError when neither applies: the caller then runs the step-wise path with the torch modules."""
         try:
             return call()
         except ValueError as e:
             if "no fused kernel instance" not in str(e):
                 raise
             from . import _jit
-            if _jit.ensure_instance(A, E, 2 * self._support_size + 1, S):
+            if _jit.ensure_instance(A, E, 2 * self._support_size + 1, S, gumbel=gumbel):
                 return call()
+            tail = _jit.build_log_tail()
+            if tail and _jit.last_build_log not in MuZero._warned_stepwise:  # a compiler was there and the build FAILED: say so
+                MuZero._warned_stepwise.add(_jit.last_build_log)
+                import warnings
+                warnings.warn(f"muax_amd: the on-demand build of a fused act() instance for num_actions={A}, embedding_dim="
+                              f"{E}, num_simulations={S} failed; compiler log {_jit.last_build_log}:\n{tail}",
+                              RuntimeWarning, stacklevel=3)
             # outside the fused kernel's limits (or no compiler): the generic one-launch search of the library
             if os.environ.get("MUAX_AMD_GENERIC", "1") == "0" or handle is None:
                 raise
@@ -321,10 +333,10 @@ class MuZero:
                 E_ = self.repr_func.embedding_dim
                 if host_io:
                     a_, w_, v_ = self._with_jit(A, E_, num_simulations, lambda: h.act_mlp_host(
-                        obs, key, dirichlet_fraction=0.0, invalid_actions=invalid_actions), h)
+                        obs, key, dirichlet_fraction=0.0, invalid_actions=invalid_actions), h, gumbel=True)
                     return PolicyOutput(a_, w_, None), v_
                 out = self._with_jit(A, E_, num_simulations, lambda: h.act_mlp(
-                    obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree), h)
+                    obs, key, invalid_actions=invalid_actions, gumbel=gumbel, with_tree=with_tree), h, gumbel=True)
                 self._last_fused = h
                 return out, h.root_value
             except ValueError as e:
@@ -401,7 +413,8 @@ class MuZero:
             warnings.warn(f"muax_amd: no in-library act() route for num_actions={A}, embedding_dim={E}, support_size="
                           f"{self._support_size}, num_simulations={S} ({err}); falling back to the step-wise search "
                           f"with torch modules, which is far slower (about 70x a tuned instance at 4096 roots x 50 "
-                          f"simulations; the generic one-launch route is about 16x)",
+                          f"simulations; the generic one-launch route is about 16x)"
+                          + (f"; last failed on-demand build: {_jit_tail()}" if _jit_tail() else ""),
                           RuntimeWarning, stacklevel=4)
 
     def _checked_search(self, run):

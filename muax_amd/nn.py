@@ -231,13 +231,14 @@ class HkConv2D(nn.Module):
             nn.init.trunc_normal_(w, 0.0, 1.0, -2.0, 2.0, generator=self._gen)
             self.w = nn.Parameter(w / math.sqrt(self.k * self.k * cin))
 
-    use_hip = True  # C -> C (32 / 64) 3x3 stride-1 convolutions of the representation nets on mzs_conv3x3_nhwc in inference
+    use_hip = True  # C -> C (16 / 32 / 64) 3x3 stride-1 convolutions of the representation nets on mzs_conv3x3_nhwc in inference
 
     def _hip_ok(self, x) -> bool:
         """A HIP convolution applies: inference on a dense fp32 NHWC map on the GPU, 3x3, and either stride 1 with C -> C
-        channels, C = 32 or 64 (mzs_conv3x3_nhwc: every layer inside the residual blocks of the representation nets,
-        42 x 42 x 32, 21 x 21, 11 x 11, 6 x 6) or stride 2 with 4 -> 32 / 32 -> 64 channels (mzs_conv3x3_stride2_nhwc: their
-        stems); the rows a run of output pixels touches must fit a CU's LDS."""
+        channels, C = 16, 32 or 64 (mzs_conv3x3_nhwc: every layer inside the residual blocks of the representation nets,
+        42 x 42 x 32, 21 x 21, 11 x 11, 6 x 6, and the EZ encoder's 16-channel first stage) or stride 2 with 4 -> 16,
+        4 -> 32, 16 -> 32 or 32 -> 64 channels (mzs_conv3x3_stride2_nhwc: the stems and the EZ encoder's strided projection
+        block); the rows a run of output pixels touches must fit a CU's LDS."""
         if not (self.use_hip and self.k == 3 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             return False
         c, co, (h, w) = x.shape[-1], self.out_channels, x.shape[1:3]

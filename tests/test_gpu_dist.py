@@ -149,6 +149,47 @@ def test_bench_plain_invocation_launches_its_own_ranks():
     assert u["ms_allreduce_alone"] > 0 and u["allreduce_bytes"] == 4 * 1564  # the default trio's 18 arrays, one message
 
 
+def _check_eight_rank_line(line, launcher):
+    assert line["n_gpus"] == 8 and line["config"]["launcher"] == launcher and line["config"]["backend"] == "gloo"
+    ranks = line["config"]["ranks"]
+    assert len(ranks) == 8 and [r.split(":")[0] for r in ranks] == [f"rank {i}" for i in range(8)]
+    # the device ordinal every rank would take on a real node, as text: LOCAL_RANK i -> cuda:i
+    for i, r in enumerate(ranks):
+        assert f"LOCAL_RANK={i} " in r and f"cuda:{i} on a real node" in r and r.startswith(f"rank {i}: cuda:0 "), r
+    c4, c5 = line["config4_atari"], line["config5_gumbel_train"]
+    assert "error" not in c4 and "error" not in c5, (c4, c5)
+    assert c4["n_gpus"] == 8 and c4["global_batch"] == 1024 and c4["roots_per_gpu"] == 128 and len(c4["ranks"]) == 8
+    assert c4["pair_mode_wanted"] is True and c4["pair_mode_survived"] in (True, False)
+    assert c5["n_gpus"] == 8 and c5["update"]["weights_identical_on_all_ranks_after"] is True
+    assert c5["update"]["allreduce_in_timed_update"] is True and c5["update"]["ms_allreduce_alone"] > 0
+
+
+def test_bench_eight_ranks_under_torch_distributed_run_on_one_gpu():
+    """The DRIVER's form of the 8-GPU job -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 8 ...` -- dry-run on this box's one device (round 5 ran only the
+    self-launch form at world 8): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher, every rank reports
+    the ordinal LOCAL_RANK gives it on a real node, all three legs report n_gpus 8."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MZS_TOWER_PAIR")}
+    env["MUAX_BENCH_SINGLE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "8", "--steps", "5", "--warmup", "2", "--cfg4-sims", "10", "--cfg4-acts", "1",
+                          "--cfg5-iters", "3", "--no-cpu-baseline"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    _check_eight_rank_line(line, "torch.distributed.run")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_8ranks_1gpu_torchrun.json"), "w") as f:
+        f.write(lines[0] + "\n")
+
+
 def test_bench_eight_rank_dry_run_on_one_gpu():
     """`python bench.py --gpus 8` as the driver's 8-GPU run will start it, dry-run on this box's one device
     (MUAX_BENCH_SINGLE_DEVICE: eight processes on device 0 over gloo) -- eight library loads, eight handles, eight
@@ -165,16 +206,9 @@ def test_bench_eight_rank_dry_run_on_one_gpu():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 8 and line["config"]["launcher"] == "self" and line["config"]["backend"] == "gloo"
-    assert len(line["config"]["ranks"]) == 8 and [r.split(":")[0] for r in line["config"]["ranks"]] == [f"rank {i}" for i in range(8)]
+    _check_eight_rank_line(line, "self")
     assert abs(line["value"] - 8 * 4096 * 10 / (line["ms_per_step"] * 10e-3)) < 0.01 * line["value"]
     assert line["value_unsettled"] > 0
-    c4, c5 = line["config4_atari"], line["config5_gumbel_train"]
-    assert "error" not in c4 and "error" not in c5, (c4, c5)
-    assert c4["n_gpus"] == 8 and c4["global_batch"] == 1024 and c4["roots_per_gpu"] == 128 and len(c4["ranks"]) == 8
-    assert c4["pair_mode_wanted"] is True and c4["pair_mode_survived"] in (True, False)
-    assert c5["n_gpus"] == 8 and c5["update"]["weights_identical_on_all_ranks_after"] is True
-    assert c5["update"]["allreduce_in_timed_update"] is True and c5["update"]["ms_allreduce_alone"] > 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_8ranks_1gpu.json"), "w") as f:
         f.write(lines[0] + "\n")

@@ -551,6 +551,71 @@ def test_generic_one_launch_search_matches_oracle(oracle, A, E, S, B, policy):
     assert_trees_equal(tree, out.search_tree, exact_floats=True)
 
 
+def test_generic_route_at_4096_roots_x_300_simulations(oracle, monkeypatch):
+    """B (S + 1)^2 cached path words beyond the slab budget used to end in MZS_E_UNSUPPORTED (and the
+    step-wise fall-back, 70-270x).  The budget is 8 GiB of the 288 GB now (4096 x 300 = 1.5 GB fits undivided) and a
+    tree beyond it is searched in chunks of roots that fit the slab (roots never interact; same kernels, same per-root
+    PRNG streams) -- forced here with a 64 MB budget, i.e. 23 chunks of 184 roots: both equal to the oracle's tree."""
+    A, E, S, B = 2, 8, 300, 4096
+    case = make_case(oracle, 901, B, 4, E, A, S)
+    key = [5, S]
+    ref = _oracle(oracle, case, True, key)
+    for budget in (None, "64"):
+        if budget:
+            monkeypatch.setenv("MZS_JUMP_BUDGET_MB", budget)
+        s, out = _fused_any(case, True, key, "generic")
+        _compare(ref, s, out)
+        # a second act() on the same handle (the slab is reused chunk after chunk, act after act), without an export
+        out2 = s.act_mlp(torch.from_numpy(case["obs"]), [6, S], dirichlet_noise=torch.from_numpy(case["noise"]),
+                         gumbel=torch.from_numpy(case["gumbel"]))
+        torch.cuda.synchronize()
+        ref2 = _oracle(oracle, case, True, [6, S])
+        assert np.array_equal(ref2["action"], out2.action.cpu().numpy())
+        assert np.array_equal(ref2["action_weights"], out2.action_weights.cpu().numpy())
+        assert np.array_equal(ref2["depth_sum"], s.depth_sum.cpu().numpy().astype(np.int64))
+        s.close()
+
+
+@pytest.mark.parametrize("A,E,S,B,policy", [(18, 8, 60, 97, "muzero"), (3, 8, 270, 50, "gumbel")])
+def test_generic_route_in_chunks_matches_oracle(oracle, monkeypatch, A, E, S, B, policy):
+    """The chunked generic route with invalid actions, ragged last chunk (97 roots in chunks of 4 / 50 in chunks of 3),
+    both policies: equal to the oracle like the undivided launch."""
+    monkeypatch.setenv("MZS_JUMP_BUDGET_MB", "1")
+    case = make_case(oracle, 640 + A, B, 6, E, A, S, invalid_frac=0.2)
+    key = [78, S]
+    if policy == "muzero":
+        s, out = _fused_any(case, True, key, "generic")
+        _compare(_oracle(oracle, case, True, key), s, out)
+        return
+    s, out = _fused_any(case, False, key, "generic", policy="gumbel", qtransform="qtransform_completed_by_mix_value")
+    _compare(_gumbel_oracle_act(oracle, case, key, 1, 16, gumbel=case["gumbel"]), s, out)
+
+
+@pytest.mark.parametrize("A,E,S,B", [(2, 8, 160, 70), (16, 8, 50, 45), (9, 8, 50, 33)])
+def test_muzero_only_instances_planned_per_policy(oracle, A, E, S, B):
+    """the planner sized every on-demand instance for the Gumbel modes' five-word children.  Planned
+    per policy the MuZero policy gets 16 roots per workgroup at 160 simulations (12 before), 8 at 16 actions (4), 12 at 9
+    actions (8): such an instance (-DMZ_FUSED_MUZERO_ONLY=1) declines a Gumbel handle, is tried before the all-modes ones
+    for a MuZero handle, and gives the oracle's tree."""
+    from muax_amd import MuZeroSearch, SearchConfig, _jit
+    F = 21
+    assert _jit.plan(A, E, F, S, gumbel=False)[2] > _jit.plan(A, E, F, S, gumbel=True)[2]
+    assert _jit.ensure_instance(A, E, F, S, gumbel=False)
+    case = make_case(oracle, 730 + A + S, B, 5, E, A, S, invalid_frac=0.25 if A > 2 else 0.0)
+    for tiebreak in (True, False):
+        key = [41, S + tiebreak]
+        s, out = _fused(case, tiebreak, key)
+        _compare(_oracle(oracle, case, tiebreak, key), s, out)
+        s.close()
+    # a Gumbel handle of the shape is NOT served by it: without an all-modes instance the library has none
+    if (A, E, 2, *_jit.plan(A, E, F, S, True)[1:], True) not in _jit._loaded:
+        g = MuZeroSearch(B, SearchConfig(A, S, E, policy="gumbel", tiebreak=False))
+        g.set_mlp_weights({k: torch.from_numpy(v) for k, v in case["w"].items()}, case["obs_dim"], 10, 0.99)
+        with pytest.raises(ValueError, match="no fused kernel instance"):
+            g.act_mlp(torch.from_numpy(case["obs"]), [1, 2], gumbel=torch.from_numpy(case["gumbel"]))
+        g.close()
+
+
 def test_model_act_above_the_fused_kernels_limits_takes_the_generic_route(oracle):
     """The reference's act() takes any num_simulations (muax/model.py:82-96): 300 simulations on the default trio (no
     instance possible) go through the library's generic one-launch search -- no step-wise policy adapter, no torch

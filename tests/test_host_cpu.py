@@ -458,13 +458,21 @@ def test_jit_planner_agrees_with_the_kernels_own_limits(tmp_path):
     except RuntimeError:
         pytest.skip("no hipcc")
     procs = []
-    for k, (A, E, S) in enumerate([(16, 8, 63), (2, 8, 255), (6, 8, 160), (4, 32, 200)]):
-        FS, NMAX, W, LONG = _jit.plan(A, E, 21, S)
+    # (round 6: instances planned for the MuZero policy's modes alone -- four words per child -- hold more roots per
+    # workgroup at 160 simulations and for 9 / 16 actions; their LDS arithmetic must pass the same static_asserts)
+    assert _jit.plan(2, 8, 21, 160, gumbel=False)[2] == 4 > _jit.plan(2, 8, 21, 160)[2]
+    assert _jit.plan(16, 8, 21, 50, gumbel=False)[2] == 2 > _jit.plan(16, 8, 21, 50)[2]
+    shapes = [(16, 8, 63, True), (2, 8, 255, True), (6, 8, 160, True), (4, 32, 200, True),
+              (2, 8, 160, False), (16, 8, 50, False), (9, 8, 50, False)]
+    for k, (A, E, S, gumbel) in enumerate(shapes):
+        FS, NMAX, W, LONG = _jit.plan(A, E, 21, S, gumbel)
+        assert _jit.lds_bytes(A, E, NMAX, W, LONG, gumbel) <= 160 * 1024
         deff = tmp_path / f"inst{k}.def"
         deff.write_text(f"MZS_INST(100, {A}, {E}, {FS}, {NMAX}, {W}, {'2' if LONG else 'false'})\n")
-        cmd = [cc] + _build.FLAGS + [f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100", "-shared",
+        cmd = [cc] + _build.FLAGS + [f'-DMZ_INSTANCES_FILE="{deff}"', "-DMZ_FUSED_GROUP=100",
+                                     f"-DMZ_FUSED_MUZERO_ONLY={0 if gumbel else 1}", "-shared",
                                      os.path.join(_build.CSRC, "mz_fused_jit.hip"), "-o", str(tmp_path / f"inst{k}.so")]
-        procs.append(((A, E, S), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        procs.append(((A, E, S, gumbel), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     # ... and one on-demand instance of the training-step kernel (mz_train_jit.hip), with the entry points _jit binds
     cmd = [cc] + _build.FLAGS + ["-DMZ_TRAIN_A=5", "-DMZ_TRAIN_E=12", "-DMZ_TRAIN_F=25", "-shared",
                                  os.path.join(_build.CSRC, "mz_train_jit.hip"), "-o", str(tmp_path / "train.so")]
@@ -479,3 +487,51 @@ def test_jit_planner_agrees_with_the_kernels_own_limits(tmp_path):
     L = ctypes.CDLL(_build.LIB_PATH)
     assert side.mzs_jit_train_abi() == L.mzs_train_jit_abi()
     assert not _jit.ensure_train_instance(17, 8, 21) and not _jit.ensure_train_instance(2, 8, 65)
+
+
+
+def test_jit_cache_key_names_everything_the_planner_decided(monkeypatch):
+    """the cache file of an on-demand instance is named after (A, E, FS, NMAX, W) AND the record kind
+    (LONG) AND the policy class, and its hash covers muax_amd/_jit.py (the planner) and PLAN_VERSION: a cache directory
+    that survives a planner change cannot serve an instance of another record kind."""
+    from muax_amd import _jit
+    t = _jit.instance_tag(2, 8, 2, 161, 4, True, False)
+    assert "_l1_" in t and "_p0-" in t
+    assert t != _jit.instance_tag(2, 8, 2, 161, 4, False, False) and t != _jit.instance_tag(2, 8, 2, 161, 4, True, True)
+    f0 = _jit.instance_file(4, 8, 21, 100)
+    real = _jit.plan
+
+    def flipped(A, E, F, S, gumbel=True):  # the planner changes its mind about the record kind of this one shape
+        pl = real(A, E, F, S, gumbel)
+        return (pl[0], pl[1], pl[2], not pl[3]) if (A, S) == (4, 100) and pl else pl
+
+    monkeypatch.setattr(_jit, "plan", flipped)
+    f1 = _jit.instance_file(4, 8, 21, 100)
+    assert f0 != f1 and f0.replace("_l1_", "_l0_") == f1 or f0.replace("_l0_", "_l1_") == f1
+    monkeypatch.setattr(_jit, "plan", real)
+    h0 = _jit._source_hash()
+    monkeypatch.setattr(_jit, "PLAN_VERSION", _jit.PLAN_VERSION + 1)
+    assert _jit._source_hash() != h0
+    # a policy-specific instance only where it buys roots per workgroup: otherwise ONE file serves every mode
+    assert _jit.instance_file(2, 8, 21, 255, gumbel=False) == _jit.instance_file(2, 8, 21, 255, gumbel=True)
+    assert _jit.instance_file(2, 8, 21, 160, gumbel=False) != _jit.instance_file(2, 8, 21, 160, gumbel=True)
+
+
+def test_jit_failed_build_leaves_a_compiler_log():
+    """A failed on-demand build is no longer silent: hipcc's output stays in muax_amd/lib/jit/mzfused_<tag>.log and
+    build_log_tail() returns its last lines (MuZero puts them into its warning)."""
+    from muax_amd import _jit
+    try:
+        _build.hipcc()
+    except RuntimeError:
+        pytest.skip("no hipcc")
+    assert not _jit.ensure_instance(3, 12, 21, 20, extra_flags=("-DMZ_FUSED_GROUP=this_is_not_a_number",))
+    log = _jit.last_build_log
+    assert log and os.path.exists(log) and log.endswith(".log")
+    text = open(log).read()
+    assert "hipcc" in text.splitlines()[0] and "error" in text
+    assert "error" in _jit.build_log_tail(40)
+    os.remove(log)
+    for f in os.listdir(_jit.JIT_DIR):  # (the one-line instance list of the failed build)
+        if f.startswith("inst_a3_e12_") and "-x" in f:
+            os.remove(os.path.join(_jit.JIT_DIR, f))

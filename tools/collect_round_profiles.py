@@ -73,10 +73,14 @@ if os.path.exists(os.path.join(R, "bench_long.txt")):
     with open(os.path.join(P, f"{tag}_generic_route.txt"), "a") as f:
         f.write("\n## long searches / wide action sets through mzs_act_mlp at several batch sizes: median ms per act (tools/bench_long.py);\n"
                 "## plan = (support slots, tree size, wavefronts per workgroup, LONG record)\n" + rd("bench_long.txt"))
-if os.path.exists(os.path.join(R, "bench_2ranks_1gpu.json")):
-    with open(os.path.join(P, f"{tag}_bench_2ranks_1gpu.json"), "w") as f:
-        f.write(open(os.path.join(R, "bench_2ranks_1gpu.json")).read())
-    print("wrote", f"profiles/{tag}_bench_2ranks_1gpu.json")
+for multi in ("bench_2ranks_1gpu.json", "bench_8ranks_1gpu.json", "bench_8ranks_1gpu_torchrun.json"):
+    if os.path.exists(os.path.join(R, multi)) or os.path.exists(os.path.join(ROOT, "gpurun_out", multi)):
+        src = os.path.join(R, multi) if os.path.exists(os.path.join(R, multi)) else os.path.join(ROOT, "gpurun_out", multi)
+        # only the JSON line(s): the ranks' "[Gloo] Rank 0 is connected ..." chatter on stdout is not part of the record
+        keep = [ln for ln in open(src).read().splitlines() if ln.startswith("{")]
+        with open(os.path.join(P, f"{tag}_{multi}"), "w") as f:
+            f.write("\n".join(keep) + "\n")
+        print("wrote", f"profiles/{tag}_{multi}")
 
 
 for extra, name, hdr in (("stress_round5.txt", "stress_parity.txt",
@@ -100,7 +104,9 @@ pj = json.load(open(os.path.join(P, "pmc_traffic.json")))
 for wl, fn in (("cartpole", "prof_cartpole.txt"), ("lunarlander", "prof_lunarlander.txt")):
     fs, ws = pmc(rd(fn), "FETCH_SIZE"), pmc(rd(fn), "WRITE_SIZE")
     if fs and ws:
-        pj[wl].update({"hbm_bytes_per_launch": int((2 * fs + ws) * 1024), "fetch_size_kb_raw": fs, "write_size_kb_raw": ws})
+        pj[wl].update({"hbm_bytes_per_launch": int((2 * fs + ws) * 1024), "fetch_size_kb_raw": fs, "write_size_kb_raw": ws,
+                       "source": f"profiles/{tag}_rocprofv3_cartpole4096.txt (tools/rocprof_passes.sh: separate --pmc passes of "
+                                 f"`python bench.py --workload {wl}`)"})
 json.dump(pj, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 print("pmc_traffic.json refreshed")
 

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, con
     const float rew = G.scal[0], val = G.scal[1];
     const int known[4] = {parent, action, depth, newn};
     int sel[3] = {0, 0, 0};
-    jump_expand_backup_body<GUMBEL>(s, g, sim, r, tree_lds, rew, w.discount, G.pl, val, nullptr, true, nullptr, nullptr, sel, known);
+    jump_expand_backup_body<GUMBEL>(s, g, tree_view_global(s, g, rb), sim, r, tree_lds, rew, w.discount, G.pl, val, nullptr, true, nullptr, nullptr,
+                                    sel, known);
     if (sim + 1 < sim_end && sim + 1 < s.S) {
       parent = sel[0];
       action = sel[1];

@@ -21,6 +21,8 @@
 //     message per simulation tells half 1 the next simulation's (parent, action, new node).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #define MZ_NO_STEP_KERNELS   // device functions and types of the step-wise path only: its kernels live in mz_api.hip,
 #define MZ_NO_TOWER_KERNELS  // the recurrent kernel's in mz_conv.hip
 #include "mz_conv_host.h"
@@ -44,9 +46,17 @@ MZ_DEV bool pair_lost_uniform(const PairLink& L, int tid, int* flag_lds) {
   return *flag_lds != 0;
 }
 
-template <bool GUMBEL, bool PAIRED>
+// LDSTREE (round 6, MuZero policy): the statistics the tree step reads and rewrites -- children_{index, visits,
+// prior_probs, rewards, values}[N][A], node_{visits, values}[N], the JUMP records [N] -- live in this CU's LDS for the
+// whole launch (copied in from the handle's HBM tree at the start, written back at the end; 75.6 KB for config 4's 201
+// nodes x 18 actions, next to the pass' 66 KB and the step's 14 KB: 155.6 of the CU's 160 KB).  Between two tree steps
+// of a root its XCD streams the 5.7 MB of convolution weights through its 4 MB L2: the step's ~260 tree lines were gone
+// every time, and a 44-level decision refresh spent 4.5 of its 7 us on memory round trips.  Same device functions on
+// the same values in the same order (a TreeView of LDS rows instead of HBM rows): same bits.
+template <bool GUMBEL, bool PAIRED, bool LDSTREE>
 __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams p, const StepArgs s, const JumpArgs g,
                                                                const SearchLoop loop) {
+  static_assert(!(GUMBEL && LDSTREE), "the Gumbel policy's decisions read the HBM tree (row_qtransform)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int* tree_lds = reinterpret_cast<int*>(lds + 2 * kBufWords + kHeadWords);
   __shared__ int lost_flag;
@@ -75,11 +85,39 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
     if (h == 0) pair_link_init<1>(p, r, L);
     else pair_link_init<2>(p, r, L);
   }
+  // the tree statistics of this root: rows of the handle's HBM tree, or their copy in LDS (half 0 / the single workgroup)
+  TreeView T = tree_view_global(s, g, rb);
+  const bool owns_tree = !PAIRED || h == 0;
+  if constexpr (LDSTREE) {
+    int* tl = tree_lds + 17 * (s.S + 2);
+    const int NA = N * A;
+    T.cidx = tl; T.cvis = tl + NA; T.prob = reinterpret_cast<float*>(tl + 2 * NA); T.rew = reinterpret_cast<float*>(tl + 3 * NA);
+    T.val = reinterpret_cast<float*>(tl + 4 * NA);
+    T.dis = nullptr; T.disc = loop.discount;
+    T.nvis = tl + 5 * NA; T.nval = reinterpret_cast<float*>(tl + 5 * NA + N); T.jpa = tl + 5 * NA + 2 * N; T.jlv = tl + 5 * NA + 3 * N;
+    if (owns_tree) {
+      const size_t o = rb * A;
+      for (int i = tid; i < NA; i += 256) {
+        T.cidx[i] = s.children_index[o + i];
+        T.cvis[i] = s.children_visits[o + i];
+        T.prob[i] = s.children_prior_probs[o + i];
+        T.rew[i] = s.children_rewards[o + i];
+        T.val[i] = s.children_values[o + i];
+      }
+      for (int i = tid; i < N; i += 256) {
+        T.nvis[i] = s.node_visits[rb + i];
+        T.nval[i] = s.node_values[rb + i];
+        T.jpa[i] = g.jump_pa[rb + i];
+        T.jlv[i] = g.jump_lv[rb + i];
+      }
+      __syncthreads();
+    }
+  }
   // simulate() of sim_begin has run (mzs_select, or the tail of the previous launch): its decision is in the handle
   int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
   int newn;
   {
-    const int next = s.children_index[(rb + parent) * A + action];
+    const int next = owns_tree ? T.cidx[parent * A + action] : s.children_index[(rb + parent) * A + action];
     newn = next == -1 ? loop.sim_begin + 1 : next;
   }
   TowerIO io;
@@ -114,7 +152,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
             jump_prefetch_path(s, g, r, JL, tid, 256, parent, action, depth, newn, fresh);
             prefetched |= 1;
           } else if (k == 1) {
-            jump_prefetch_levels(s, r, JL, tid, 256, depth);
+            jump_prefetch_levels(s, T, JL, tid, 256, depth);
             prefetched |= 2;
           }
         };
@@ -133,14 +171,14 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
 #ifndef MZ_SEARCH_LIF
 #define MZ_SEARCH_LIF kLevelsInFlight
 #endif
-      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF>(s, g, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
+      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
                                       nullptr, sel, known, prefetched, score_tbl);
       MZ_ST(2)
       if (more) {
         parent = sel[0];
         action = sel[1];
         depth = sel[2];
-        const int next = s.children_index[(rb + parent) * A + action];
+        const int next = T.cidx[parent * A + action];
         newn = next == -1 ? sim + 2 : next;
       }
       if constexpr (PAIRED) {
@@ -188,6 +226,26 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   if (tid == 0)
     for (int k = 1; k < 4; ++k) g_tower_prof[(size_t)blockIdx.x * 16 + 11 + k] += st[k];  // slots 12..14 (0..11, 15: the pass itself)
 #endif
+  if constexpr (LDSTREE) {
+    if (owns_tree) {  // back into the handle's tree: mzs_finish / mzs_tree_export / the next launch read it there
+      __syncthreads();
+      const size_t o = rb * A;
+      const int NA = N * A;
+      for (int i = tid; i < NA; i += 256) {
+        s.children_index[o + i] = T.cidx[i];
+        s.children_visits[o + i] = T.cvis[i];
+        s.children_prior_probs[o + i] = T.prob[i];
+        s.children_rewards[o + i] = T.rew[i];
+        s.children_values[o + i] = T.val[i];
+      }
+      for (int i = tid; i < N; i += 256) {
+        s.node_visits[rb + i] = T.nvis[i];
+        s.node_values[rb + i] = T.nval[i];
+        g.jump_pa[rb + i] = T.jpa[i];
+        g.jump_lv[rb + i] = T.jlv[i];
+      }
+    }
+  }
   if constexpr (PAIRED) {
     // the root's epoch advances by the simulations of this launch (each uses fewer than kPairMsgs message numbers);
     // both halves read it before their first message and half 0 is past the last one it waits for
@@ -237,8 +295,13 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
     return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: simulation range");
   if (2 * a->blocks + 3 > mz::kPairMsgs)
     return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: too many blocks");
-  const size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 17 * ((size_t)sa.S + 2);  // (15 arrays of the tree step + the score table)
+  size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 17 * ((size_t)sa.S + 2);  // (15 arrays of the tree step + the score table)
   if (lds > 160 * 1024) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: num_simulations too large for the LDS of a CU");
+  // the tree's statistics in LDS as well when they fit next to that (MuZero policy; MZS_SEARCH_LDS_TREE=0: A/B, tests)
+  const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N);
+  const char* lt = getenv("MZS_SEARCH_LDS_TREE");
+  const bool ldstree = policy != 1 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
+  if (ldstree) lds = lds_tree;
   if (sa.S + 1 > 4096 || sa.A > 255)
     return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: message T packs (node, action, node) as 12 + 8 + 12 bits");
   const mz::SearchLoop loop = {sim_begin, sim_end, discount};
@@ -252,18 +315,20 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
     if (a->pair_scratch_bytes < need) return mzh::fail_handle(h, MZS_E_INVALID, "mzs_resnet_search: pair_scratch too small");
     p.pair_f = static_cast<float*>(a->pair_scratch);
     p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot * 2);  // (8-byte words)
-    fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, true>)
-                : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true>);
+    fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, true, false>)
+                : (ldstree ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true, true>)
+                           : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true, false>));
     grid = dim3(16 * ((a->batch + 7) / 8));
   } else {
-    fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, false>)
-                : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false>);
+    fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, false, false>)
+                : (ldstree ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false, true>)
+                           : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false, false>));
     grid = dim3(a->batch);
   }
   {
     // raise the kernel's dynamic-LDS limit once per (instance, device) and size
-    static mzh::LdsGrant granted[4];
-    mzh::LdsGrant& have = granted[(gumbel ? 2 : 0) + (a->pair_scratch ? 1 : 0)];
+    static mzh::LdsGrant granted[6];
+    mzh::LdsGrant& have = granted[(gumbel ? 4 : (ldstree ? 2 : 0)) + (a->pair_scratch ? 1 : 0)];
     if (!have.covers(a->device, lds)) {
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return mzh::fail_handle(h, MZS_E_RUNTIME, "mzs_resnet_search: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");

@@ -57,6 +57,28 @@ struct JumpArgs {
   uint32_t* node_path;  // [B][N][N]  entry e = node at level e | action taken there << 16
 };
 
+// The statistics of ONE root's tree that the per-simulation step both reads and rewrites (the MuZero policy's decisions:
+// children_{index, visits, prior_probs, rewards, values}, node_{visits, values}, the JUMP records), as pointers to the
+// root's own rows.  The step-wise kernels point them at the HBM tree (tree_view_global).  The one-launch ResNet search
+// (mz_search_conv.hip) keeps them in the CU's LDS for the whole search when they fit (round 6): between two tree steps
+// of a root its XCD streams 5.7 MB of convolution weights through a 4 MB L2, so every tree step used to find its ~260
+// cache lines evicted -- 4.5 of the 7 us of a 44-level decision refresh were memory round trips, not arithmetic.
+struct TreeView {
+  int* cidx; int* cvis; float* prob; float* rew; float* val;  // [N][A]
+  float* dis;    // [N][A] children_discounts, or nullptr: `disc` on every edge (an unexpanded child's value is +0, so
+  float disc;    // rew + disc * val is the same +0 as with the array's 0 there)
+  int* nvis; float* nval;  // [N]
+  int* jpa; int* jlv;      // [N]
+};
+MZ_DEV TreeView tree_view_global(const StepArgs& s, const JumpArgs& g, size_t rb) {
+  const size_t o = rb * (size_t)s.A;
+  TreeView T;
+  T.cidx = s.children_index + o; T.cvis = s.children_visits + o; T.prob = s.children_prior_probs + o;
+  T.rew = s.children_rewards + o; T.val = s.children_values + o; T.dis = s.children_discounts + o; T.disc = 0.0f;
+  T.nvis = s.node_visits + rb; T.nval = s.node_values + rb; T.jpa = g.jump_pa + rb; T.jlv = g.jump_lv + rb;
+  return T;
+}
+
 // pUCT scores of all children of `node` (muzero_action_selection with qtransform_by_parent_and_siblings),
 // noise-free; first-max argmax; `near` = some other action is within the reach of the tie-break noise.
 // Split into the loads and the arithmetic so that a row can put the loads of several levels in flight before it
@@ -67,11 +89,11 @@ struct LevelIn {
   int nvis, inv;  // inv: bit t = action j + 16 t is invalid at the root
   float nval;
 };
-MZ_DEV void level_load(const StepArgs& s, size_t rb, int r, int node, int j, LevelIn& L) {
+MZ_DEV void level_load(const StepArgs& s, const TreeView& T, int r, int node, int j, LevelIn& L) {
   const int A = s.A;
-  const size_t nb = (rb + node) * A;
-  L.nvis = s.node_visits[rb + node];
-  L.nval = s.node_values[rb + node];
+  const int nb = node * A;
+  L.nvis = T.nvis[node];
+  L.nval = T.nval[node];
   L.inv = 0;
 #pragma unroll
   for (int t = 0; t < kMaxAS; ++t) {
@@ -79,13 +101,13 @@ MZ_DEV void level_load(const StepArgs& s, size_t rb, int r, int node, int j, Lev
     const bool ok = a < A;
     L.cidx[t] = -1; L.cvis[t] = 0; L.prob[t] = 0.0f; L.rew[t] = 0.0f; L.dis[t] = 0.0f; L.val[t] = 0.0f;
     if (16 * t < A) {
-      const size_t o = nb + (ok ? a : 0);
-      L.cidx[t] = s.children_index[o];
-      L.cvis[t] = s.children_visits[o];
-      L.prob[t] = s.children_prior_probs[o];
-      L.rew[t] = s.children_rewards[o];
-      L.dis[t] = s.children_discounts[o];
-      L.val[t] = s.children_values[o];
+      const int o = nb + (ok ? a : 0);
+      L.cidx[t] = T.cidx[o];
+      L.cvis[t] = T.cvis[o];
+      L.prob[t] = T.prob[o];
+      L.rew[t] = T.rew[o];
+      L.dis[t] = T.dis ? T.dis[o] : T.disc;
+      L.val[t] = T.val[o];
       if (node == 0 && ok && s.root_invalid[(size_t)r * A + a]) L.inv |= 1 << t;  // the root is level 0 only
     }
   }
@@ -151,10 +173,10 @@ MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc
   }
   near = ((__builtin_amdgcn_ballot_w64(unsafe) >> (threadIdx.x & 48)) & 0xffffull) != 0;  // any lane of the row
 }
-MZ_DEV void level_decide(const StepArgs& s, size_t rb, int r, int node, int j, float (&sc)[kMaxAS],
+MZ_DEV void level_decide(const StepArgs& s, const TreeView& T, int r, int node, int j, float (&sc)[kMaxAS],
                          int (&cidx)[kMaxAS], int& best, int& child, bool& near) {
   LevelIn L;
-  level_load(s, rb, r, node, j, L);
+  level_load(s, T, r, node, j, L);
   level_compute(s, j, L, sc, best, child, near);
 #pragma unroll
   for (int t = 0; t < kMaxAS; ++t) cidx[t] = L.cidx[t];
@@ -200,14 +222,14 @@ MZ_DEV void gumbel_decide(const StepArgs& s, size_t rb, int r, int node, int j, 
   }
 }
 template <bool GUMBEL>
-MZ_DEV void decide_any(const StepArgs& s, size_t rb, int r, int node, int j, int& best, int& child, bool& near) {
+MZ_DEV void decide_any(const StepArgs& s, const TreeView& T, size_t rb, int r, int node, int j, int& best, int& child, bool& near) {
   if constexpr (GUMBEL) {
-    gumbel_decide(s, rb, r, node, j, best, child);
+    gumbel_decide(s, rb, r, node, j, best, child);  // (the Gumbel policy's statistics stay in the HBM tree)
     near = false;
   } else {
     float sc[kMaxAS];
     int cidx[kMaxAS];
-    level_decide(s, rb, r, node, j, sc, cidx, best, child, near);
+    level_decide(s, T, r, node, j, sc, cidx, best, child, near);
   }
 }
 
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) 
   MZ_JROW_SETUP
   int best, child;
   bool near;
-  decide_any<GUMBEL>(s, rb, r, 0, j, best, child, near);
+  decide_any<GUMBEL>(s, tree_view_global(s, g, rb), rb, r, 0, j, best, child, near);
   if (j == 0) {
     g.jump_pa[rb] = best << 16 | (near ? (int)0x80000000 : 0);
     g.jump_lv[rb] = 0;
@@ -229,7 +251,8 @@ __global__ __launch_bounds__(256) void jump_root_kernel(StepArgs s, JumpArgs g) 
 // -- every row repeats the (O(1)) selection, so every thread knows the parent and the whole workgroup gathers its
 // embedding row (a separate transfer kernel costs its own 4.7 us minimum); otherwise one 16-lane row per root.
 // jump_select_core: the decision alone -- every 16-lane row that calls it gets the same (parent, action, depth).
-MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int r, int& parent, int& action, int& depth) {
+MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int& parent, int& action,
+                             int& depth) {
   const int lane = opaque_tid() & 63;
   const int j = lane & 15;
   const int N = s.N, A = s.A;
@@ -238,7 +261,7 @@ MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int 
   const int NB = (A + 1) / 2;
   uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 0;
   int klevel = -1;  // key walk not started
-  int jw = g.jump_pa[rb], level = g.jump_lv[rb];
+  int jw = T.jpa[0], level = T.jlv[0];
   for (;;) {
     parent = jw & 0xffff;
     action = (jw >> 16) & 0xff;
@@ -264,7 +287,7 @@ MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int 
       float sc[kMaxAS];
       int cidx[kMaxAS], best, child;
       bool near;
-      level_decide(s, rb, r, parent, j, sc, cidx, best, child, near);
+      level_decide(s, T, r, parent, j, sc, cidx, best, child, near);
       float bscore = -INFINITY;
       best = 1 << 20;
       child = -1;
@@ -284,8 +307,8 @@ MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int 
       row_argmax<4>(bscore, best, child);
       action = best;
       if (child >= 0 && level + 1 < s.max_depth) {
-        jw = g.jump_pa[rb + child];
-        level = g.jump_lv[rb + child];
+        jw = T.jpa[child];
+        level = T.jlv[child];
         continue;
       }
     }
@@ -302,13 +325,13 @@ MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, int sim, int 
 }
 // `parent_embedding_out` == nullptr: no gather (the caller reads the tree's embedding row in place)
 template <bool WG>
-MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int32_t* action_out,
+MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int32_t* action_out,
                              float* parent_embedding_out, int* sel_out = nullptr) {
   const int j = threadIdx.x & 15;
   const int N = s.N, E = s.E;
   const size_t rb = (size_t)r * N;
   int parent, action, depth;
-  jump_select_core(s, g, sim, r, parent, action, depth);
+  jump_select_core(s, g, T, sim, r, parent, action, depth);
   if (sel_out) { sel_out[0] = parent; sel_out[1] = action; sel_out[2] = depth; }
   if (WG ? threadIdx.x == 0 : j == 0) {
     s.sel_parent[r] = parent;
@@ -333,7 +356,7 @@ __global__ __launch_bounds__(256) void jump_select_kernel(StepArgs s, JumpArgs g
                                                            float* parent_embedding_out) {
   const int r = WIDE ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4));
   if (r >= s.B) return;
-  jump_select_body<WIDE>(s, g, sim, r, action_out, parent_embedding_out);
+  jump_select_body<WIDE>(s, g, tree_view_global(s, g, (size_t)r * s.N), sim, r, action_out, parent_embedding_out);
 }
 
 // mctx search.expand + search.backward + refresh of the decisions on the path: one workgroup per root.
@@ -385,20 +408,19 @@ MZ_DEV void jump_prefetch_path(const StepArgs& s, const JumpArgs& g, int r, cons
   }
 }
 // (2) per-level inputs of the backward pass (the last edge's reward / discount come from recurrent_fn: filled in later)
-MZ_DEV void jump_prefetch_levels(const StepArgs& s, int r, const JumpLds& L, int tid, int nthr, int depth) {
-  const size_t rb = (size_t)r * s.N;
+MZ_DEV void jump_prefetch_levels(const StepArgs& s, const TreeView& T, const JumpLds& L, int tid, int nthr, int depth) {
   for (int e = tid; e < depth; e += nthr) {
-    const size_t e2 = (rb + L.pn[e]) * s.A + L.pa[e];
-    L.cnt[e] = s.node_visits[rb + L.pn[e]];
-    L.val[e] = s.node_values[rb + L.pn[e]];
-    L.rw[e] = (e == depth - 1) ? 0.0f : s.children_rewards[e2];
-    L.ds[e] = (e == depth - 1) ? 0.0f : s.children_discounts[e2];
+    const int e2 = L.pn[e] * s.A + L.pa[e];
+    L.cnt[e] = T.nvis[L.pn[e]];
+    L.val[e] = T.nval[L.pn[e]];
+    L.rw[e] = (e == depth - 1) ? 0.0f : T.rew[e2];
+    L.ds[e] = (e == depth - 1) ? 0.0f : (T.dis ? T.dis[e2] : T.disc);  // (levels above the last edge are expanded edges)
   }
 }
 
 // `prefetched`: bit 0 = jump_prefetch_path, bit 1 = jump_prefetch_levels have run for this simulation (and a barrier since)
 template <bool GUMBEL, int LIF = kLevelsInFlight>
-MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int sim, int r, int* lds_i, float rew_new,
+MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
                                     int* sel_out = nullptr, const int* known = nullptr, int prefetched = 0,
@@ -413,7 +435,8 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
   const int parent = known ? known[0] : s.sel_parent[r], action = known ? known[1] : s.sel_action[r];
   const int depth = known ? known[2] : s.sel_depth[r];
   const size_t eo = (rb + parent) * A + action;
-  const int next = known ? (known[3] == sim + 1 ? -1 : known[3]) : s.children_index[eo];
+  const int eol = parent * A + action;
+  const int next = known ? (known[3] == sim + 1 ? -1 : known[3]) : T.cidx[eol];
   __syncthreads();  // every thread has read the edge before row 0 rewrites it
   const bool fresh = next == -1;
   const int newn = fresh ? sim + 1 : next;
@@ -439,16 +462,16 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
       const int a = j + 16 * t;
       if (a < A) {
         s.children_prior_logits[(rb + newn) * A + a] = x[t];
-        s.children_prior_probs[(rb + newn) * A + a] = pr[t];
+        T.prob[newn * A + a] = pr[t];
       }
     }
     if (j == 0) {
       s.raw_values[rb + newn] = v;
-      s.node_values[rb + newn] = v;
-      s.node_visits[rb + newn] = s.node_visits[rb + newn] + 1;
-      s.children_index[eo] = newn;
-      s.children_rewards[eo] = rew_new;
-      s.children_discounts[eo] = dis_new;
+      T.nval[newn] = v;
+      T.nvis[newn] = T.nvis[newn] + 1;
+      T.cidx[eol] = newn;
+      T.rew[eol] = rew_new;
+      s.children_discounts[eo] = dis_new;  // (== T.dis[eol] when the view is the HBM tree)
       s.parents[rb + newn] = parent;
       s.action_from_parent[rb + newn] = action;
       s.xfer_node[r] = newn;
@@ -460,7 +483,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
   __syncthreads();
   MZ_JT(0)
   // -- per-level inputs of the backward pass --
-  if (!(prefetched & 2)) jump_prefetch_levels(s, r, JL, tid, nthr, depth);
+  if (!(prefetched & 2)) jump_prefetch_levels(s, T, JL, tid, nthr, depth);
   if (tid == (depth - 1) % nthr && depth > 0) {  // (the thread that wrote the entry, if it was written just now)
     rw[depth - 1] = rew_new;
     ds[depth - 1] = dis_new;
@@ -497,11 +520,11 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
     nv[e] = (e == depth) ? v : (val[e] * (float)cnt[e] + Gs[e]) / ((float)cnt[e] + 1.0f);
   __syncthreads();
   for (int e = tid; e < depth; e += nthr) {
-    const size_t e2 = (rb + pn[e]) * A + pa[e];
-    s.node_values[rb + pn[e]] = nv[e];
-    s.node_visits[rb + pn[e]] = cnt[e] + 1;
-    s.children_values[e2] = nv[e + 1];
-    s.children_visits[e2] = s.children_visits[e2] + 1;
+    const int e2 = pn[e] * A + pa[e];
+    T.nval[pn[e]] = nv[e];
+    T.nvis[pn[e]] = cnt[e] + 1;
+    T.val[e2] = nv[e + 1];
+    T.cvis[e2] = T.cvis[e2] + 1;
   }
   __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
   MZ_JT(3)
@@ -514,14 +537,14 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
         if (e <= depth) {
           int best, child;
           bool near;
-          decide_any<GUMBEL>(s, rb, r, pn[e], j, best, child, near);
+          decide_any<GUMBEL>(s, T, rb, r, pn[e], j, best, child, near);
           if (j == 0) {
             bst[e] = best;
             chd[e] = child;
             flg[e] = near ? 1 : 0;
             const bool off_path = child >= 0 && !(e < depth && child == pn[e + 1]);
-            cjp[e] = off_path ? g.jump_pa[rb + child] : 0;
-            cjl[e] = off_path ? g.jump_lv[rb + child] : 0;
+            cjp[e] = off_path ? T.jpa[child] : 0;
+            cjl[e] = off_path ? T.jlv[child] : 0;
           }
         }
       }
@@ -532,7 +555,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
 #pragma unroll
       for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
-        level_load(s, rb, r, pn[e <= depth ? e : depth], j, L[u]);
+        level_load(s, T, r, pn[e <= depth ? e : depth], j, L[u]);
       }
 #ifdef MZ_PROF_DECIDE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -547,8 +570,8 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
       }
 #pragma unroll
       for (int u = 0; u < LIF; ++u) {  // the off-path children's stored records, all requested together
-        cj[u] = offu[u] ? g.jump_pa[rb + childu[u]] : 0;
-        cl[u] = offu[u] ? g.jump_lv[rb + childu[u]] : 0;
+        cj[u] = offu[u] ? T.jpa[childu[u]] : 0;
+        cl[u] = offu[u] ? T.jlv[childu[u]] : 0;
       }
 #pragma unroll
       for (int u = 0; u < LIF; ++u) {
@@ -587,14 +610,14 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, int si
     }
     for (int e = tid; e <= depth; e += nthr) {
       const int from = src[e];
-      g.jump_pa[rb + pn[e]] = njp[from];
-      g.jump_lv[rb + pn[e]] = njl[from];
+      T.jpa[pn[e]] = njp[from];
+      T.jlv[pn[e]] = njl[from];
     }
   }
   MZ_JT(5)
   if (select_next && sim + 1 < s.S) {
     __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
-    jump_select_body<true>(s, g, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out);
+    jump_select_body<true>(s, g, T, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out);
   }
   MZ_JT(6)
 }
@@ -606,7 +629,7 @@ __global__ __launch_bounds__(1024) void jump_expand_backup_kernel(StepArgs s, Ju
                                                                   float* next_parent_embedding_out) {
   extern __shared__ int lds_i[];
   const int r = blockIdx.x;
-  jump_expand_backup_body<GUMBEL>(s, g, sim, r, lds_i, reward[r], discount[r], prior_logits + (size_t)r * s.A, value[r],
+  jump_expand_backup_body<GUMBEL>(s, g, tree_view_global(s, g, (size_t)r * s.N), sim, r, lds_i, reward[r], discount[r], prior_logits + (size_t)r * s.A, value[r],
                                   next_embedding + (size_t)r * s.E, next_action_out != nullptr, next_action_out,
                                   next_parent_embedding_out);
 }

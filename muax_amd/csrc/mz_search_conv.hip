@@ -53,7 +53,9 @@ MZ_DEV bool pair_lost_uniform(const PairLink& L, int tid, int* flag_lds) {
 // of a root its XCD streams the 5.7 MB of convolution weights through its 4 MB L2: the step's ~260 tree lines were gone
 // every time, and a 44-level decision refresh spent 4.5 of its 7 us on memory round trips.  Same device functions on
 // the same values in the same order (a TreeView of LDS rows instead of HBM rows): same bits.
-template <bool GUMBEL, bool PAIRED, bool LDSTREE>
+// AS (LDSTREE instances): the 16-lane slots the action count fills (1: A <= 16, 2: A <= 32) -- the decision refresh of
+// a path level without the run-time tests of the general code's four slots (mz_step_jump.cuh, level_load); 0: any A
+template <bool GUMBEL, bool PAIRED, bool LDSTREE, int AS = 0>
 __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams p, const StepArgs s, const JumpArgs g,
                                                                const SearchLoop loop) {
   static_assert(!(GUMBEL && LDSTREE), "the Gumbel policy's decisions read the HBM tree (row_qtransform)");
@@ -88,27 +90,32 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   // the tree statistics of this root: rows of the handle's HBM tree, or their copy in LDS (half 0 / the single workgroup)
   TreeView T = tree_view_global(s, g, rb);
   const bool owns_tree = !PAIRED || h == 0;
+  int depth_acc = 0;  // LDSTREE: the selection depths of this launch (added to depth_sum[r] at its end)
   if constexpr (LDSTREE) {
+    // child records {index, visits, prior prob, reward, value} and node records {visits, value, JUMP parent | action,
+    // JUMP level}, interleaved: one address per (node, action) / node, the fields at immediate offsets
     int* tl = tree_lds + 17 * (s.S + 2);
     const int NA = N * A;
-    T.cidx = tl; T.cvis = tl + NA; T.prob = reinterpret_cast<float*>(tl + 2 * NA); T.rew = reinterpret_cast<float*>(tl + 3 * NA);
-    T.val = reinterpret_cast<float*>(tl + 4 * NA);
+    T.cs = 5; T.ns = 4;
+    T.cidx = tl; T.cvis = tl + 1; T.prob = reinterpret_cast<float*>(tl + 2); T.rew = reinterpret_cast<float*>(tl + 3);
+    T.val = reinterpret_cast<float*>(tl + 4);
     T.dis = nullptr; T.disc = loop.discount;
-    T.nvis = tl + 5 * NA; T.nval = reinterpret_cast<float*>(tl + 5 * NA + N); T.jpa = tl + 5 * NA + 2 * N; T.jlv = tl + 5 * NA + 3 * N;
+    int* nl = tl + 5 * NA;
+    T.nvis = nl; T.nval = reinterpret_cast<float*>(nl + 1); T.jpa = nl + 2; T.jlv = nl + 3;
     if (owns_tree) {
       const size_t o = rb * A;
       for (int i = tid; i < NA; i += 256) {
-        T.cidx[i] = s.children_index[o + i];
-        T.cvis[i] = s.children_visits[o + i];
-        T.prob[i] = s.children_prior_probs[o + i];
-        T.rew[i] = s.children_rewards[o + i];
-        T.val[i] = s.children_values[o + i];
+        T.cidx[5 * i] = s.children_index[o + i];
+        T.cvis[5 * i] = s.children_visits[o + i];
+        T.prob[5 * i] = s.children_prior_probs[o + i];
+        T.rew[5 * i] = s.children_rewards[o + i];
+        T.val[5 * i] = s.children_values[o + i];
       }
       for (int i = tid; i < N; i += 256) {
-        T.nvis[i] = s.node_visits[rb + i];
-        T.nval[i] = s.node_values[rb + i];
-        T.jpa[i] = g.jump_pa[rb + i];
-        T.jlv[i] = g.jump_lv[rb + i];
+        T.nvis[4 * i] = s.node_visits[rb + i];
+        T.nval[4 * i] = s.node_values[rb + i];
+        T.jpa[4 * i] = g.jump_pa[rb + i];
+        T.jlv[4 * i] = g.jump_lv[rb + i];
       }
       __syncthreads();
     }
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
   int newn;
   {
-    const int next = owns_tree ? T.cidx[parent * A + action] : s.children_index[(rb + parent) * A + action];
+    const int next = owns_tree ? T.cidx[(parent * A + action) * T.cs] : s.children_index[(rb + parent) * A + action];
     newn = next == -1 ? loop.sim_begin + 1 : next;
   }
   TowerIO io;
@@ -171,14 +178,14 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
 #ifndef MZ_SEARCH_LIF
 #define MZ_SEARCH_LIF kLevelsInFlight
 #endif
-      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true, nullptr,
-                                      nullptr, sel, known, prefetched, score_tbl);
+      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF, AS>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true,
+                                                         nullptr, nullptr, sel, known, prefetched, score_tbl, LDSTREE ? &depth_acc : nullptr);
       MZ_ST(2)
       if (more) {
         parent = sel[0];
         action = sel[1];
         depth = sel[2];
-        const int next = T.cidx[parent * A + action];
+        const int next = T.cidx[(parent * A + action) * T.cs];
         newn = next == -1 ? sim + 2 : next;
       }
       if constexpr (PAIRED) {
@@ -232,18 +239,19 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
       const size_t o = rb * A;
       const int NA = N * A;
       for (int i = tid; i < NA; i += 256) {
-        s.children_index[o + i] = T.cidx[i];
-        s.children_visits[o + i] = T.cvis[i];
-        s.children_prior_probs[o + i] = T.prob[i];
-        s.children_rewards[o + i] = T.rew[i];
-        s.children_values[o + i] = T.val[i];
+        s.children_index[o + i] = T.cidx[5 * i];
+        s.children_visits[o + i] = T.cvis[5 * i];
+        s.children_prior_probs[o + i] = T.prob[5 * i];
+        s.children_rewards[o + i] = T.rew[5 * i];
+        s.children_values[o + i] = T.val[5 * i];
       }
       for (int i = tid; i < N; i += 256) {
-        s.node_visits[rb + i] = T.nvis[i];
-        s.node_values[rb + i] = T.nval[i];
-        g.jump_pa[rb + i] = T.jpa[i];
-        g.jump_lv[rb + i] = T.jlv[i];
+        s.node_visits[rb + i] = T.nvis[4 * i];
+        s.node_values[rb + i] = T.nval[4 * i];
+        g.jump_pa[rb + i] = T.jpa[4 * i];
+        g.jump_lv[rb + i] = T.jlv[4 * i];
       }
+      if (tid == 0) s.depth_sum[r] += depth_acc;
     }
   }
   if constexpr (PAIRED) {
@@ -300,7 +308,8 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
   // the tree's statistics in LDS as well when they fit next to that (MuZero policy; MZS_SEARCH_LDS_TREE=0: A/B, tests)
   const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N);
   const char* lt = getenv("MZS_SEARCH_LDS_TREE");
-  const bool ldstree = policy != 1 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
+  const bool ldstree = policy != 1 && sa.A <= 32 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
+  const bool wide = sa.A > 16;  // (LDS-tree instances: one or two 16-lane slots of actions)
   if (ldstree) lds = lds_tree;
   if (sa.S + 1 > 4096 || sa.A > 255)
     return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: message T packs (node, action, node) as 12 + 8 + 12 bits");
@@ -316,19 +325,21 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
     p.pair_f = static_cast<float*>(a->pair_scratch);
     p.pair_u = reinterpret_cast<unsigned*>(p.pair_f + (size_t)a->batch * 4 * mz::kPairSlot * 2);  // (8-byte words)
     fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, true, false>)
-                : (ldstree ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true, true>)
+                : (ldstree ? (wide ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true, true, 2>)
+                                   : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true, true, 1>))
                            : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, true, false>));
     grid = dim3(16 * ((a->batch + 7) / 8));
   } else {
     fn = gumbel ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<true, false, false>)
-                : (ldstree ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false, true>)
+                : (ldstree ? (wide ? reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false, true, 2>)
+                                   : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false, true, 1>))
                            : reinterpret_cast<const void*>(mz::mz_resnet_search_kernel<false, false, false>));
     grid = dim3(a->batch);
   }
   {
     // raise the kernel's dynamic-LDS limit once per (instance, device) and size
-    static mzh::LdsGrant granted[6];
-    mzh::LdsGrant& have = granted[(gumbel ? 4 : (ldstree ? 2 : 0)) + (a->pair_scratch ? 1 : 0)];
+    static mzh::LdsGrant granted[8];
+    mzh::LdsGrant& have = granted[(gumbel ? 6 : (ldstree ? (wide ? 4 : 2) : 0)) + (a->pair_scratch ? 1 : 0)];
     if (!have.covers(a->device, lds)) {
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return mzh::fail_handle(h, MZS_E_RUNTIME, "mzs_resnet_search: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");

@@ -64,11 +64,14 @@ struct JumpArgs {
 // of a root its XCD streams 5.7 MB of convolution weights through a 4 MB L2, so every tree step used to find its ~260
 // cache lines evicted -- 4.5 of the 7 us of a 44-level decision refresh were memory round trips, not arithmetic.
 struct TreeView {
-  int* cidx; int* cvis; float* prob; float* rew; float* val;  // [N][A]
+  int* cidx; int* cvis; float* prob; float* rew; float* val;  // [N][A], element (node, a) at [(node * A + a) * cs]
   float* dis;    // [N][A] children_discounts, or nullptr: `disc` on every edge (an unexpanded child's value is +0, so
   float disc;    // rew + disc * val is the same +0 as with the array's 0 there)
-  int* nvis; float* nval;  // [N]
+  int* nvis; float* nval;  // [N], element `node` at [node * ns]
   int* jpa; int* jlv;      // [N]
+  // word strides: 1 / 1 for the HBM tree's separate arrays; the LDS copy interleaves the five words of a child and the
+  // four of a node (cs = 5, ns = 4): one address per (node, action), its fields at immediate offsets (ds_read2_b32)
+  int cs, ns;
 };
 MZ_DEV TreeView tree_view_global(const StepArgs& s, const JumpArgs& g, size_t rb) {
   const size_t o = rb * (size_t)s.A;
@@ -76,6 +79,7 @@ MZ_DEV TreeView tree_view_global(const StepArgs& s, const JumpArgs& g, size_t rb
   T.cidx = s.children_index + o; T.cvis = s.children_visits + o; T.prob = s.children_prior_probs + o;
   T.rew = s.children_rewards + o; T.val = s.children_values + o; T.dis = s.children_discounts + o; T.disc = 0.0f;
   T.nvis = s.node_visits + rb; T.nval = s.node_values + rb; T.jpa = g.jump_pa + rb; T.jlv = g.jump_lv + rb;
+  T.cs = 1; T.ns = 1;
   return T;
 }
 
@@ -89,25 +93,28 @@ struct LevelIn {
   int nvis, inv;  // inv: bit t = action j + 16 t is invalid at the root
   float nval;
 };
+// AS: 0 = any action count up to 16 kMaxAS (every 16-lane slot behind a run-time test), else the number of slots the
+// caller's action count fills (16 (AS - 1) < A <= 16 AS): the same operations without the dead slots' branches
+template <int AS = 0>
 MZ_DEV void level_load(const StepArgs& s, const TreeView& T, int r, int node, int j, LevelIn& L) {
   const int A = s.A;
   const int nb = node * A;
-  L.nvis = T.nvis[node];
-  L.nval = T.nval[node];
+  L.nvis = T.nvis[node * T.ns];
+  L.nval = T.nval[node * T.ns];
   L.inv = 0;
 #pragma unroll
-  for (int t = 0; t < kMaxAS; ++t) {
+  for (int t = 0; t < (AS ? AS : kMaxAS); ++t) {
     const int a = j + 16 * t;
     const bool ok = a < A;
     L.cidx[t] = -1; L.cvis[t] = 0; L.prob[t] = 0.0f; L.rew[t] = 0.0f; L.dis[t] = 0.0f; L.val[t] = 0.0f;
-    if (16 * t < A) {
+    if (AS || 16 * t < A) {
       const int o = nb + (ok ? a : 0);
-      L.cidx[t] = T.cidx[o];
-      L.cvis[t] = T.cvis[o];
-      L.prob[t] = T.prob[o];
-      L.rew[t] = T.rew[o];
-      L.dis[t] = T.dis ? T.dis[o] : T.disc;
-      L.val[t] = T.val[o];
+      L.cidx[t] = T.cidx[o * T.cs];
+      L.cvis[t] = T.cvis[o * T.cs];
+      L.prob[t] = T.prob[o * T.cs];
+      L.rew[t] = T.rew[o * T.cs];
+      L.dis[t] = T.dis ? T.dis[o * T.cs] : T.disc;
+      L.val[t] = T.val[o * T.cs];
       if (node == 0 && ok && s.root_invalid[(size_t)r * A + a]) L.inv |= 1 << t;  // the root is level 0 only
     }
   }
@@ -116,18 +123,20 @@ MZ_DEV void level_load(const StepArgs& s, const TreeView& T, int r, int node, in
 // for a whole search (mz_search_conv.hip) -- the same puct_scale() values, and x / n by Markstein's exact sequence for
 // n <= 300 (div_small, mz_fused.cuh; tests/test_oracle_kat.py): the refresh of a path's decisions is arithmetic-bound,
 // a log, a sqrt and three of its four IEEE divisions per level go
+template <int AS = 0>
 MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc)[kMaxAS], int& best, int& child,
                           bool& near, const float* tbl = nullptr) {
+  constexpr int NSLOT = AS ? AS : kMaxAS;
   const int A = s.A;
   const float nval = L.nval;
   const float tn = tbl ? tbl[2 * L.nvis] : puct_scale(L.nvis, s.pb_c_init, s.pb_c_base);
   float q[kMaxAS];
   float lo = nval, hi = nval;
 #pragma unroll
-  for (int t = 0; t < kMaxAS; ++t) {
+  for (int t = 0; t < NSLOT; ++t) {
     const bool ok = j + 16 * t < A;
     q[t] = 0.0f;
-    if (16 * t < A) {
+    if (AS || 16 * t < A) {
       q[t] = L.rew[t] + L.dis[t] * L.val[t];
       const float safe = (ok && L.cvis[t] > 0) ? q[t] : nval;
       lo = fminf(lo, safe);
@@ -141,11 +150,11 @@ MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc
   best = 1 << 20;
   child = -1;
 #pragma unroll
-  for (int t = 0; t < kMaxAS; ++t) {
+  for (int t = 0; t < NSLOT; ++t) {
     const int a = j + 16 * t;
     const bool ok = a < A;
     sc[t] = -INFINITY;
-    if (16 * t < A) {
+    if (AS || 16 * t < A) {
       const float value_score = ((L.cvis[t] > 0 ? q[t] : lo) - lo) / span;
       float policy_score;
       if (tbl) {
@@ -166,7 +175,7 @@ MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc
   bool unsafe = false;
   if (s.tiebreak) {
 #pragma unroll
-    for (int t = 0; t < kMaxAS; ++t) {
+    for (int t = 0; t < NSLOT; ++t) {
       const int a = j + 16 * t;
       unsafe = unsafe || (a < A && a != best && !((sc[t] + 1e-7f) < bscore));
     }
@@ -307,8 +316,8 @@ MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, const TreeVie
       row_argmax<4>(bscore, best, child);
       action = best;
       if (child >= 0 && level + 1 < s.max_depth) {
-        jw = T.jpa[child];
-        level = T.jlv[child];
+        jw = T.jpa[child * T.ns];
+        level = T.jlv[child * T.ns];
         continue;
       }
     }
@@ -326,7 +335,7 @@ MZ_DEV void jump_select_core(const StepArgs& s, const JumpArgs& g, const TreeVie
 // `parent_embedding_out` == nullptr: no gather (the caller reads the tree's embedding row in place)
 template <bool WG>
 MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int32_t* action_out,
-                             float* parent_embedding_out, int* sel_out = nullptr) {
+                             float* parent_embedding_out, int* sel_out = nullptr, int* depth_acc = nullptr) {
   const int j = threadIdx.x & 15;
   const int N = s.N, E = s.E;
   const size_t rb = (size_t)r * N;
@@ -337,7 +346,8 @@ MZ_DEV void jump_select_body(const StepArgs& s, const JumpArgs& g, const TreeVie
     s.sel_parent[r] = parent;
     s.sel_action[r] = action;
     s.sel_depth[r] = depth;
-    s.depth_sum[r] += depth;
+    if (depth_acc) *depth_acc += depth;
+    else s.depth_sum[r] += depth;
     if (action_out) action_out[r] = action;
     if (WG) s.xfer_node[r] = parent;
   }
@@ -411,20 +421,23 @@ MZ_DEV void jump_prefetch_path(const StepArgs& s, const JumpArgs& g, int r, cons
 MZ_DEV void jump_prefetch_levels(const StepArgs& s, const TreeView& T, const JumpLds& L, int tid, int nthr, int depth) {
   for (int e = tid; e < depth; e += nthr) {
     const int e2 = L.pn[e] * s.A + L.pa[e];
-    L.cnt[e] = T.nvis[L.pn[e]];
-    L.val[e] = T.nval[L.pn[e]];
-    L.rw[e] = (e == depth - 1) ? 0.0f : T.rew[e2];
-    L.ds[e] = (e == depth - 1) ? 0.0f : (T.dis ? T.dis[e2] : T.disc);  // (levels above the last edge are expanded edges)
+    L.cnt[e] = T.nvis[(L.pn[e]) * T.ns];
+    L.val[e] = T.nval[(L.pn[e]) * T.ns];
+    L.rw[e] = (e == depth - 1) ? 0.0f : T.rew[e2 * T.cs];
+    L.ds[e] = (e == depth - 1) ? 0.0f : (T.dis ? T.dis[e2 * T.cs] : T.disc);  // (levels above the last edge are expanded edges)
   }
 }
 
 // `prefetched`: bit 0 = jump_prefetch_path, bit 1 = jump_prefetch_levels have run for this simulation (and a barrier since)
-template <bool GUMBEL, int LIF = kLevelsInFlight>
+// AS: see level_load (0: any action count); `depth_acc` != nullptr: the next selection's depth is added there (a register
+// of the caller, who owns depth_sum[r] for the launch) instead of to the HBM word -- a load-add-store round trip per
+// simulation on the caller's critical path otherwise
+template <bool GUMBEL, int LIF = kLevelsInFlight, int AS = 0>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
                                     int* sel_out = nullptr, const int* known = nullptr, int prefetched = 0,
-                                    const float* score_tbl = nullptr) {
+                                    const float* score_tbl = nullptr, int* depth_acc = nullptr) {
   const int tid = opaque_tid(), j = tid & 15, row = tid >> 4;
   MZ_JT_BEGIN
   const int nthr = blockDim.x, nrows = blockDim.x >> 4;  // 1024 / 256 threads (64 / 16 levels in flight) or one wavefront (4)
@@ -436,7 +449,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
   const int depth = known ? known[2] : s.sel_depth[r];
   const size_t eo = (rb + parent) * A + action;
   const int eol = parent * A + action;
-  const int next = known ? (known[3] == sim + 1 ? -1 : known[3]) : T.cidx[eol];
+  const int next = known ? (known[3] == sim + 1 ? -1 : known[3]) : T.cidx[eol * T.cs];
   __syncthreads();  // every thread has read the edge before row 0 rewrites it
   const bool fresh = next == -1;
   const int newn = fresh ? sim + 1 : next;
@@ -462,16 +475,16 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
       const int a = j + 16 * t;
       if (a < A) {
         s.children_prior_logits[(rb + newn) * A + a] = x[t];
-        T.prob[newn * A + a] = pr[t];
+        T.prob[(newn * A + a) * T.cs] = pr[t];
       }
     }
     if (j == 0) {
       s.raw_values[rb + newn] = v;
-      T.nval[newn] = v;
-      T.nvis[newn] = T.nvis[newn] + 1;
-      T.cidx[eol] = newn;
-      T.rew[eol] = rew_new;
-      s.children_discounts[eo] = dis_new;  // (== T.dis[eol] when the view is the HBM tree)
+      T.nval[newn * T.ns] = v;
+      T.nvis[newn * T.ns] = T.nvis[newn * T.ns] + 1;
+      T.cidx[eol * T.cs] = newn;
+      T.rew[eol * T.cs] = rew_new;
+      s.children_discounts[eo] = dis_new;  // (== T.dis[eol * T.cs] when the view is the HBM tree)
       s.parents[rb + newn] = parent;
       s.action_from_parent[rb + newn] = action;
       s.xfer_node[r] = newn;
@@ -503,13 +516,17 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
       const int e = 63 * c + tid;
       const int cn = min(63, depth - 63 * c);
       const bool mine = tid < cn;
-      const float rr = mine ? rw[e] : 0.0f, dd = mine ? ds[e] : 0.0f;
-      float X = G;
-      for (int k = 0; k < cn; ++k) {
-        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), 0x130, 0xf, 0xf, false));  // wave_shl:1
-        const float t = rr + dd * up;
-        X = mine ? t : G;
-      }
+      // lanes past the chunk's levels run identity steps on the value arriving from below: (-0) + 1 * x == x for every x
+      // (until round 6 a select per step kept them at G; the loop compiled to ~100 cycles a level)
+      const float rr = mine ? rw[e] : -0.0f, dd = mine ? ds[e] : 1.0f;
+      float X = G, Xt = dd * G;  // (lane 63 has no lane above it: its Xt stays dd * G = G through every step)
+      // four steps per statement: the DPP source X is the register the add before it has just written -- two wait
+      // states (s_nop 1), which the hazard recogniser does not insert inside asm.  A level is final after (levels of
+      // the chunk - e) steps and a further step maps it onto itself, so the count is rounded up to a multiple of four.
+#define MZ_CSTEP "s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32 %1, %0, %3\n\t"
+      for (int k = 0; k < cn; k += 4)
+        asm volatile(MZ_CSTEP MZ_CSTEP MZ_CSTEP MZ_CSTEP : "+v"(Xt), "+v"(X) : "v"(dd), "v"(rr));
+#undef MZ_CSTEP
       if (mine) Gs[e] = X;
       G = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(X)));  // arrival at the chunk's first level
     }
@@ -521,10 +538,10 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
   __syncthreads();
   for (int e = tid; e < depth; e += nthr) {
     const int e2 = pn[e] * A + pa[e];
-    T.nval[pn[e]] = nv[e];
-    T.nvis[pn[e]] = cnt[e] + 1;
-    T.val[e2] = nv[e + 1];
-    T.cvis[e2] = T.cvis[e2] + 1;
+    T.nval[(pn[e]) * T.ns] = nv[e];
+    T.nvis[(pn[e]) * T.ns] = cnt[e] + 1;
+    T.val[e2 * T.cs] = nv[e + 1];
+    T.cvis[e2 * T.cs] = T.cvis[e2 * T.cs] + 1;
   }
   __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
   MZ_JT(3)
@@ -543,8 +560,8 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
             chd[e] = child;
             flg[e] = near ? 1 : 0;
             const bool off_path = child >= 0 && !(e < depth && child == pn[e + 1]);
-            cjp[e] = off_path ? T.jpa[child] : 0;
-            cjl[e] = off_path ? T.jlv[child] : 0;
+            cjp[e] = off_path ? T.jpa[child * T.ns] : 0;
+            cjl[e] = off_path ? T.jlv[child * T.ns] : 0;
           }
         }
       }
@@ -555,7 +572,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
 #pragma unroll
       for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
-        level_load(s, T, r, pn[e <= depth ? e : depth], j, L[u]);
+        level_load<AS>(s, T, r, pn[e <= depth ? e : depth], j, L[u]);
       }
 #ifdef MZ_PROF_DECIDE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -565,13 +582,13 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
       for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
         float sc[kMaxAS];
-        level_compute(s, j, L[u], sc, bestu[u], childu[u], nearu[u], score_tbl);
+        level_compute<AS>(s, j, L[u], sc, bestu[u], childu[u], nearu[u], score_tbl);
         offu[u] = e <= depth && childu[u] >= 0 && !(e < depth && childu[u] == pn[e + 1]);
       }
 #pragma unroll
       for (int u = 0; u < LIF; ++u) {  // the off-path children's stored records, all requested together
-        cj[u] = offu[u] ? T.jpa[childu[u]] : 0;
-        cl[u] = offu[u] ? T.jlv[childu[u]] : 0;
+        cj[u] = offu[u] ? T.jpa[(childu[u]) * T.ns] : 0;
+        cl[u] = offu[u] ? T.jlv[(childu[u]) * T.ns] : 0;
       }
 #pragma unroll
       for (int u = 0; u < LIF; ++u) {
@@ -610,14 +627,14 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     }
     for (int e = tid; e <= depth; e += nthr) {
       const int from = src[e];
-      T.jpa[pn[e]] = njp[from];
-      T.jlv[pn[e]] = njl[from];
+      T.jpa[(pn[e]) * T.ns] = njp[from];
+      T.jlv[(pn[e]) * T.ns] = njl[from];
     }
   }
   MZ_JT(5)
   if (select_next && sim + 1 < s.S) {
     __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
-    jump_select_body<true>(s, g, T, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out);
+    jump_select_body<true>(s, g, T, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out, depth_acc);
   }
   MZ_JT(6)
 }

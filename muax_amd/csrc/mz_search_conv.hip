@@ -102,6 +102,14 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
     T.dis = nullptr; T.disc = loop.discount;
     int* nl = tl + 5 * NA;
     T.nvis = nl; T.nval = reinterpret_cast<float*>(nl + 1); T.jpa = nl + 2; T.jlv = nl + 3;
+    // root_invalid_actions of this lane's two action slots, once per launch (the root is refreshed every simulation)
+    T.inv_bits = 0;
+    if (owns_tree) {
+      const int j = tid & 15;
+#pragma unroll
+      for (int t = 0; t < AS; ++t)
+        if (j + 16 * t < A && s.root_invalid[(size_t)r * A + j + 16 * t]) T.inv_bits |= 1 << t;
+    }
     if (owns_tree) {
       const size_t o = rb * A;
       for (int i = tid; i < NA; i += 256) {
@@ -131,6 +139,14 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   io.reward = p.reward + r;
   io.value = p.value + r;
   io.prior_logits = p.prior_logits + (size_t)r * A;
+  if constexpr (LDSTREE) {
+    // reward / value / prior logits of a pass go from the heads to the tree step of the SAME workgroup: through LDS
+    // (behind the node records), not through an HBM word and back (two L2 round trips per simulation)
+    float* hs = reinterpret_cast<float*>(tree_lds + 17 * (s.S + 2) + 5 * N * A + 4 * N);
+    io.reward = hs;
+    io.value = hs + 1;
+    io.prior_logits = hs + 2;
+  }
 #ifdef MZ_PROFILE
   unsigned long long st[4] = {0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
 #define MZ_ST(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - tl; tl = t_; }
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
 #ifndef MZ_SEARCH_LIF
 #define MZ_SEARCH_LIF kLevelsInFlight
 #endif
-      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF, AS>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true,
+      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF, AS, LDSTREE>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true,
                                                          nullptr, nullptr, sel, known, prefetched, score_tbl, LDSTREE ? &depth_acc : nullptr);
       MZ_ST(2)
       if (more) {
@@ -306,9 +322,9 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
   size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 17 * ((size_t)sa.S + 2);  // (15 arrays of the tree step + the score table)
   if (lds > 160 * 1024) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: num_simulations too large for the LDS of a CU");
   // the tree's statistics in LDS as well when they fit next to that (MuZero policy; MZS_SEARCH_LDS_TREE=0: A/B, tests)
-  const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N);
+  const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N + 2 + (size_t)sa.A);
   const char* lt = getenv("MZS_SEARCH_LDS_TREE");
-  const bool ldstree = policy != 1 && sa.A <= 32 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
+  const bool ldstree = policy != 1 && sa.A <= 32 && sa.S + 2 <= 300 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
   const bool wide = sa.A > 16;  // (LDS-tree instances: one or two 16-lane slots of actions)
   if (ldstree) lds = lds_tree;
   if (sa.S + 1 > 4096 || sa.A > 255)

@@ -240,7 +240,8 @@ MZ_DEV void row_argmax(float& score, int& idx, int& payload) {
     float os = dpp_f<Bfly<s>::ctrl>(score);
     int oi = dpp_i<Bfly<s>::ctrl>(idx);
     int op = dpp_i<Bfly<s>::ctrl>(payload);
-    bool take = (os > score) || (os == score && oi < idx);
+    // (bitwise, not short-circuit: the compiler turned the || / && form into exec-masked branches around three moves)
+    const bool take = (os > score) | ((os == score) & (oi < idx));
     score = take ? os : score;
     idx = take ? oi : idx;
     payload = take ? op : payload;

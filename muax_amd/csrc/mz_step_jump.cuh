@@ -72,6 +72,9 @@ struct TreeView {
   // word strides: 1 / 1 for the HBM tree's separate arrays; the LDS copy interleaves the five words of a child and the
   // four of a node (cs = 5, ns = 4): one address per (node, action), its fields at immediate offsets (ds_read2_b32)
   int cs, ns;
+  // root_invalid_actions of this lane's actions (bit t: action j + 16 t), read once by a caller that lives for a whole
+  // search; -1: level_load reads s.root_invalid whenever it meets the root (a global round trip in front of the scores)
+  int inv_bits;
 };
 MZ_DEV TreeView tree_view_global(const StepArgs& s, const JumpArgs& g, size_t rb) {
   const size_t o = rb * (size_t)s.A;
@@ -79,7 +82,7 @@ MZ_DEV TreeView tree_view_global(const StepArgs& s, const JumpArgs& g, size_t rb
   T.cidx = s.children_index + o; T.cvis = s.children_visits + o; T.prob = s.children_prior_probs + o;
   T.rew = s.children_rewards + o; T.val = s.children_values + o; T.dis = s.children_discounts + o; T.disc = 0.0f;
   T.nvis = s.node_visits + rb; T.nval = s.node_values + rb; T.jpa = g.jump_pa + rb; T.jlv = g.jump_lv + rb;
-  T.cs = 1; T.ns = 1;
+  T.cs = 1; T.ns = 1; T.inv_bits = -1;
   return T;
 }
 
@@ -115,21 +118,23 @@ MZ_DEV void level_load(const StepArgs& s, const TreeView& T, int r, int node, in
       L.rew[t] = T.rew[o * T.cs];
       L.dis[t] = T.dis ? T.dis[o * T.cs] : T.disc;
       L.val[t] = T.val[o * T.cs];
-      if (node == 0 && ok && s.root_invalid[(size_t)r * A + a]) L.inv |= 1 << t;  // the root is level 0 only
+      if (T.inv_bits < 0 && node == 0 && ok && s.root_invalid[(size_t)r * A + a]) L.inv |= 1 << t;  // the root is level 0 only
     }
   }
+  if (T.inv_bits >= 0 && node == 0) L.inv = T.inv_bits;
 }
 // `tbl` (optional, LDS): {sqrt(n) pb_c(n), RN(1 / n)} for n = 0 .. S + 1, built once per launch by a kernel that lives
 // for a whole search (mz_search_conv.hip) -- the same puct_scale() values, and x / n by Markstein's exact sequence for
 // n <= 300 (div_small, mz_fused.cuh; tests/test_oracle_kat.py): the refresh of a path's decisions is arithmetic-bound,
 // a log, a sqrt and three of its four IEEE divisions per level go
-template <int AS = 0>
+// TBL: `tbl` is there (the caller's launch built it): no code for the other case
+template <int AS = 0, bool TBL = false>
 MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc)[kMaxAS], int& best, int& child,
                           bool& near, const float* tbl = nullptr) {
   constexpr int NSLOT = AS ? AS : kMaxAS;
   const int A = s.A;
   const float nval = L.nval;
-  const float tn = tbl ? tbl[2 * L.nvis] : puct_scale(L.nvis, s.pb_c_init, s.pb_c_base);
+  const float tn = (TBL || tbl) ? tbl[2 * L.nvis] : puct_scale(L.nvis, s.pb_c_init, s.pb_c_base);
   float q[kMaxAS];
   float lo = nval, hi = nval;
 #pragma unroll
@@ -149,15 +154,34 @@ MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc
   float bscore = -INFINITY;
   best = 1 << 20;
   child = -1;
+  // two slots of actions: the lane's two value scores share their denominator -- ONE refined reciprocal and the
+  // hardware's own quotient correction on the packed pair (div_newton2, mz_spec.cuh: the IEEE quotient while every
+  // numerator is 0 or >= 2^-100 and the span is below 2^100; a wave-uniform test, the IEEE divisions otherwise) as in
+  // the fused kernel's puct_scores: 12 instructions instead of 26
+  [[maybe_unused]] f32x2 vs2 = splat2(0.0f);
+  [[maybe_unused]] bool have_vs2 = false;
+  if constexpr (AS == 2) {
+    const float n0 = (L.cvis[0] > 0 ? q[0] : lo) - lo, n1 = (L.cvis[1] > 0 ? q[1] : lo) - lo;
+    const uint32_t low = min(f2u(n0) - 1u, f2u(n1) - 1u);  // 0 wraps to the top: only (0, 2^-100) fails the test
+    const bool risky = (low < f2u(0x1p-100f) - 1u) | !(span < 0x1p100f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(risky) == 0, 1)) {
+      const float y0 = __builtin_amdgcn_rcpf(span);
+      const float y = __builtin_fmaf(__builtin_fmaf(-span, y0, 1.0f), y0, y0);
+      vs2 = div_newton2((f32x2){n0, n1}, splat2(span), splat2(y));
+      have_vs2 = true;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NSLOT; ++t) {
     const int a = j + 16 * t;
     const bool ok = a < A;
     sc[t] = -INFINITY;
     if (AS || 16 * t < A) {
-      const float value_score = ((L.cvis[t] > 0 ? q[t] : lo) - lo) / span;
+      float value_score;
+      if (AS == 2 && have_vs2) value_score = t == 0 ? vs2.x : vs2.y;
+      else value_score = ((L.cvis[t] > 0 ? q[t] : lo) - lo) / span;
       float policy_score;
-      if (tbl) {
+      if (TBL || tbl) {
         const float x = tn * L.prob[t], d = (float)(L.cvis[t] + 1), y = tbl[2 * (L.cvis[t] + 1) + 1];
         const float q0 = x * y;
         policy_score = __builtin_fmaf(__builtin_fmaf(-q0, d, x), y, q0);
@@ -177,7 +201,7 @@ MZ_DEV void level_compute(const StepArgs& s, int j, const LevelIn& L, float (&sc
 #pragma unroll
     for (int t = 0; t < NSLOT; ++t) {
       const int a = j + 16 * t;
-      unsafe = unsafe || (a < A && a != best && !((sc[t] + 1e-7f) < bscore));
+      unsafe = unsafe | ((a < A) & (a != best) & !((sc[t] + 1e-7f) < bscore));
     }
   }
   near = ((__builtin_amdgcn_ballot_w64(unsafe) >> (threadIdx.x & 48)) & 0xffffull) != 0;  // any lane of the row
@@ -432,7 +456,7 @@ MZ_DEV void jump_prefetch_levels(const StepArgs& s, const TreeView& T, const Jum
 // AS: see level_load (0: any action count); `depth_acc` != nullptr: the next selection's depth is added there (a register
 // of the caller, who owns depth_sum[r] for the launch) instead of to the HBM word -- a load-add-store round trip per
 // simulation on the caller's critical path otherwise
-template <bool GUMBEL, int LIF = kLevelsInFlight, int AS = 0>
+template <bool GUMBEL, int LIF = kLevelsInFlight, int AS = 0, bool TBL = false>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
@@ -582,7 +606,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
       for (int u = 0; u < LIF; ++u) {
         const int e = base + u * nrows + row;
         float sc[kMaxAS];
-        level_compute<AS>(s, j, L[u], sc, bestu[u], childu[u], nearu[u], score_tbl);
+        level_compute<AS, TBL>(s, j, L[u], sc, bestu[u], childu[u], nearu[u], score_tbl);
         offu[u] = e <= depth && childu[u] >= 0 && !(e < depth && childu[u] == pn[e + 1]);
       }
 #pragma unroll
@@ -617,7 +641,19 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     nxa[e] = inherit ? e + 1 : e;
   }
   __syncthreads();
-  {
+  if (depth < 64) {
+    // the whole path in one wavefront: lane e chases its pointer through ds_bpermute (a register exchange: no LDS
+    // array, no barrier per round -- six rounds of ~100 cycles instead of six workgroup barriers)
+    if (tid < 64) {
+      const int e = tid <= depth ? tid : depth;
+      int from = nxa[e];
+      for (int span = 1; span <= depth; span <<= 1) from = __builtin_amdgcn_ds_bpermute(4 * from, from);
+      if (tid <= depth) {
+        T.jpa[(pn[e]) * T.ns] = njp[from];
+        T.jlv[(pn[e]) * T.ns] = njl[from];
+      }
+    }
+  } else {
     int* src = nxa;
     int* dst = nxb;
     for (int span = 1; span <= depth; span <<= 1) {

@@ -690,8 +690,15 @@ MZ_DEV void reward_head(const TowerParams& p, const TowerIO& io, const float* in
   reward_finish(p, io, H, sacc, tid, lane, wave);
 }
 // prediction heads on the normalised next state held in `cur` (haloed map)
+// `side(k)`, k = 0, 1: work of the CALLER for wave 3, run while waves 0 / 1 are in the first 1x1 convolutions (k = 0: the
+// longest stretch of the heads, during which waves 2 and 3 have nothing to do) and while wave 0 is in the value head's
+// second convolution (k = 1) -- pair mode hangs the reward head's tail there (round 6)
+struct NoSideWork {
+  MZ_DEV void operator()(int) const {}
+};
+template <class Side = NoSideWork>
 MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const float* cur, const HeadLds& H, const int (&rowc)[3],
-                             int tid, int lane, int wave MZ_TH_PARAMS) {
+                             int tid, int lane, int wave MZ_TH_PARAMS, Side&& side = Side()) {
   const int g4 = lane >> 4, n16 = lane & 15;
   // the weights of the last layers do not depend on the map: requested here, before the 1x1 convolutions and their
   // barriers (a barrier is a fence: the compiler cannot hoist them itself).  The flatten -> Linear(576 -> 16) matrices were
@@ -720,9 +727,12 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
         const int px = 16 * mt + 4 * g4 + v;
         if (px < kTowerPix) dst[px * 16 + n16] = fmaxf(h[mt][v], 0.0f);
       }
+  } else if (wave == 3) {
+    side(0);
   }
   __syncthreads();
   MZ_TH(6)
+  if (wave == 3) side(1);
   if (wave == 0) {  // value head: second 1x1 conv (16 -> 16) + relu
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
@@ -1135,9 +1145,17 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
         // (the head's tail -- 4 barriers, ~1.5 us -- was also tried inside idle pass 9: it costs the pass what it saves
         // here, and the stand-alone pass kernel 8 us: profiles/r04_search_phases.txt)
         for (; rh_k < 9; ++rh_k) reward_linear_pixel(p, rhmap + (9 * wave + rh_k) * kTowerC, 9 * wave + rh_k, lane, rh_acc);
-        __syncthreads();
-        reward_finish(p, io, H, rh_acc, tid, lane, wave);
+        __syncthreads();  // (every wave is done with rhmap: its words become the scratch of the reward head's tail)
       }
+      // Round 6: the reward head's tail (four waves' partial sums -> hidden vector -> logits -> support decode:
+      // reward_finish, four barriers, 1.6 us in front of the prediction heads) runs on WAVE 3 inside the prediction
+      // heads' own barrier intervals -- the vector while the channel (min, scale) pairs are published, the logits while
+      // waves 0 / 1 are in the heads' first 1x1 convolutions, the decode during the value head's second one.  Same
+      // operations in the same order on other lanes: the same reward, bit for bit.
+      float* rpart = rhmap;        // [256] the four waves' partial sums (rhmap is dead by now)
+      float* rvec = rhmap + 256;   // [64]
+      float* rlgt = rhmap + 320;   // [64]
+      if constexpr (TSEL == 1) rpart[tid] = rh_acc;
       MZ_TH(3)
       // ---- prediction heads on the normalised next state ----
       store_map<TSEL>(acc, cur, ch, lane);
@@ -1149,6 +1167,8 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
           cmn[ch] = mn;
           cmn[kTowerC + ch] = scale;
         }
+        if (wave == 3)
+          rvec[lane] = fmaxf(((rpart[lane] + rpart[64 + lane]) + (rpart[128 + lane] + rpart[192 + lane])) + p.r_b1[lane], 0.0f);
         __syncthreads();
         {
           // (five words a thread: all five loads in flight at once; a copy that is not message C yet is polled)
@@ -1165,7 +1185,23 @@ MZ_DEV void tower_body(const TowerParams& p, const TowerIO& io, float* lds, Pair
       }
       __syncthreads();
       MZ_TH(4)
-      prediction_heads(p, io, cur, H, rowc, tid, lane, wave MZ_TH_ARGS);
+      if constexpr (TSEL == 1) {
+        auto reward_tail = [&](int k) {  // (wave 3 only)
+          if (k == 0) {
+            if (lane < p.F) {
+              float a = 0.0f;
+              for (int q = 0; q < 64; ++q) a = __builtin_fmaf(rvec[q], p.r_l2[q * p.F + lane], a);
+              rlgt[lane] = a + p.r_b2[lane];
+            }
+          } else {
+            const float rw = decode_support(rlgt, p.F, p.support, lane);  // (the lanes' own writes: same wave, LDS in order)
+            if (lane == 0) *io.reward = rw;
+          }
+        };
+        prediction_heads(p, io, cur, H, rowc, tid, lane, wave MZ_TH_ARGS, reward_tail);
+      } else {
+        prediction_heads(p, io, cur, H, rowc, tid, lane, wave MZ_TH_ARGS);
+      }
     }
   }
   MZ_TT(11)

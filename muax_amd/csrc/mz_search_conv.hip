@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
 #ifndef MZ_SEARCH_LIF
 #define MZ_SEARCH_LIF kLevelsInFlight
 #endif
-      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF, AS, LDSTREE>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true,
+      jump_expand_backup_body<GUMBEL, MZ_SEARCH_LIF, AS, LDSTREE, LDSTREE>(s, g, T, sim, r, tree_lds, rew, loop.discount, io.prior_logits, val, nullptr, true,
                                                          nullptr, nullptr, sel, known, prefetched, score_tbl, LDSTREE ? &depth_acc : nullptr);
       MZ_ST(2)
       if (more) {

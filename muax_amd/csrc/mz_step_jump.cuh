@@ -456,7 +456,15 @@ MZ_DEV void jump_prefetch_levels(const StepArgs& s, const TreeView& T, const Jum
 // AS: see level_load (0: any action count); `depth_acc` != nullptr: the next selection's depth is added there (a register
 // of the caller, who owns depth_sum[r] for the launch) instead of to the HBM word -- a load-add-store round trip per
 // simulation on the caller's critical path otherwise
-template <bool GUMBEL, int LIF = kLevelsInFlight, int AS = 0, bool TBL = false>
+// LDSB: every array the phases of this step hand to one another is in LDS (the LDS tree of the one-launch search): its
+// barriers wait for the LDS queue only (s_waitcnt lgkmcnt(0); s_barrier) -- a __syncthreads() also drains vmcnt, i.e.
+// waits for the acknowledgement of the write-only HBM stores (prior logits, parents, the selection ...) issued just before
+template <bool LDSB>
+MZ_DEV void step_barrier() {
+  if constexpr (LDSB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+template <bool GUMBEL, int LIF = kLevelsInFlight, int AS = 0, bool TBL = false, bool LDSB = false>
 MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const TreeView& T, int sim, int r, int* lds_i, float rew_new,
                                     float dis_new, const float* prior_logits_row, float v, const float* next_embedding_row,
                                     bool select_next, int32_t* next_action_out, float* next_parent_embedding_out,
@@ -517,7 +525,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
   // (a whole workgroup per root: wide rows need no separate transfer kernel here)
   if (next_embedding_row != nullptr)
     for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding_row[i];
-  __syncthreads();
+  step_barrier<LDSB>();
   MZ_JT(0)
   // -- per-level inputs of the backward pass --
   if (!(prefetched & 2)) jump_prefetch_levels(s, T, JL, tid, nthr, depth);
@@ -525,7 +533,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     rw[depth - 1] = rew_new;
     ds[depth - 1] = dis_new;
   }
-  __syncthreads();
+  step_barrier<LDSB>();
   MZ_JT(1)
   // -- leaf_value = reward + discount * leaf_value, leaf to root (the one sequential chain) --
   // One wavefront, 63 levels per chunk, every lane its own level: one step is X[e] = r[e] + d[e] * X[e + 1] on all
@@ -555,11 +563,11 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
       G = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(X)));  // arrival at the chunk's first level
     }
   }
-  __syncthreads();
+  step_barrier<LDSB>();
   MZ_JT(2)
   for (int e = tid; e <= depth; e += nthr)
     nv[e] = (e == depth) ? v : (val[e] * (float)cnt[e] + Gs[e]) / ((float)cnt[e] + 1.0f);
-  __syncthreads();
+  step_barrier<LDSB>();
   for (int e = tid; e < depth; e += nthr) {
     const int e2 = pn[e] * A + pa[e];
     T.nval[(pn[e]) * T.ns] = nv[e];
@@ -567,7 +575,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     T.val[e2 * T.cs] = nv[e + 1];
     T.cvis[e2 * T.cs] = T.cvis[e2 * T.cs] + 1;
   }
-  __syncthreads();  // (workgroup-scope: the refreshed statistics are visible to every row below)
+  step_barrier<LDSB>();  // (workgroup-scope: the refreshed statistics are visible to every row below)
   MZ_JT(3)
   // -- decisions of the path nodes and the leaf: one row per level, LIF (kLevelsInFlight) levels per row at once (all
   // their loads are issued before the first is used: a deep path costs one memory round trip, not one per 64 levels) --
@@ -627,7 +635,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
       }
     }
   }
-  __syncthreads();
+  step_barrier<LDSB>();
   MZ_JT(4)
   // -- JUMP records: a level takes its own end point (near tie, or an unexpanded best child), the stored record of
   // its off-path best child, or -- when its best child is the next level of this very path -- whatever that level
@@ -640,7 +648,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     njl[e] = own ? e : cjl[e];
     nxa[e] = inherit ? e + 1 : e;
   }
-  __syncthreads();
+  step_barrier<LDSB>();
   if (depth < 64) {
     // the whole path in one wavefront: lane e chases its pointer through ds_bpermute (a register exchange: no LDS
     // array, no barrier per round -- six rounds of ~100 cycles instead of six workgroup barriers)
@@ -658,7 +666,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     int* dst = nxb;
     for (int span = 1; span <= depth; span <<= 1) {
       for (int e = tid; e <= depth; e += nthr) dst[e] = src[src[e]];
-      __syncthreads();
+      step_barrier<LDSB>();
       int* t = src; src = dst; dst = t;
     }
     for (int e = tid; e <= depth; e += nthr) {
@@ -669,7 +677,7 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
   }
   MZ_JT(5)
   if (select_next && sim + 1 < s.S) {
-    __syncthreads();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
+    step_barrier<LDSB>();  // the refreshed records (and, above, the statistics a near-tie evaluation reads) are visible
     jump_select_body<true>(s, g, T, sim + 1, r, next_action_out, next_parent_embedding_out, sel_out, depth_acc);
   }
   MZ_JT(6)

@@ -20,7 +20,8 @@ every capture is one `model._plan(params, key, obs, ...)` call -- root inference
 `mctx.gumbel_muzero_policy`, returned `(PolicyOutput, root.value)` -- and the PRNG intermediates are re-drawn with plain
 jax.random calls along mctx's key walk so that sampler and search can be checked separately.
 
-Captured (SURVEY.md 8(c)): seeds {0, 1, 2} x {CartPole shapes A=2, E=8, obs 4 at num_simulations 1 / 10 / 50;
+Captured: seeds {0, 1, 2} x {CartPole shapes A=2, E=8, obs 4 at num_simulations 1 / 10 / 50 (+ 160 and a
+twelve-action trio at seed 0, round 6: the HIP side's LONG / wide instances);
 LunarLander shapes A=4, E=32, obs 8 at 50}, B = 8; Gumbel MuZero on both shapes with both qtransforms (seed 0); one
 checkpoint written by the reference's own save (muax/model.py:203-212) with the flattened weights beside it; when
 gymnasium is importable, 20 CartPole-v1 steps of the fit loop's act() calls (muax/train.py:153-170); and one case of the
@@ -42,7 +43,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import mctx_fixture as fx  # noqa: E402
 
-SHAPES = {"cartpole": dict(obs_dim=4, E=8, A=2), "lunarlander": dict(obs_dim=8, E=32, A=4)}
+SHAPES = {"cartpole": dict(obs_dim=4, E=8, A=2), "lunarlander": dict(obs_dim=8, E=32, A=4),
+          # round 6: twelve actions -- on the HIP side an on-demand instance that keeps all of a node's scores in one lane
+          "wide12": dict(obs_dim=4, E=8, A=12)}
 SUPPORT = 10
 TIEBREAK_LEVELS = 12
 
@@ -387,6 +390,14 @@ def main():
     for name in ("cartpole", "lunarlander"):
         for qt in ("qtransform_by_parent_and_siblings", "qtransform_completed_by_mix_value"):
             capture(ref, nn, policy_mod, route, name, SHAPES[name], 0, 50, policy="gumbel", qtransform=qt, out_dir=args.out)
+    # round 6: the record kinds the HIP side added since the kit was written -- 160 simulations (FusedCfg::LONG: root
+    # paths in HBM; an instance planned per policy) and twelve actions (in-lane scores), both policies
+    capture(ref, nn, policy_mod, route, "cartpole", SHAPES["cartpole"], 0, 160, out_dir=args.out)
+    capture(ref, nn, policy_mod, route, "cartpole", SHAPES["cartpole"], 0, 160, policy="gumbel",
+            qtransform="qtransform_completed_by_mix_value", out_dir=args.out)
+    capture(ref, nn, policy_mod, route, "wide12", SHAPES["wide12"], 0, 50, out_dir=args.out)
+    capture(ref, nn, policy_mod, route, "wide12", SHAPES["wide12"], 0, 50, policy="gumbel",
+            qtransform="qtransform_completed_by_mix_value", out_dir=args.out)
     model, params, w, pred_on = first
     capture_checkpoint(model, w, args.out)
     capture_rollout(model, params, w, args.out, pred_on)

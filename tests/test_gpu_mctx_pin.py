@@ -93,12 +93,17 @@ def test_hip_path_reproduces_the_reference_fit_loop_trace(oracle, tmp_path):
     _check_rollout(fx.load_rollout())
 
 
-@pytest.mark.parametrize("policy,shape", [("muzero", (4, 8, 2)), ("muzero", (8, 32, 4)), ("gumbel", (4, 8, 2))])
-def test_harness_on_a_synthetic_file(oracle, tmp_path, policy, shape):
+@pytest.mark.parametrize("policy,shape,S", [("muzero", (4, 8, 2), 50), ("muzero", (8, 32, 4), 50), ("gumbel", (4, 8, 2), 50),
+                                            # round 6 -- the record kinds added since the kit was written, so that the
+                                            # day a capture runs it pins them too: a LONG instance (root paths in HBM, 160
+                                            # simulations; planned per policy) and a twelve-action one (all of a node's
+                                            # scores in one lane), both built on demand through MuZero._plan
+                                            ("muzero", (4, 8, 2), 160), ("muzero", (4, 8, 12), 50), ("gumbel", (4, 8, 12), 50)])
+def test_harness_on_a_synthetic_file(oracle, tmp_path, policy, shape, S):
     """The same harness on a file in the capture format holding the ORACLE's output (not a pin): the HIP path must
     reproduce it exactly -- i.e. the route a real capture will take is known to work end to end."""
     od, E, A = shape
-    path = fx.synthetic_case(oracle, str(tmp_path / "synthetic.npz"), policy=policy, obs_dim=od, E=E, A=A, S=50, seed=3)
+    path = fx.synthetic_case(oracle, str(tmp_path / "synthetic.npz"), policy=policy, obs_dim=od, E=E, A=A, S=S, seed=3)
     case = fx.load_case(path)
     for src in (("capture", "key") if policy == "muzero" else ("key",)):
         got = hip_run(case, src)

@@ -285,6 +285,21 @@ int mzs_mlp_set_weights(mzs_handle* h, const mzs_mlp_weights* w) {
 static int ensure_step_state(mzs_handle* h);
 static int step_block(int batch);
 static int step_grid(int batch);
+// the generic route's ONE search launch over `n` roots (round 6: MuZero-policy instances specialised on the 16-lane slots
+// the action count fills, with the pUCT table in LDS while it fits the workgroup's 64 KB)
+static void launch_mlp_search(const mzs_config& c, const mz::StepArgs& sa, const mz::JumpArgs& ja, const mz::MlpGen& g, int n,
+                              size_t lds_search, hipStream_t stream) {
+  const size_t lds_tbl = lds_search + sizeof(float) * 2 * ((size_t)sa.S + 2);
+  const bool tbl = sa.S + 2 <= 1030 && lds_tbl <= 64 * 1024;  // (Markstein's sequence is checked for every divisor up to 1030)
+  if (c.policy == 1)
+    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<true>), dim3(n), dim3(64), lds_search, stream, sa, ja, g, 0, sa.S);
+  else if (tbl && sa.A <= 16)
+    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<false, 1, true>), dim3(n), dim3(64), lds_tbl, stream, sa, ja, g, 0, sa.S);
+  else if (tbl && sa.A <= 32)
+    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<false, 2, true>), dim3(n), dim3(64), lds_tbl, stream, sa, ja, g, 0, sa.S);
+  else
+    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<false>), dim3(n), dim3(64), lds_search, stream, sa, ja, g, 0, sa.S);
+}
 // rows [rb, rb + n) of the step-wise tree as a batch of their own: every per-root array starts at row rb, the PRNG streams
 // stay those of the global root index (root_offset + rb)
 static mz::StepArgs slice_rows(mz::StepArgs s, size_t rb, int n) {
@@ -309,15 +324,14 @@ static int act_mlp_generic_chunks(mzs_handle* h, const mzs_act_args* a, const mz
                                   int32_t* act0, size_t lds_search, hipStream_t stream) {
   const mzs_config& c = h->cfg;
   const size_t A = (size_t)c.num_actions, E = (size_t)c.embed_dim;
-  const int S = c.num_simulations;
   uint32_t gk[2] = {0, 0};
   if (c.policy == 1) {
     h_split(a->key, 2, 1, gk);  // mctx gumbel_muzero_policy: rng_key, gumbel_rng = split(rng_key)
   } else {
     derive_keys(h, a->key);
     if (c.tiebreak)
-      MZS_HIP(h, hipMemcpyAsync(h->step.sim_keys, h->sim_keys.data(), sizeof(uint32_t) * 2 * (size_t)S, hipMemcpyHostToDevice,
-                                stream));
+      MZS_HIP(h, hipMemcpyAsync(h->step.sim_keys, h->sim_keys.data(), sizeof(uint32_t) * 2 * (size_t)c.num_simulations,
+                                hipMemcpyHostToDevice, stream));
   }
   const mz::StepArgs whole = h->step.args(c);
   for (size_t rb = 0; rb < (size_t)c.batch; rb += (size_t)h->jump_roots) {
@@ -336,12 +350,11 @@ static int act_mlp_generic_chunks(mzs_handle* h, const mzs_act_args* a, const mz
       hipLaunchKernelGGL(mz::jump_root_kernel<false>, grid, blk, 0, stream, sa, h->jump);
     }
     hipLaunchKernelGGL(mz::jump_select_kernel<false>, grid, blk, 0, stream, sa, h->jump, 0, act0 + rb, emb + rb * E);
+    launch_mlp_search(c, sa, h->jump, g, n, lds_search, stream);
     if (c.policy == 1) {
-      hipLaunchKernelGGL(mz::mz_mlp_search_kernel<true>, dim3(n), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
       hipLaunchKernelGGL(mz::step_finish_gumbel_kernel, grid, blk, 0, stream, sa, a->action + rb, a->action_weights + rb * A,
                          a->search_value ? a->search_value + rb : nullptr, a->depth_sum ? a->depth_sum + rb : nullptr);
     } else {
-      hipLaunchKernelGGL(mz::mz_mlp_search_kernel<false>, dim3(n), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
       hipLaunchKernelGGL(mz::step_finish_kernel, grid, blk, 0, stream, sa, a->temperature, a->gumbel ? a->gumbel + rb * A : nullptr,
                          h->k_sample[0], h->k_sample[1], a->action + rb, a->action_weights + rb * A,
                          a->search_value ? a->search_value + rb : nullptr, a->depth_sum ? a->depth_sum + rb : nullptr);
@@ -394,10 +407,7 @@ static int act_mlp_generic(mzs_handle* h, const mzs_act_args* a, void* stream_) 
   if (rc) return rc;
   if ((rc = mzs_select(h, 0, act0, emb, stream_))) return rc;  // simulate() of simulation 0 (emb: consumed by mzs_root, reused)
   mz::StepArgs sa = h->step.args(c);
-  if (c.policy == 1)
-    hipLaunchKernelGGL(mz::mz_mlp_search_kernel<true>, dim3(c.batch), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
-  else
-    hipLaunchKernelGGL(mz::mz_mlp_search_kernel<false>, dim3(c.batch), dim3(64), lds_search, stream, sa, h->jump, g, 0, S);
+  launch_mlp_search(c, sa, h->jump, g, c.batch, lds_search, stream);
   MZS_HIP(h, hipGetLastError());
   if ((rc = mzs_finish(h, a->temperature, c.policy == 1 ? nullptr : a->gumbel, a->action, a->action_weights, a->search_value,
                        a->depth_sum, stream_)))

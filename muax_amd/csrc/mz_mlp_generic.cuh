@@ -129,7 +129,10 @@ __global__ __launch_bounds__(64) void mz_mlp_root_kernel(const MlpGen w, int B, 
 }
 
 // all simulations [sim_begin, sim_end) of every root (simulate() of sim_begin has run: mzs_select)
-template <bool GUMBEL>
+// AS (round 6, MuZero policy): the 16-lane slots the action count fills (1: A <= 16, 2: A <= 32; 0: any A <= 64) -- the tree
+// step's decision refresh without the run-time tests of the general code's four slots (mz_step_jump.cuh, level_load); TBL:
+// the {sqrt(n) pb_c(n), RN(1 / n)} table behind the trio's scratch (visit counts up to 1030: Markstein's checked range)
+template <bool GUMBEL, int AS = 0, bool TBL = false>
 __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, const JumpArgs g, const MlpGen w, int sim_begin,
                                                            int sim_end) {
   extern __shared__ int gen_i[];
@@ -139,6 +142,24 @@ __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, con
   const size_t rb = (size_t)r * N;
   int* tree_lds = gen_i;
   const GenLds G = gen_lds(reinterpret_cast<float*>(gen_i + 15 * (N + 1)), E, A);
+  float* score_tbl = nullptr;
+  if constexpr (TBL) {
+    score_tbl = reinterpret_cast<float*>(gen_i + 15 * (N + 1)) + gen_scratch_words(E, A);
+    for (int n = tid; n < N + 1; n += 64) {
+      score_tbl[2 * n] = puct_scale(n, s.pb_c_init, s.pb_c_base);
+      score_tbl[2 * n + 1] = n > 0 ? 1.0f / (float)n : 0.0f;
+    }
+    __syncthreads();
+  }
+  TreeView T = tree_view_global(s, g, rb);
+  if constexpr (AS != 0) {  // the root's invalid-action mask once per launch, not a load in front of level 0's scores every time
+    T.inv_bits = 0;
+#pragma unroll
+    for (int t = 0; t < AS; ++t) {
+      const int a = (tid & 15) + 16 * t;
+      if (a < A && s.root_invalid[(size_t)r * A + a]) T.inv_bits |= 1 << t;
+    }
+  }
   int parent = s.sel_parent[r], action = s.sel_action[r], depth = s.sel_depth[r];
   int newn;
   {
@@ -173,8 +194,8 @@ __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, con
     const float rew = G.scal[0], val = G.scal[1];
     const int known[4] = {parent, action, depth, newn};
     int sel[3] = {0, 0, 0};
-    jump_expand_backup_body<GUMBEL>(s, g, tree_view_global(s, g, rb), sim, r, tree_lds, rew, w.discount, G.pl, val, nullptr, true, nullptr, nullptr,
-                                    sel, known);
+    jump_expand_backup_body<GUMBEL, kLevelsInFlight, AS, TBL>(s, g, T, sim, r, tree_lds, rew, w.discount, G.pl, val, nullptr, true, nullptr,
+                                                              nullptr, sel, known, 0, score_tbl);
     if (sim + 1 < sim_end && sim + 1 < s.S) {
       parent = sel[0];
       action = sel[1];

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   const int tid = threadIdx.x;
   // {sqrt(n) pb_c(n), RN(1 / n)} by visit count, behind the tree step's arrays (level_compute): while every count
   // stays within Markstein's tested range
-  float* score_tbl = (!GUMBEL && s.S + 2 <= 300) ? reinterpret_cast<float*>(tree_lds + 15 * (s.S + 2)) : nullptr;
+  float* score_tbl = (!GUMBEL && s.S + 2 <= 1030) ? reinterpret_cast<float*>(tree_lds + 15 * (s.S + 2)) : nullptr;
   if (score_tbl) {
     for (int n = tid; n < s.S + 2; n += 256) {
       score_tbl[2 * n] = puct_scale(n, s.pb_c_init, s.pb_c_base);
@@ -324,7 +324,7 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
   // the tree's statistics in LDS as well when they fit next to that (MuZero policy; MZS_SEARCH_LDS_TREE=0: A/B, tests)
   const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N + 2 + (size_t)sa.A);
   const char* lt = getenv("MZS_SEARCH_LDS_TREE");
-  const bool ldstree = policy != 1 && sa.A <= 32 && sa.S + 2 <= 300 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
+  const bool ldstree = policy != 1 && sa.A <= 32 && sa.S + 2 <= 1030 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
   const bool wide = sa.A > 16;  // (LDS-tree instances: one or two 16-lane slots of actions)
   if (ldstree) lds = lds_tree;
   if (sa.S + 1 > 4096 || sa.A > 255)

@@ -125,7 +125,7 @@ MZ_DEV void level_load(const StepArgs& s, const TreeView& T, int r, int node, in
 }
 // `tbl` (optional, LDS): {sqrt(n) pb_c(n), RN(1 / n)} for n = 0 .. S + 1, built once per launch by a kernel that lives
 // for a whole search (mz_search_conv.hip) -- the same puct_scale() values, and x / n by Markstein's exact sequence for
-// n <= 300 (div_small, mz_fused.cuh; tests/test_oracle_kat.py): the refresh of a path's decisions is arithmetic-bound,
+// n <= 1030 (div_small, mz_fused.cuh; tests/test_oracle_kat.py): the refresh of a path's decisions is arithmetic-bound,
 // a log, a sqrt and three of its four IEEE divisions per level go
 // TBL: `tbl` is there (the caller's launch built it): no code for the other case
 template <int AS = 0, bool TBL = false>

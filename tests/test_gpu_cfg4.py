@@ -25,7 +25,7 @@ F32 = np.float32
 A, S_FULL, SUPPORT = 18, 200, 10
 
 
-def _nets(seed=0):
+def _nets(seed=0, A=A):
     g = torch.Generator().manual_seed(seed)
     mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, 2 * SUPPORT + 1, generator=g),
             mx.nn.ResNetDynamic(A, 2 * SUPPORT + 1, generator=g))
@@ -470,6 +470,48 @@ def test_one_launch_search_equals_the_per_simulation_launches(B, S, policy, max_
         assert torch.equal(t0[f], t1[f]), (f, int((t0[f] != t1[f]).sum()))
     if max_depth:
         assert int(t1["node_visits"][:, 1:].max()) > 1 and int((t1["parents"][:, 1:] == -1).sum()) > 0  # re-expansions happened
+
+
+@pytest.mark.parametrize("A_,B,S,lds_tree", [(6, 20, 50, "1"), (6, 150, 30, "1"), (16, 9, 40, "1"), (18, 12, 60, "0"), (6, 20, 50, "0"),
+                                            (32, 7, 30, "1"), (33, 7, 30, "1")])
+def test_one_launch_search_tree_in_lds_for_any_action_count(monkeypatch, A_, B, S, lds_tree):
+    """Round 6: the one-launch search keeps the statistics its tree step reads and rewrites in LDS (TreeView) and
+    specialises the decision refresh on the 16-lane slots the action count fills -- one slot (6, 16 actions), two (18, 32),
+    the general code with the HBM tree beyond 32 actions or with MZS_SEARCH_LDS_TREE=0 -- in pair mode and with one
+    workgroup per root (150 roots).  Each against the loop of per-simulation launches (HBM tree, general code): every tree
+    array, actions, weights, depth sums, bit for bit."""
+    monkeypatch.setenv("MZS_SEARCH_LDS_TREE", lds_tree)
+    m, mods = _nets(70 + A_, A=A_)
+    dy, pred = mods[2], mods[1]
+    obs = torch.from_numpy(_frames(B, seed=B + A_)).cuda()
+    pl, v, emb = m._root_inference(None, None, obs)
+    rng = np.random.default_rng(B + A_)
+    noise = torch.from_numpy(rng.dirichlet([0.3] * A_, B).astype(F32)).cuda()
+    invalid = (rng.uniform(size=(B, A_)) < 0.15).astype(np.uint8)
+    invalid[np.arange(B), rng.integers(0, A_, B)] = 0
+    invalid = torch.from_numpy(invalid).cuda()
+
+    def rec(action, flat):
+        (r, disc, logits, val), ns = m._recurrent_inference(None, None, action, flat.reshape(B, 6, 6, 64))
+        return r, disc, logits, val, ns.reshape(B, -1)
+
+    def native(handle, b, e):
+        dy.hip_search(pred, handle, SUPPORT, 0.99, b, e)
+
+    assert dy.hip_search_ok(pred, (6, 6, 64), SUPPORT)
+    outs = []
+    for loop in (None, native):
+        s = mx.MuZeroSearch(B, mx.SearchConfig(A_, S, 2304, tiebreak=True))
+        o = s.search((pl, v, emb.reshape(B, -1)), rec, key=[9, B], invalid_actions=invalid, with_tree=True,
+                     native_loop=loop, dirichlet_noise=noise)
+        torch.cuda.synchronize()
+        outs.append((o.action.clone(), o.action_weights.clone(), s.depth_sum.clone(),
+                     {f: getattr(o.search_tree, f).clone() for f in o.search_tree._fields}))
+        s.close()
+    (a0, w0, d0, t0), (a1, w1, d1, t1) = outs
+    assert torch.equal(a0, a1) and torch.equal(w0, w1) and torch.equal(d0, d1)
+    for f in t0:
+        assert torch.equal(t0[f], t1[f]), (f, int((t0[f] != t1[f]).sum()))
 
 
 @pytest.mark.parametrize("B,S", [(128, S_FULL), (144, 60)])

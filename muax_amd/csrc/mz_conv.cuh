@@ -101,6 +101,13 @@ struct TowerIO {
   // and the head maps' padding rows are still zero -- no pass writes them -- and every word a pass reads besides those it
   // writes first, so the 66 KB zero fill (2 of the 2.5 us of "LDS init + state load") is needed once per launch only
   bool lds_clean = false;
+  // round 6 (the one-launch search): the weights of the prediction heads' first 1x1 convolutions in the workgroup's LDS
+  // for the whole launch -- v_c1 [64][16] then p_c1 [64][16] -- when head_w_lds is set.  They are 8 KB that every
+  // simulation needs at the very start of the heads, and by then the passes' 5.7 MB of convolution weights have
+  // streamed through the L2 (and the TLBs) since their last use: the heads' first phase was 2.6 us of waiting for 0.64 us
+  // of MFMAs
+  const float* head_w = nullptr;
+  bool head_w_lds = false;
 };
 
 constexpr int kTowerC = 64, kTowerHW = 6, kTowerPix = 36, kHalo = 8, kPixStride = 68;  // 16-byte aligned pixels
@@ -154,6 +161,10 @@ MZ_DEV void wg_sum(float (&v)[NV], RedSlots& R, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
 }
+
+// a workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): loads requested from global memory
+// before it stay in flight across it -- a __syncthreads() drains vmcnt as well, i.e. WAITS for them
+MZ_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // acc[mt] = conv3x3 of the haloed map `in`, this wave's 16 output channels.
 // K is walked in 36 groups of 16 input channels (9 taps x 4): lane (m, g) reads channels 16 c + 4 g + {0..3}
@@ -701,24 +712,37 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
                              int tid, int lane, int wave MZ_TH_PARAMS, Side&& side = Side()) {
   const int g4 = lane >> 4, n16 = lane & 15;
   // the weights of the last layers do not depend on the map: requested here, before the 1x1 convolutions and their
-  // barriers (a barrier is a fence: the compiler cannot hoist them itself).  The flatten -> Linear(576 -> 16) matrices were
+  // barriers (a barrier is a fence: the compiler cannot hoist them itself).  Round 6: the barriers of this function
+  // order LDS only -- every hand-over between its phases goes through LDS -- so these loads (L2 misses: the convolution
+  // weights of the passes have streamed through the L2 since their last use, ~2 us) stay in flight until their use
+  // four phases later.  With __syncthreads() the FIRST barrier waited for them: the "first 1x1 convolutions" phase
+  // measured 2.6 us with its own weight loads removed, for 0.64 us of MFMAs.  The flatten -> Linear(576 -> 16) matrices were
   // tried up here too (the first convolution's own weight loads queue behind those 72 loads) and as a copy in LDS for
   // the whole search (the layer went from 0.4 to 1.9 us): the phase is the 192 MFMAs of the first 1x1 convolutions on
   // one wave per head, 2.6 of its 8 us (profiles/r04_search_phases.txt).
   const int n = tid & 15, sl = tid >> 4;
   float wl2[16];
-  float bl2 = 0.0f;
+  float bl2, bl1;
   {
-    const bool isv = tid < p.F, isp = tid >= 64 && tid < 64 + p.A;
-    const int j = isv ? tid : tid - 64;
+    // UNCONDITIONAL loads at clamped indices (a thread that is neither a value logit nor a policy logit reads column 0 of
+    // the value matrix and never uses it).  Until round 6 they sat under per-thread conditions with a constant 0 in the
+    // other lanes: the constant's move into the register a load is still to write forces an s_waitcnt vmcnt(0) on the
+    // spot -- a full L2-miss latency (~1.5 us) in front of the heads' first convolutions, every simulation.
+    const bool isp = tid >= 64 && tid < 64 + p.A;
+    const float* w2 = isp ? p.p_l2 : p.v_l2;
+    const float* b2 = isp ? p.p_b2 : p.v_b2;
+    const int ld2 = isp ? p.A : p.F;
+    const int j = isp ? tid - 64 : (tid < p.F ? tid : 0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) wl2[k] = isv ? p.v_l2[k * p.F + j] : (isp ? p.p_l2[k * p.A + j] : 0.0f);
-    bl2 = isv ? p.v_b2[j] : (isp ? p.p_b2[j] : 0.0f);
+    for (int k = 0; k < 16; ++k) wl2[k] = w2[k * ld2 + j];
+    bl2 = b2[j];
+    bl1 = ((tid & 16) ? p.p_b1 : p.v_b1)[n];  // (used by tid < 32: value units 0..15, policy units 16..31)
   }
-  const float bl1 = tid < 32 ? (tid < 16 ? p.v_b1[n] : p.p_b1[n]) : 0.0f;
   if (wave < 2) {  // wave 0: value head, wave 1: policy head -- first 1x1 conv (64 -> 16) + relu
     f32x4 h[3];
-    conv1x1_tiles(cur, rowc, wave == 0 ? p.v_c1 : p.p_c1, 16, n16, 4, g4, h);
+    const float* vw = io.head_w_lds ? io.head_w : p.v_c1;
+    const float* pw = io.head_w_lds ? io.head_w + kTowerC * 16 : p.p_c1;
+    conv1x1_tiles(cur, rowc, wave == 0 ? vw : pw, 16, n16, 4, g4, h);
     float* dst = wave == 0 ? H.hv : H.hp;
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
@@ -730,7 +754,7 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
   } else if (wave == 3) {
     side(0);
   }
-  __syncthreads();
+  lds_barrier();
   MZ_TH(6)
   if (wave == 3) side(1);
   if (wave == 0) {  // value head: second 1x1 conv (16 -> 16) + relu
@@ -744,7 +768,7 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   MZ_TH(7)
   {
     // Linear(576 -> 16) of both heads: thread = (output unit n, one of 16 slices of 36 inputs)
@@ -760,11 +784,11 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
       sv = __builtin_fmaf(H.hv2[36 * sl + i], wv[i], sv);
       sp = __builtin_fmaf(H.hp[36 * sl + i], wp[i], sp);
     }
-    __syncthreads();
+    lds_barrier();
     H.part[tid] = sv;
     H.part2[tid] = sp;
   }
-  __syncthreads();
+  lds_barrier();
   MZ_TH(8)
   if (tid < 32) {
     const float* src = tid < 16 ? H.part : H.part2;
@@ -772,7 +796,7 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
     for (int q = 0; q < 16; ++q) a = a + src[q * 16 + n];
     H.vec[tid] = fmaxf(a + bl1, 0.0f);
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < p.F) {
     float a = 0.0f;
 #pragma unroll
@@ -785,7 +809,7 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
     for (int k = 0; k < 16; ++k) a = __builtin_fmaf(H.vec[16 + k], wl2[k], a);
     io.prior_logits[j] = a + bl2;
   }
-  __syncthreads();
+  lds_barrier();
   if (wave == 0) {
     const float vl = decode_support(H.lgt, p.F, p.support, lane);
     if (lane == 0) *io.value = vl;

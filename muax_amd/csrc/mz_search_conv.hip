@@ -49,7 +49,7 @@ MZ_DEV bool pair_lost_uniform(const PairLink& L, int tid, int* flag_lds) {
 // LDSTREE (round 6, MuZero policy): the statistics the tree step reads and rewrites -- children_{index, visits,
 // prior_probs, rewards, values}[N][A], node_{visits, values}[N], the JUMP records [N] -- live in this CU's LDS for the
 // whole launch (copied in from the handle's HBM tree at the start, written back at the end; 75.6 KB for config 4's 201
-// nodes x 18 actions, next to the pass' 66 KB and the step's 14 KB: 155.6 of the CU's 160 KB).  Between two tree steps
+// nodes x 18 actions, next to the pass' 66 KB, the step's 14 KB and 8 KB of head weights: 163 784 of the CU's 163 840 bytes).  Between two tree steps
 // of a root its XCD streams the 5.7 MB of convolution weights through its 4 MB L2: the step's ~260 tree lines were gone
 // every time, and a 44-level decision refresh spent 4.5 of its 7 us on memory round trips.  Same device functions on
 // the same values in the same order (a TreeView of LDS rows instead of HBM rows): same bits.
@@ -140,12 +140,24 @@ __global__ __launch_bounds__(256) void mz_resnet_search_kernel(const TowerParams
   io.value = p.value + r;
   io.prior_logits = p.prior_logits + (size_t)r * A;
   if constexpr (LDSTREE) {
-    // reward / value / prior logits of a pass go from the heads to the tree step of the SAME workgroup: through LDS
-    // (behind the node records), not through an HBM word and back (two L2 round trips per simulation)
-    float* hs = reinterpret_cast<float*>(tree_lds + 17 * (s.S + 2) + 5 * N * A + 4 * N);
-    io.reward = hs;
-    io.value = hs + 1;
-    io.prior_logits = hs + 2;
+    // reward / value / prior logits of a pass go from the heads to the tree step of the SAME workgroup: through LDS, not
+    // through an HBM word and back (two L2 round trips per simulation) -- in words of the pass' own scratch that are
+    // dead between the heads and the next pass for the prior logits (the Linear layers' partial sums: A <= 32 of 256
+    // words, written after their last reader of the simulation), two words of their own for reward and value (one
+    // workgroup per root evaluates the reward head BEFORE the passes: nothing of the pass' scratch survives those)
+    io.prior_logits = lds + 2 * kBufWords + 32 + 3 * 768;
+    // the prediction heads' first 1x1 convolutions (v_c1 | p_c1, 2 x 64 x 16 floats) behind the node records, copied once
+    float* hw = reinterpret_cast<float*>(tree_lds + 17 * (s.S + 2) + 5 * N * A + 4 * N);
+    io.reward = hw + 2 * kTowerC * 16;
+    io.value = hw + 2 * kTowerC * 16 + 1;
+    if (owns_tree) {
+      for (int i = tid; i < kTowerC * 16; i += 256) {
+        hw[i] = p.v_c1[i];
+        hw[kTowerC * 16 + i] = p.p_c1[i];
+      }
+    }
+    io.head_w = hw;
+    io.head_w_lds = true;
   }
 #ifdef MZ_PROFILE
   unsigned long long st[4] = {0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
@@ -322,7 +334,7 @@ int mzs_resnet_search(mzs_handle* h, const mzs_tower_args* a, float discount, in
   size_t lds = sizeof(float) * (2 * (size_t)mz::kBufWords + mz::kHeadWords) + sizeof(int32_t) * 17 * ((size_t)sa.S + 2);  // (15 arrays of the tree step + the score table)
   if (lds > 160 * 1024) return mzh::fail_handle(h, MZS_E_UNSUPPORTED, "mzs_resnet_search: num_simulations too large for the LDS of a CU");
   // the tree's statistics in LDS as well when they fit next to that (MuZero policy; MZS_SEARCH_LDS_TREE=0: A/B, tests)
-  const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N + 2 + (size_t)sa.A);
+  const size_t lds_tree = lds + sizeof(int32_t) * (5 * (size_t)sa.N * sa.A + 4 * (size_t)sa.N + 2 * mz::kTowerC * 16 + 2);  // (+ the heads' 1x1 weights, reward, value)
   const char* lt = getenv("MZS_SEARCH_LDS_TREE");
   const bool ldstree = policy != 1 && sa.A <= 32 && sa.S + 2 <= 1030 && lds_tree <= 160 * 1024 && !(lt && lt[0] == '0');
   const bool wide = sa.A > 16;  // (LDS-tree instances: one or two 16-lane slots of actions)

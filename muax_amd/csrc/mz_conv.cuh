@@ -713,13 +713,10 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
   const int g4 = lane >> 4, n16 = lane & 15;
   // the weights of the last layers do not depend on the map: requested here, before the 1x1 convolutions and their
   // barriers (a barrier is a fence: the compiler cannot hoist them itself).  Round 6: the barriers of this function
-  // order LDS only -- every hand-over between its phases goes through LDS -- so these loads (L2 misses: the convolution
-  // weights of the passes have streamed through the L2 since their last use, ~2 us) stay in flight until their use
-  // four phases later.  With __syncthreads() the FIRST barrier waited for them: the "first 1x1 convolutions" phase
-  // measured 2.6 us with its own weight loads removed, for 0.64 us of MFMAs.  The flatten -> Linear(576 -> 16) matrices were
-  // tried up here too (the first convolution's own weight loads queue behind those 72 loads) and as a copy in LDS for
-  // the whole search (the layer went from 0.4 to 1.9 us): the phase is the 192 MFMAs of the first 1x1 convolutions on
-  // one wave per head, 2.6 of its 8 us (profiles/r04_search_phases.txt).
+  // order LDS only -- every hand-over between its phases goes through LDS -- so these loads (L2 misses: the passes' 5.7 MB
+  // of convolution weights have streamed through the L2 since their last use) stay in flight until their use four
+  // phases later.  The LDS copy of the flatten -> Linear matrices for the whole search was tried in round 4 (the layer
+  // went from 0.4 to 1.9 us).
   const int n = tid & 15, sl = tid >> 4;
   float wl2[16];
   float bl2, bl1;
@@ -773,6 +770,9 @@ MZ_DEV void prediction_heads(const TowerParams& p, const TowerIO& io, const floa
   {
     // Linear(576 -> 16) of both heads: thread = (output unit n, one of 16 slices of 36 inputs)
     float sv = 0.0f, sp = 0.0f;
+    // (requested at the top of the heads instead -- 72 more registers in flight across the convolution phases -- the
+    // layer drops from 1.0 to 0.4 us and the act does not get faster, round 5 and again round 6: 24.4-24.7 against
+    // 24.4-24.5 ms, same box)
     float wv[36], wp[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) {  // all 72 loads in flight before the first fma

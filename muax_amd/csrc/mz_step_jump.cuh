@@ -452,6 +452,39 @@ MZ_DEV void jump_prefetch_levels(const StepArgs& s, const TreeView& T, const Jum
   }
 }
 
+// leaf_value = reward + discount * leaf_value, leaf to root (mctx search.backward): the one sequential chain of the step.
+// One wavefront (`lane` = 0 .. 63 of the calling wavefront), 63 levels per chunk, every lane its own level: one step is
+// X[e] = r[e] + d[e] * X[e + 1] on all lanes at once -- v_mul_f32_dpp wave_shl:1 + v_add_f32 -- and level e is final
+// after (levels of the chunk - e) steps: ~25 cycles per level (round 3: two v_readlane + mul + add + select per level on
+// the wave-uniform G, ~140 cycles as compiled; until round 6 a select per step, ~100).  The paths of a long search on few
+// roots are 50 .. 150 levels deep and this chain paces the root.  Same operations in the same order for every level.
+// `patch`: the last edge's (reward, discount) come from the caller's registers (rew_new, dis_new), not from rw / ds.
+MZ_DEV void return_chain(const float* rw, const float* ds, float* Gs, float v, int depth, int lane, bool patch, float rew_new,
+                         float dis_new) {
+  float G = v;
+  for (int c = (depth - 1) / 63; c >= 0; --c) {
+    const int e = 63 * c + lane;
+    const int cn = min(63, depth - 63 * c);
+    const bool mine = lane < cn;
+    // lanes past the chunk's levels run identity steps on the value arriving from below: (-0) + 1 * x == x for every x
+    float rr = mine ? rw[e] : -0.0f, dd = mine ? ds[e] : 1.0f;
+    if (patch && mine && e == depth - 1) {  // (`mine`: lane 63 of the chunk BELOW the last edge's has the same e)
+      rr = rew_new;
+      dd = dis_new;
+    }
+    float X = G, Xt = dd * G;  // (lane 63 has no lane above it: its Xt stays dd * G = G through every step)
+    // four steps per statement: the DPP source X is the register the add before it has just written -- two wait
+    // states (s_nop 1), which the hazard recogniser does not insert inside asm.  A level is final after (levels of
+    // the chunk - e) steps and a further step maps it onto itself, so the count is rounded up to a multiple of four.
+#define MZ_CSTEP "s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32 %1, %0, %3\n\t"
+    for (int k = 0; k < cn; k += 4)
+      asm volatile(MZ_CSTEP MZ_CSTEP MZ_CSTEP MZ_CSTEP : "+v"(Xt), "+v"(X) : "v"(dd), "v"(rr));
+#undef MZ_CSTEP
+    if (mine) Gs[e] = X;
+    G = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(X)));  // arrival at the chunk's first level
+  }
+}
+
 // `prefetched`: bit 0 = jump_prefetch_path, bit 1 = jump_prefetch_levels have run for this simulation (and a barrier since)
 // AS: see level_load (0: any action count); `depth_acc` != nullptr: the next selection's depth is added there (a register
 // of the caller, who owns depth_sum[r] for the launch) instead of to the HBM word -- a load-add-store round trip per
@@ -493,6 +526,12 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
 
   // -- path of the leaf: the parent's own root path + (parent, action) --
   if (!(prefetched & 1)) jump_prefetch_path(s, g, r, JL, tid, nthr, parent, action, depth, newn, fresh);
+  // the caller has prefetched the path AND the per-level inputs (the fused search, in idle convolution passes): the
+  // discounted-return chain needs nothing else but (rew_new, dis_new, v), which are in registers -- it runs on the SECOND
+  // wavefront right away, beside the expansion on the first (the new node's softmax, ~0.9 us), and the barrier between
+  // the two phases goes
+  const bool early_chain = prefetched == 3 && nthr >= 128;
+  if (early_chain && (tid >> 6) == 1) return_chain(rw, ds, Gs, v, depth, tid & 63, true, rew_new, dis_new);
   // -- expand (row 0): prior of the new node, node and edge records --
   if (row == 0) {
     float x[kMaxAS], pr[kMaxAS];
@@ -527,43 +566,18 @@ MZ_DEV void jump_expand_backup_body(const StepArgs& s, const JumpArgs& g, const 
     for (int i = tid; i < E; i += nthr) s.embeddings[(rb + newn) * E + i] = next_embedding_row[i];
   step_barrier<LDSB>();
   MZ_JT(0)
-  // -- per-level inputs of the backward pass --
-  if (!(prefetched & 2)) jump_prefetch_levels(s, T, JL, tid, nthr, depth);
-  if (tid == (depth - 1) % nthr && depth > 0) {  // (the thread that wrote the entry, if it was written just now)
-    rw[depth - 1] = rew_new;
-    ds[depth - 1] = dis_new;
-  }
-  step_barrier<LDSB>();
-  MZ_JT(1)
-  // -- leaf_value = reward + discount * leaf_value, leaf to root (the one sequential chain) --
-  // One wavefront, 63 levels per chunk, every lane its own level: one step is X[e] = r[e] + d[e] * X[e + 1] on all
-  // lanes at once -- v_mul_f32_dpp wave_shl:1 + v_add_f32 (+ a select for the lanes past the chunk, which hold the
-  // value arriving from below) -- and level e is final after (levels of the chunk - e) steps: ~25 cycles per level
-  // (round 3: two v_readlane + mul + add + select per level on the wave-uniform G, ~140 cycles as compiled; before
-  // that an LDS round trip per level on a lone thread).  The paths of a long search on few roots are 50 .. 150 levels
-  // deep and this chain paces the root.  Same operations in the same order for every level: same bits.
-  if (tid < 64) {
-    float G = v;
-    for (int c = (depth - 1) / 63; c >= 0; --c) {
-      const int e = 63 * c + tid;
-      const int cn = min(63, depth - 63 * c);
-      const bool mine = tid < cn;
-      // lanes past the chunk's levels run identity steps on the value arriving from below: (-0) + 1 * x == x for every x
-      // (until round 6 a select per step kept them at G; the loop compiled to ~100 cycles a level)
-      const float rr = mine ? rw[e] : -0.0f, dd = mine ? ds[e] : 1.0f;
-      float X = G, Xt = dd * G;  // (lane 63 has no lane above it: its Xt stays dd * G = G through every step)
-      // four steps per statement: the DPP source X is the register the add before it has just written -- two wait
-      // states (s_nop 1), which the hazard recogniser does not insert inside asm.  A level is final after (levels of
-      // the chunk - e) steps and a further step maps it onto itself, so the count is rounded up to a multiple of four.
-#define MZ_CSTEP "s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32 %1, %0, %3\n\t"
-      for (int k = 0; k < cn; k += 4)
-        asm volatile(MZ_CSTEP MZ_CSTEP MZ_CSTEP MZ_CSTEP : "+v"(Xt), "+v"(X) : "v"(dd), "v"(rr));
-#undef MZ_CSTEP
-      if (mine) Gs[e] = X;
-      G = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(X)));  // arrival at the chunk's first level
+  if (!early_chain) {
+    // -- per-level inputs of the backward pass --
+    if (!(prefetched & 2)) jump_prefetch_levels(s, T, JL, tid, nthr, depth);
+    if (tid == (depth - 1) % nthr && depth > 0) {  // (the thread that wrote the entry, if it was written just now)
+      rw[depth - 1] = rew_new;
+      ds[depth - 1] = dis_new;
     }
+    step_barrier<LDSB>();
+    MZ_JT(1)
+    if (tid < 64) return_chain(rw, ds, Gs, v, depth, tid, false, rew_new, dis_new);
+    step_barrier<LDSB>();
   }
-  step_barrier<LDSB>();
   MZ_JT(2)
   for (int e = tid; e <= depth; e += nthr)
     nv[e] = (e == depth) ? v : (val[e] * (float)cnt[e] + Gs[e]) / ((float)cnt[e] + 1.0f);

@@ -40,6 +40,18 @@ def _nets(seed=0, A=A):
     return m, mods
 
 
+def _bench_nets(B=128):
+    """tools/bench_atari.py's nets and frames, draw for draw (the frames BEFORE init: the lazy Linear layers draw from the
+    same generator): trees ~44 levels deep on average at 200 simulations, where _nets' stay under 20."""
+    g = torch.Generator().manual_seed(0)
+    mods = (mx.nn.ResNetRepresentation(32, generator=g), mx.nn.ResNetPrediction(A, 2 * SUPPORT + 1, generator=g),
+            mx.nn.ResNetDynamic(A, 2 * SUPPORT + 1, generator=g))
+    obs = torch.randint(0, 256, (B, 84, 84, 4), generator=g).float().cuda()
+    m = mx.MuZero(*mods)
+    m.init(0, np.zeros((1, 84, 84, 4), F32))
+    return m, mods, obs
+
+
 def _frames(B, seed=1):
     return np.random.default_rng(seed).integers(0, 256, (B, 84, 84, 4)).astype(F32)
 
@@ -514,18 +526,65 @@ def test_one_launch_search_tree_in_lds_for_any_action_count(monkeypatch, A_, B, 
         assert torch.equal(t0[f], t1[f]), (f, int((t0[f] != t1[f]).sum()))
 
 
-@pytest.mark.parametrize("B,S", [(128, S_FULL), (144, 60)])
-def test_one_launch_search_replayed_in_the_oracle(oracle, B, S):
+def test_one_launch_search_on_paths_deeper_than_a_wavefront():
+    """The bench's own nets (_bench_nets: trees ~44 levels deep on average): paths of 64 and more levels take the return chain
+    in chunks of 63 levels, and pair mode runs that chain on its second wavefront beside the expansion with the last
+    edge's reward / discount patched in from registers (mz_step_jump.cuh, return_chain).  A path of EXACTLY 64 levels
+    puts the last edge alone in the upper chunk, where lane 63 of the lower chunk has the same level index: the case a
+    first version of the patch got wrong with every other test green.  Pair mode against the loop of per-simulation
+    launches (no prefetch, chain after the expansion): every tree array, actions, weights, depth sums, bit for bit."""
+    B, S = 128, S_FULL
+    m, mods, obs = _bench_nets(B)
+    dy, pred = mods[2], mods[1]
+    pl, v, emb = m._root_inference(None, None, obs)
+    noise = torch.from_numpy(np.random.default_rng(7).dirichlet([0.3] * A, B).astype(F32)).cuda()
+
+    def rec(action, flat):
+        (r, disc, logits, val), ns = m._recurrent_inference(None, None, action, flat.reshape(B, 6, 6, 64))
+        return r, disc, logits, val, ns.reshape(B, -1)
+
+    def native(handle, b, e):
+        dy.hip_search(pred, handle, SUPPORT, 0.99, b, e)
+
+    assert dy.hip_search_ok(pred, (6, 6, 64), SUPPORT)
+    outs = []
+    for loop in (None, native):
+        s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, 2304, tiebreak=True))
+        o = s.search((pl, v, emb.reshape(B, -1)), rec, key=[12, B], with_tree=True, native_loop=loop, dirichlet_noise=noise)
+        torch.cuda.synchronize()
+        if loop is not None:
+            assert not getattr(s, "_native_loop_unusable", False) and dy._pair_scratch and not dy.pair_lost()
+        outs.append((o.action.clone(), o.action_weights.clone(), s.depth_sum.clone(),
+                     {f: getattr(o.search_tree, f).clone() for f in o.search_tree._fields}))
+        s.close()
+    (a0, w0, d0, t0), (a1, w1, d1, t1) = outs
+    par = t0["parents"].cpu().numpy()
+    depth = np.zeros_like(par)
+    for k in range(1, S + 1):
+        depth[:, k] = depth[np.arange(B), par[:, k]] + 1
+    assert (depth == 64).any() and depth.max() > 64, depth.max()  # the workload reaches the case this test is for
+    assert torch.equal(d0, d1), int((d0 != d1).sum())
+    for f in t0:
+        assert torch.equal(t0[f], t1[f]), (f, int((t0[f] != t1[f]).sum()))
+    assert torch.equal(a0, a1) and torch.equal(w0, w1)
+
+
+@pytest.mark.parametrize("B,S,deep", [(128, S_FULL, False), (144, 60, False), (128, S_FULL, True)])
+def test_one_launch_search_replayed_in_the_oracle(oracle, B, S, deep):
     """mz_resnet_search_kernel (the bench line's dominant config-4 kernel) against the ORACLE directly, not through
     the per-simulation HIP route: the tree the one launch leaves is replayed -- for every simulation the oracle's own
     `step_select` (its tree, the same simulation key) must name the (parent, action) the kernel stored for node
     sim + 1, then the oracle's `step_expand_backup` is fed that node's own stored reward / prior logits / raw value /
     embedding -- and at the end every tree array, the sampled actions and the weights must be equal, bit for bit.
     128 roots x 200 simulations x 18 actions is config 4's shard (pair mode); 144 roots take one workgroup per root.
-    A regression in the tree-step body the two HIP routes share (mz_step_jump.cuh) fails HERE."""
-    m, mods = _nets(5)
+    A regression in the tree-step body the two HIP routes share (mz_step_jump.cuh) fails HERE.
+    `deep`: the bench's own nets and frames, whose paths pass 64 levels (the chain's chunks, pointer jumping's LDS form)."""
+    if deep:
+        m, mods, obs = _bench_nets(B)
+    else:
+        m, mods = _nets(5)
+        obs = torch.from_numpy(_frames(B, seed=40 + B)).cuda()
     dy, pred = mods[2], mods[1]
-    obs = torch.from_numpy(_frames(B, seed=40 + B)).cuda()
     pl, v, emb = m._root_inference(None, None, obs)
     E = 2304
     rng = np.random.default_rng(B + S)
@@ -570,6 +629,7 @@ def test_one_launch_search_replayed_in_the_oracle(oracle, B, S):
     for k in range(1, S + 1):
         depth[:, k] = depth[rows, par[:, k]] + 1
     assert np.array_equal(depth.sum(1), s.depth_sum.cpu().numpy())
+    assert not deep or ((depth == 64).any() and depth.max() > 64)
     s.close()
 
 

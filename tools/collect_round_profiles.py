@@ -65,6 +65,13 @@ if os.path.exists(os.path.join(R, "search_phases.txt")):  # round 4: the one-lau
     write("search_phases.txt", rd("search_phases.txt"),
           f"# {tag} -- config 4's shard (128 roots x 200 simulations): act() through the three routes, and in-kernel phase timers\n"
           f"# (s_memtime, -DMZ_PROFILE build) of the one-launch search, per simulation (tools/profile_search.py run)\n\n")
+    with open(os.path.join(P, f"{tag}_search_phases.txt"), "a") as f:
+        if os.path.exists(os.path.join(R, "search_phases_heads.txt")):
+            f.write("\n## the same with the heads' own timers (-DMZ_PROF_HEADS build: slots 3..9 time the pieces of \"heads after the tower\")\n"
+                    + "".join(ln for ln in rd("search_phases_heads.txt").splitlines(True) if not ln.startswith("act()")))
+        if os.path.exists(os.path.join(R, "ab_ldstree.txt")):
+            f.write("\n## the tree statistics in LDS against the HBM tree, same kernels otherwise (MZS_SEARCH_LDS_TREE=1 / 0), same box,\n"
+                    "## three alternations (tools/bench_atari.py 128 200)\n" + rd("ab_ldstree.txt"))
 if os.path.exists(os.path.join(R, "generic.txt")):  # round 4: default-trio shapes without a listed instance
     write("generic_route.txt", rd("generic.txt"),
           f"# {tag} -- act() of the default MLP trio: tuned fused instance vs the generic one-launch search (mz_mlp_generic.cuh),\n"
@@ -73,6 +80,9 @@ if os.path.exists(os.path.join(R, "bench_long.txt")):
     with open(os.path.join(P, f"{tag}_generic_route.txt"), "a") as f:
         f.write("\n## long searches / wide action sets through mzs_act_mlp at several batch sizes: median ms per act (tools/bench_long.py);\n"
                 "## plan = (support slots, tree size, wavefronts per workgroup, LONG record)\n" + rd("bench_long.txt"))
+if os.path.exists(os.path.join(R, "sync_gap.txt")):
+    with open(os.path.join(P, f"{tag}_generic_route.txt"), "a") as f:
+        f.write("\n## a synchronised act() of the metric's workload taken apart (tools/sync_gap.py, three runs)\n" + rd("sync_gap.txt"))
 for multi in ("bench_2ranks_1gpu.json", "bench_8ranks_1gpu.json", "bench_8ranks_1gpu_torchrun.json"):
     if os.path.exists(os.path.join(R, multi)) or os.path.exists(os.path.join(ROOT, "gpurun_out", multi)):
         src = os.path.join(R, multi) if os.path.exists(os.path.join(R, multi)) else os.path.join(ROOT, "gpurun_out", multi)
@@ -129,7 +139,7 @@ if os.path.exists(os.path.join(R, "tower_pmc.txt")):
         pj["atari"] = {
             "hbm_bytes_per_launch": int((2 * fs + ws) * 1024), "fetch_size_kb_raw": fs, "write_size_kb_raw": ws,
             "correction": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024", "simulations_per_launch": sims,
-            "kernel": "mz::mz_resnet_search_kernel<false, true> (128 roots, pair mode)",
+            "kernel": "mz::mz_resnet_search_kernel<false, true, true, 2> (MuZero policy, pair mode, tree statistics in LDS, two action slots; 128 roots)",
             "mfma_busy": {"value": round(busy / (gui / 8 * 1024), 4), "simulations_per_launch": sims,
                           "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)"},
             "l2_hit_rate": None if not (hit and req) else round(hit / req, 4),

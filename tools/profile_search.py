@@ -115,7 +115,10 @@ def run():
         assert L.mzs_debug_jump_profile(jbuf, 1024 * 8) == 0
         jp = np.frombuffer(jbuf, dtype=np.uint64).reshape(1024, 8).astype(np.float64) / (n * S)
         jp = jp[jp.sum(1) > 0]
-        names = ["path + expand", "per-level inputs", "discounted-return chain", "new values + write back", "decisions of the path",
+        # (pair mode: path and inputs are prefetched in idle convolution passes and the chain runs beside the expansion on
+        # the second wavefront -- slots 1 and 2 stay empty there)
+        names = ["path + expand (pair mode: || chain)", "per-level inputs", "discounted-return chain", "new values + write back",
+                 "decisions of the path",
                  "JUMP records (pointer jumping) + stores", "next selection"]
         print(f"# tree step by phase ({len(jp)} workgroups): " + ", ".join(f"{nm} {jp[:, k].mean() / 2400:.2f}" for k, nm in enumerate(names))
               + (f" [slot 7: {jp[:, 7].mean() / 2400:.2f}]" if jp[:, 7].any() else ""))

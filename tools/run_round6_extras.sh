@@ -16,6 +16,8 @@ cd $REPO
 timeout 600 bash tools/rocprof_tower_pmc.sh 200 > $OUT/tower_pmc.txt 2>&1
 cd $REPO
 timeout 300 python tools/profile_search.py run 2>&1 | grep -v amdgpu.ids > $OUT/search_phases.txt
+# (tools/bin/libmzsearch_prof_heads.so: MZ_PROF_HEADS=1 python tools/profile_search.py build)
+MZ_PROF_HEADS=1 timeout 300 python tools/profile_search.py run 2>&1 | grep -v amdgpu.ids > $OUT/search_phases_heads.txt
 for r in 1 2 3; do for v in 1 0; do echo -n "rep $r MZS_SEARCH_LDS_TREE=$v: "; MZS_SEARCH_LDS_TREE=$v timeout 120 python tools/bench_atari.py 128 200 2>&1 | grep -v amdgpu.ids | tail -1; done; done > $OUT/ab_ldstree.txt 2>&1
 timeout 300 python tools/bench_generic.py --round6 2>&1 | grep -v amdgpu.ids > $OUT/generic.txt
 timeout 300 python tools/bench_generic.py 2>&1 | grep -v amdgpu.ids >> $OUT/generic.txt

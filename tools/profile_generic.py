@@ -10,6 +10,9 @@ from muax_amd import MuZeroSearch, SearchConfig, _lib
 L = _lib.load()
 L.mzs_debug_generic_jump_profile.argtypes = [C.c_void_p, C.c_int32]
 B, od, E, A, S = 4096, 4, 8, 2, 50
+if len(sys.argv) > 1:  # python tools/profile_generic.py A [S] [E] [B]
+    A = int(sys.argv[1]); S = int(sys.argv[2]) if len(sys.argv) > 2 else S; E = int(sys.argv[3]) if len(sys.argv) > 3 else E
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else B
 w = haiku_style_weights(0, od, E, A, 21)
 s = MuZeroSearch(B, SearchConfig(A, S, E, tiebreak=True))
 s.set_mlp_weights(w, od, 10, 0.99)
@@ -27,6 +30,6 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 L.mzs_debug_generic_jump_profile(buf, 1024 * 8)
 jp = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.float64)
 # blockIdx & 1023 aliases 4 blocks per slot
-jp = jp / (n * S * 4)
+jp = jp / (n * S * max(1, B // 1024))
 names = ["path + expand", "per-level inputs", "chain", "values + write back", "decisions", "JUMP + stores", "next selection"]
-print(f"generic act {dt*1e3:.3f} ms = {dt/S*1e6:.2f} us/sim; tree step phases (us at 2.1 GHz, per sim per root): " + ", ".join(f"{nm} {jp[:, k].mean()/2100:.2f}" for k, nm in enumerate(names)), "sum", jp[:, :7].sum(1).mean()/2100)
+print(f"B={B} A={A} E={E} S={S} depth {float(s.depth_sum.float().mean()) / S:.1f}: generic act {dt*1e3:.3f} ms = {dt/S*1e6:.2f} us/sim; tree step phases (us at 2.1 GHz, per sim per root): " + ", ".join(f"{nm} {jp[:, k].mean()/2100:.2f}" for k, nm in enumerate(names)), "sum", jp[:, :7].sum(1).mean()/2100)

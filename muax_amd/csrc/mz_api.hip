@@ -291,14 +291,20 @@ static void launch_mlp_search(const mzs_config& c, const mz::StepArgs& sa, const
                               size_t lds_search, hipStream_t stream) {
   const size_t lds_tbl = lds_search + sizeof(float) * 2 * ((size_t)sa.S + 2);
   const bool tbl = sa.S + 2 <= 1030 && lds_tbl <= 64 * 1024;  // (Markstein's sequence is checked for every divisor up to 1030)
-  if (c.policy == 1)
-    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<true>), dim3(n), dim3(64), lds_search, stream, sa, ja, g, 0, sa.S);
-  else if (tbl && sa.A <= 16)
-    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<false, 1, true>), dim3(n), dim3(64), lds_tbl, stream, sa, ja, g, 0, sa.S);
-  else if (tbl && sa.A <= 32)
-    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<false, 2, true>), dim3(n), dim3(64), lds_tbl, stream, sa, ja, g, 0, sa.S);
-  else
-    hipLaunchKernelGGL((mz::mz_mlp_search_kernel<false>), dim3(n), dim3(64), lds_search, stream, sa, ja, g, 0, sa.S);
+  // the 128-register build (four wavefronts per SIMD, mz_mlp_generic.cuh) where it puts MORE roots on the chip: more roots
+  // than two wavefronts per SIMD hold, and workgroups small enough that sixteen share a CU's LDS
+  const size_t lds = (c.policy != 1 && tbl && sa.A <= 32) ? lds_tbl : lds_search;
+  const bool occ4 = n > 2 * 4 * 256 && 16 * lds <= 160 * 1024;
+#define MZ_GEN_LAUNCH(...)                                                                                            \
+  do {                                                                                                                \
+    if (occ4) hipLaunchKernelGGL((mz::mz_mlp_search_kernel_occ4<__VA_ARGS__>), dim3(n), dim3(64), lds, stream, sa, ja, g, 0, sa.S); \
+    else hipLaunchKernelGGL((mz::mz_mlp_search_kernel<__VA_ARGS__>), dim3(n), dim3(64), lds, stream, sa, ja, g, 0, sa.S);           \
+  } while (0)
+  if (c.policy == 1) MZ_GEN_LAUNCH(true);
+  else if (tbl && sa.A <= 16) MZ_GEN_LAUNCH(false, 1, true);
+  else if (tbl && sa.A <= 32) MZ_GEN_LAUNCH(false, 2, true);
+  else MZ_GEN_LAUNCH(false);
+#undef MZ_GEN_LAUNCH
 }
 // rows [rb, rb + n) of the step-wise tree as a batch of their own: every per-root array starts at row rb, the PRNG streams
 // stay those of the global root index (root_offset + rb)

@@ -32,20 +32,27 @@ struct MlpGen {
 constexpr int kGenHidden = 16;  // hk.Linear(16) everywhere in muax/nn.py:73-115
 
 // haiku Linear, output j: dot (k-ordered fma chain from 0) then + bias; x in LDS (every lane reads the same word)
+// U32: the weights indexed from the UNIFORM base with a 32-bit per-lane offset (global_load saddr + voffset) instead of
+// through the per-lane pointer `w + j`.  That pointer is loop-invariant for the whole search and the compiler keeps one
+// register pair per weight array alive across every simulation -- ~40 of the search kernel's 215 VGPRs; the 32-bit form
+// costs an address add per load (1 - 3 % at equal occupancy) and is what lets the four-wavefront build of the search
+// kernel (mz_mlp_search_kernel_occ4) get by with two dozen spilled loop invariants instead of 66 registers
+template <bool U32 = false>
 MZ_DEV float gen_linear(const float* x, int n_in, const float* __restrict__ w, const float* __restrict__ b, int n_out, int j) {
   // the weights of eight links are requested before the first of their fmas issues (one link at a time is one L1 / L2
   // round trip per link: ~0.5 us each on a lone chain); the chain itself stays k-ordered
   float acc = 0.0f;
   const float* wj = w + j;
+  auto wt = [&](int i) { return U32 ? w[(unsigned)(i * n_out + j)] : wj[(size_t)i * n_out]; };
   int i = 0;
   for (; i + 8 <= n_in; i += 8) {
     float wv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) wv[k] = wj[(size_t)(i + k) * n_out];
+    for (int k = 0; k < 8; ++k) wv[k] = wt(i + k);
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = __builtin_fmaf(x[i + k], wv[k], acc);
   }
-  for (; i < n_in; ++i) acc = __builtin_fmaf(x[i], wj[(size_t)i * n_out], acc);
+  for (; i < n_in; ++i) acc = __builtin_fmaf(x[i], wt(i), acc);
   return acc + b[j];
 }
 // muax/nn.py:37-44 over a vector of n floats in LDS, by one wavefront (min / max do not depend on the order)
@@ -91,16 +98,17 @@ MZ_DEV GenLds gen_lds(float* f, int E, int A) {
   return G;
 }
 // Prediction on the embedding `s` (LDS): value logits -> G.vl, prior logits -> G.pl, value -> G.scal[1]
+template <bool U32 = false>
 MZ_DEV void gen_prediction(const MlpGen& w, const GenLds& G, const float* s, int tid) {
   const int E = w.E, A = w.A, F = w.F;
   if (tid < 32) {
     const int u = tid & 15;
-    const float a = (tid < 16) ? gen_linear(s, E, w.pv_w1, w.pv_b1, kGenHidden, u) : gen_linear(s, E, w.pp_w1, w.pp_b1, kGenHidden, u);
+    const float a = (tid < 16) ? gen_linear<U32>(s, E, w.pv_w1, w.pv_b1, kGenHidden, u) : gen_linear<U32>(s, E, w.pp_w1, w.pp_b1, kGenHidden, u);
     G.hid[tid] = elu(a);
   }
   __syncthreads();
-  for (int j = tid; j < F; j += 64) G.vl[j] = gen_linear(G.hid, kGenHidden, w.pv_w2, w.pv_b2, F, j);
-  for (int j = tid; j < A; j += 64) G.pl[j] = gen_linear(G.hid + 16, kGenHidden, w.pp_w2, w.pp_b2, A, j);
+  for (int j = tid; j < F; j += 64) G.vl[j] = gen_linear<U32>(G.hid, kGenHidden, w.pv_w2, w.pv_b2, F, j);
+  for (int j = tid; j < A; j += 64) G.pl[j] = gen_linear<U32>(G.hid + 16, kGenHidden, w.pp_w2, w.pp_b2, A, j);
   __syncthreads();
   if (tid < 16) {
     const float v = gen_decode(G.vl, F, w.support, tid);
@@ -132,9 +140,8 @@ __global__ __launch_bounds__(64) void mz_mlp_root_kernel(const MlpGen w, int B, 
 // AS (round 6, MuZero policy): the 16-lane slots the action count fills (1: A <= 16, 2: A <= 32; 0: any A <= 64) -- the tree
 // step's decision refresh without the run-time tests of the general code's four slots (mz_step_jump.cuh, level_load); TBL:
 // the {sqrt(n) pb_c(n), RN(1 / n)} table behind the trio's scratch (visit counts up to 1030: Markstein's checked range)
-template <bool GUMBEL, int AS = 0, bool TBL = false>
-__global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, const JumpArgs g, const MlpGen w, int sim_begin,
-                                                           int sim_end) {
+template <bool GUMBEL, int AS, bool TBL, bool U32>
+MZ_DEV void mlp_search_body(const StepArgs& s, const JumpArgs& g, const MlpGen& w, int sim_begin, int sim_end) {
   extern __shared__ int gen_i[];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (r >= s.B) return;
@@ -174,13 +181,13 @@ __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, con
     __syncthreads();
     if (tid < 32) {
       const int u = tid & 15;
-      const float a = (tid < 16) ? gen_linear(G.sa, E + A, w.dr_w1, w.dr_b1, kGenHidden, u)
-                                 : gen_linear(G.sa, E + A, w.dn_w1, w.dn_b1, kGenHidden, u);
+      const float a = (tid < 16) ? gen_linear<U32>(G.sa, E + A, w.dr_w1, w.dr_b1, kGenHidden, u)
+                                 : gen_linear<U32>(G.sa, E + A, w.dn_w1, w.dn_b1, kGenHidden, u);
       G.hid[tid] = elu(a);
     }
     __syncthreads();
-    for (int j = tid; j < w.F; j += 64) G.rl[j] = gen_linear(G.hid, kGenHidden, w.dr_w2, w.dr_b2, w.F, j);
-    for (int e = tid; e < E; e += 64) G.ns[e] = gen_linear(G.hid + 16, kGenHidden, w.dn_w2, w.dn_b2, E, e);
+    for (int j = tid; j < w.F; j += 64) G.rl[j] = gen_linear<U32>(G.hid, kGenHidden, w.dr_w2, w.dr_b2, w.F, j);
+    for (int e = tid; e < E; e += 64) G.ns[e] = gen_linear<U32>(G.hid + 16, kGenHidden, w.dn_w2, w.dn_b2, E, e);
     __syncthreads();
     gen_min_max_normalize(G.ns, E, tid);
     __syncthreads();
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, con
       const float rw = gen_decode(G.rl, w.F, w.support, tid & 15);
       if (tid == 48) G.scal[0] = rw;
     }
-    gen_prediction(w, G, w.pred_on_parent ? G.sa : G.ns, tid);
+    gen_prediction<U32>(w, G, w.pred_on_parent ? G.sa : G.ns, tid);
     const float rew = G.scal[0], val = G.scal[1];
     const int known[4] = {parent, action, depth, newn};
     int sel[3] = {0, 0, 0};
@@ -205,6 +212,21 @@ __global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, con
     }
     __syncthreads();
   }
+}
+// As compiled the search needs 215 .. 225 VGPRs = TWO wavefronts per SIMD: 2048 roots resident, 4096 roots two rounds (per
+// simulation 18.6 us at 1024 roots, 21.7 at 2048, 41.9 at 4096).  _occ4: the same body held to 128 registers (four
+// wavefronts per SIMD; ~25 loop invariants spilled to scratch) for launches of more roots than two wavefronts per SIMD
+// hold whose workgroups fit sixteen to a CU's LDS -- 1.2 - 1.3x there, slower everywhere else (the host chooses:
+// mz_api.hip, launch_mlp_search; both measured in profiles/r06_generic_notes.txt).
+template <bool GUMBEL, int AS = 0, bool TBL = false>
+__global__ __launch_bounds__(64) void mz_mlp_search_kernel(const StepArgs s, const JumpArgs g, const MlpGen w, int sim_begin,
+                                                           int sim_end) {
+  mlp_search_body<GUMBEL, AS, TBL, false>(s, g, w, sim_begin, sim_end);
+}
+template <bool GUMBEL, int AS = 0, bool TBL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void mz_mlp_search_kernel_occ4(
+    const StepArgs s, const JumpArgs g, const MlpGen w, int sim_begin, int sim_end) {
+  mlp_search_body<GUMBEL, AS, TBL, true>(s, g, w, sim_begin, sim_end);
 }
 
 }  // namespace mz

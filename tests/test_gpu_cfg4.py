@@ -532,7 +532,8 @@ def test_one_launch_search_on_paths_deeper_than_a_wavefront():
     edge's reward / discount patched in from registers (mz_step_jump.cuh, return_chain).  A path of EXACTLY 64 levels
     puts the last edge alone in the upper chunk, where lane 63 of the lower chunk has the same level index: the case a
     first version of the patch got wrong with every other test green.  Pair mode against the loop of per-simulation
-    launches (no prefetch, chain after the expansion): every tree array, actions, weights, depth sums, bit for bit."""
+    launches (no prefetch, chain after the expansion) and against the one launch with one workgroup per root: every tree
+    array, actions, weights, depth sums, bit for bit."""
     B, S = 128, S_FULL
     m, mods, obs = _bench_nets(B)
     dy, pred = mods[2], mods[1]
@@ -548,16 +549,24 @@ def test_one_launch_search_on_paths_deeper_than_a_wavefront():
 
     assert dy.hip_search_ok(pred, (6, 6, 64), SUPPORT)
     outs = []
-    for loop in (None, native):
+    for loop, pair in ((None, True), (native, True), (native, False)):  # the last: the one launch with one workgroup per root
+        dy.use_pair_tower = pair
+        if not pair:
+            dy._pair_scratch.clear()
         s = mx.MuZeroSearch(B, mx.SearchConfig(A, S, 2304, tiebreak=True))
         o = s.search((pl, v, emb.reshape(B, -1)), rec, key=[12, B], with_tree=True, native_loop=loop, dirichlet_noise=noise)
         torch.cuda.synchronize()
         if loop is not None:
-            assert not getattr(s, "_native_loop_unusable", False) and dy._pair_scratch and not dy.pair_lost()
+            assert not getattr(s, "_native_loop_unusable", False)
+            assert bool(dy._pair_scratch) == pair and not dy.pair_lost()
         outs.append((o.action.clone(), o.action_weights.clone(), s.depth_sum.clone(),
                      {f: getattr(o.search_tree, f).clone() for f in o.search_tree._fields}))
         s.close()
-    (a0, w0, d0, t0), (a1, w1, d1, t1) = outs
+    dy.__dict__.pop("use_pair_tower", None)
+    (a0, w0, d0, t0), (a1, w1, d1, t1), (a2, w2, d2, t2) = outs
+    assert torch.equal(d1, d2) and torch.equal(a1, a2) and torch.equal(w1, w2)
+    for f in t1:
+        assert torch.equal(t1[f], t2[f]), ("one workgroup per root", f, int((t1[f] != t2[f]).sum()))
     par = t0["parents"].cpu().numpy()
     depth = np.zeros_like(par)
     for k in range(1, S + 1):

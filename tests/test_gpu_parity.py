@@ -527,13 +527,15 @@ def test_gumbel_fused_wide_and_long_instances_built_on_demand(oracle, A, E, S, B
 @pytest.mark.parametrize("A,E,S,B,policy", [(18, 8, 50, 130, "muzero"), (2, 8, 300, 40, "muzero"), (4, 100, 40, 25, "muzero"),
                                             (33, 20, 70, 21, "muzero"), (18, 8, 40, 50, "gumbel"), (2, 8, 260, 9, "gumbel"),
                                             (18, 8, 30, 2100, "muzero"), (5, 70, 20, 2200, "muzero"), (33, 12, 20, 2100, "muzero"),
+                                            (1, 70, 130, 6, "muzero"), (1, 70, 70, 2100, "muzero"),
                                             (20, 8, 20, 2100, "gumbel")])
 def test_generic_one_launch_search_matches_oracle(oracle, A, E, S, B, policy):
     """What no instance of the fused kernel can serve -- 18 / 33 actions, 260 / 300 simulations, a 100-wide embedding --
     through mzs_act_mlp's generic route (mz_mlp_generic.cuh: the trio with run-time shapes, tree in HBM, one launch for
     all simulations): every tree array, actions, weights, values and depth sums equal to the oracle's, both policies.
     More than 2048 roots of a short search take the kernel's 128-register build (four wavefronts per SIMD, weights through
-    32-bit offsets, a dozen loop invariants in scratch): one case per variant of it (two / one / any action slots, Gumbel)."""
+    32-bit offsets, a dozen loop invariants in scratch): one case per variant of it (two / one / any action slots, Gumbel).
+    One action: the tree is a chain, paths of 70 / 130 levels (the return chain's 63-level chunks, pointer jumping in LDS)."""
     case = make_case(oracle, 500 + A + E, B, 6, E, A, S, invalid_frac=0.2 if A > 2 else 0.0)
     key = [77, S]
     if policy == "muzero":

@@ -953,7 +953,6 @@ __global__ __launch_bounds__(C::THREADS, (C::PH && !C::LONG) ? 2 : 1) void mz_ac
   int32_t* gpath = C::PH ? p.path_scratch + (size_t)r * N * C::PATHW : nullptr;
 
   if constexpr (!C::PK) nets.load(p, j);
-
   // ---- tree init (mctx instantiate_tree_from_root) ----
   // all-zero records written 16 bytes per lane, then children_index = -1 (same wave: LDS keeps the order)
   {
@@ -988,11 +987,26 @@ __global__ __launch_bounds__(C::THREADS, (C::PH && !C::LONG) ? 2 : 1) void mz_ac
     for (int t = 0; t < C::ES; ++t) {
       int k = j + 16 * t;
       float acc = 0.0f;
-      if (k < E) {
-        for (int i = 0; i < p.obs_dim; ++i) acc = __builtin_fmaf(ob[i], p.repr_w[i * E + k], acc);
-        acc = acc + p.repr_b[k];
+      {
+        // four links' operands requested before the first of their fmas issues (obs_dim is a run-time count: one link at a
+        // time was one memory round trip per link -- eight in a row for LunarLander); lanes past E compute a value nobody
+        // reads from a clamped column instead of branching around the loads
+        const int kc = k < E ? k : 0;
+        int i = 0;
+        for (; i + 4 <= p.obs_dim; i += 4) {
+          float o4[4], w4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o4[q] = ob[i + q];
+            w4[q] = p.repr_w[(i + q) * E + kc];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(o4[q], w4[q], acc);
+        }
+        for (; i < p.obs_dim; ++i) acc = __builtin_fmaf(ob[i], p.repr_w[i * E + kc], acc);
+        acc = acc + p.repr_b[kc];
       }
-      s[t] = acc;
+      s[t] = k < E ? acc : 0.0f;
     }
     row_min_max_normalize<E>(s, j);
   }
